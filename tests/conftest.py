@@ -1,0 +1,71 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are skipped automatically when no device is visible
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        with np.load(os.path.join(GOLD, name + ".npz")) as z:
+            return {k: torch.from_numpy(z[k]) for k in z.files}
+    return load
+
+
+@pytest.fixture(scope="session")
+def specs():
+    with open(os.path.join(GOLD, "specs.json")) as f:
+        return json.load(f)
+
+
+def formula_sd(spec):
+    """State dict with the deterministic formula weights for a golden spec."""
+    from oracle.mvlt_oracle import formula_fill
+    return formula_fill([(k, tuple(s), getattr(torch, d)) for k, s, d in spec])
+
+
+def synth_batch(B, T, seed, vocab=30522):
+    """Same generator as tests/golden/make_golden.py:synth_batch."""
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, 224, 224, generator=g)
+    ids = torch.zeros(B, T, dtype=torch.long)
+    labels = torch.full((B, T), -100, dtype=torch.long)
+    for b in range(B):
+        ln = int(torch.randint(max(4, T // 4), T, (1,), generator=g))
+        row = torch.randint(1000, vocab, (ln,), generator=g)
+        row[-1] = 104
+        nm = min(10, max(1, round(0.2 * ln)))
+        pos = torch.randperm(ln, generator=g)[:nm]
+        labels[b, pos] = row[pos]
+        row[pos[: max(1, int(0.8 * nm))]] = 103
+        ids[b, :ln] = row
+    itm = torch.randint(0, 2, (B,), generator=g)
+    return image, ids, labels, itm
+
+
+def rel_err(a, b):
+    a = a.double()
+    b = b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))

@@ -1,0 +1,425 @@
+"""Generate golden vectors by importing the REAL reference (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference (/root/reference) is Python and cannot travel to the GPU box, so
+this script runs it HERE on CPU with deterministic formula weights
+(oracle.mvlt_oracle.formula_fill -- both sides can regenerate them) and stores
+only inputs' seeds and expected *outputs* as small fixtures.  No reference
+source is copied: the reference is imported as a library.
+
+Dependency shims (absent here: torchvision, timm, yacs; HF 5.x removed
+BeamSearchScorer) follow SURVEY.md section 8(c).
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def install_shims():
+    import transformers  # noqa: F401  (must be first)
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    tv = mod("torchvision")
+    tvm = mod("torchvision.models", ResNet=_Dummy, VisionTransformer=_Dummy)
+    res = mod("torchvision.models.resnet", ResNet=_Dummy, Bottleneck=_Dummy, BasicBlock=_Dummy,
+              model_urls={})
+    vit = mod("torchvision.models.vision_transformer", VisionTransformer=_Dummy, model_urls={})
+    tv.models = tvm
+    tvm.resnet = res
+    tvm.vision_transformer = vit
+    try:
+        from torch.hub import load_state_dict_from_url
+    except Exception:  # pragma: no cover
+        load_state_dict_from_url = None
+    mod("torchvision._internally_replaced_utils", load_state_dict_from_url=load_state_dict_from_url)
+    mod("torchvision.utils")
+
+    class DropPath(nn.Module):
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            if self.drop_prob == 0.0 or not self.training:
+                return x
+            keep = 1 - self.drop_prob
+            m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            return x * m / keep
+
+    timm = mod("timm")
+    tm = mod("timm.models")
+    tl = mod("timm.models.layers", DropPath=DropPath, to_2tuple=lambda v: (v, v) if not isinstance(v, tuple) else v,
+             trunc_normal_=nn.init.trunc_normal_)
+    timm.models = tm
+    tm.layers = tl
+
+    class CfgNode(dict):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+
+        def __getattr__(self, k):
+            return self[k]
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def clone(self):
+            return self
+
+        def defrost(self):
+            pass
+
+        def freeze(self):
+            pass
+
+    yacs = mod("yacs")
+    yc = mod("yacs.config", CfgNode=CfgNode)
+    yacs.config = yc
+
+    # importing a transformers submodule can re-register the lazy top-level
+    # module, so patch the object that is in sys.modules AFTER those imports
+    import transformers.models.bert.modeling_bert  # noqa: F401
+    from transformers import PreTrainedModel, LogitsProcessorList  # noqa: F401
+    tr = sys.modules["transformers"]
+    if "BeamSearchScorer" not in tr.__dict__:
+        tr.BeamSearchScorer = type("BeamSearchScorer", (), {})
+
+
+def swin_ns(embed_dim=96, depths=(2, 2, 18, 2), heads=(3, 6, 12, 24), dpr=0.3):
+    S = types.SimpleNamespace
+    return S(DATA=S(IMG_SIZE=224),
+             MODEL=S(NUM_CLASSES=1000, DROP_RATE=0.0, DROP_PATH_RATE=dpr,
+                     SWIN=S(PATCH_SIZE=4, IN_CHANS=3, EMBED_DIM=embed_dim, DEPTHS=list(depths),
+                            NUM_HEADS=list(heads), WINDOW_SIZE=7, MLP_RATIO=4.0, QKV_BIAS=True,
+                            QK_SCALE=None, APE=False, PATCH_NORM=True)),
+             TRAIN=S(USE_CHECKPOINT=False))
+
+
+def import_reference(swin_cfg):
+    sys.path.insert(0, REF)
+    import modules.model as M
+    M.parse_option = lambda: (None, swin_cfg)
+    M.torch.load = lambda *a, **k: {"model": {}}
+    return M
+
+
+def make_config(M, cls, **over):
+    import modules.config as C
+    cfg = getattr(C, cls)()
+    cfg.conv = "swintransformer"
+    cfg.cls_token_id, cfg.sep_token_id, cfg.mask_token_id, cfg.eos_token_id = 101, 102, 103, 104
+    cfg.vocab_size = 30522
+    cfg._attn_implementation = "eager"
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+SPECS = {}
+
+
+def fill_formula(model, spec_name=None):
+    from oracle.mvlt_oracle import formula_fill
+    sd = model.state_dict()
+    spec = [(k, tuple(v.shape), v.dtype) for k, v in sd.items()]
+    new = formula_fill(spec)
+    with torch.no_grad():
+        for k, v in new.items():
+            sd[k].copy_(v)
+    out = [(k, list(s), str(d).replace("torch.", "")) for k, s, d in spec]
+    if spec_name is not None:
+        SPECS[spec_name] = out
+    return out
+
+
+def synth_batch(B, T, seed, vocab=30522):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, 224, 224, generator=g)
+    ids = torch.zeros(B, T, dtype=torch.long)
+    labels = torch.full((B, T), -100, dtype=torch.long)
+    for b in range(B):
+        ln = int(torch.randint(max(4, T // 4), T, (1,), generator=g))
+        row = torch.randint(1000, vocab, (ln,), generator=g)
+        row[-1] = 104
+        nm = min(10, max(1, round(0.2 * ln)))
+        pos = torch.randperm(ln, generator=g)[:nm]
+        labels[b, pos] = row[pos]
+        row[pos[: max(1, int(0.8 * nm))]] = 103
+        ids[b, :ln] = row
+    itm = torch.randint(0, 2, (B,), generator=g)
+    return image, ids, labels, itm
+
+
+def to_np(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def int_tables(M):
+    """INT rows a2-a5, a13, a21 straight from reference code paths."""
+    import modules.visual_feature_extractor as V
+    out = {}
+    wa = V.WindowAttention(96, (7, 7), 3)
+    out["relative_position_index"] = wa.relative_position_index.clone()
+    for H in (56, 28, 14):
+        blk = V.SwinTransformerBlock(32, (H, H), 1, window_size=7, shift_size=3)
+        out[f"attn_mask_{H}"] = (blk.attn_mask != 0).to(torch.int8)
+        out[f"attn_mask_val_{H}"] = torch.tensor([blk.attn_mask.min().item(), blk.attn_mask.max().item()])
+        idx = torch.arange(H * H, dtype=torch.float32).view(1, H, H, 1)
+        out[f"winmap_noshift_{H}"] = V.window_partition(idx, 7).reshape(-1).long()
+        rolled = torch.roll(idx, shifts=(-3, -3), dims=(1, 2))
+        wm = V.window_partition(rolled, 7).reshape(-1).long()
+        out[f"winmap_shift_{H}"] = wm
+        # inverse path: window_reverse + roll(+3) must put token t back at t
+        back = torch.roll(V.window_reverse(wm.float().view(-1, 7, 7, 1), 7, H, H), shifts=(3, 3), dims=(1, 2))
+        assert torch.equal(back.reshape(-1).long(), torch.arange(H * H))
+        pm = V.PatchMerging((H, H), 1)       # reference gather order, norm/reduction bypassed
+        pm.norm, pm.reduction = nn.Identity(), nn.Identity()
+        out[f"mergemap_{H}"] = pm(idx.view(1, H * H, 1)).view(-1, 4).long()
+    blk = V.SwinTransformerBlock(32, (7, 7), 1, window_size=7, shift_size=3)
+    out["stage3_shift"] = torch.tensor([blk.shift_size, 0 if blk.attn_mask is None else 1])
+
+    cfg = make_config(M, "MVLBertPretrainConfig")
+    cfg.num_hidden_layers = 1
+    mv = M.MVLBert(cfg, add_pooling_layer=False)
+    with torch.no_grad():
+        mv.word_embeddings.weight.zero_()
+        mv.position_embeddings.weight.copy_(torch.arange(512.0)[:, None].expand(512, 768))
+        mv.token_type_embeddings.weight.copy_(1000.0 * torch.arange(3.0)[:, None].expand(3, 768))
+    B, T = 3, 80
+    ids = torch.zeros(B, T, dtype=torch.long)
+    for b, ln in enumerate((80, 17, 1)):
+        ids[b, :ln] = 2000 + torch.arange(ln)
+    img = torch.zeros(B, 49, 768)
+    imask = torch.ones(B, 49, dtype=torch.bool)
+    emb, am, obj_end, text_end = mv.get_embedding(ids, ids > 0, img, imask, seq2seq_mask=False)
+    code = emb[0, :, 0].round().long()
+    out["vl_position_ids"] = code % 1000
+    out["vl_token_type_ids"] = code // 1000
+    out["vl_bidir_mask"] = am.to(torch.int8)
+    out["vl_obj_end_text_end"] = torch.tensor([int(obj_end), int(text_end)])
+    out["vl_text_ids"] = ids
+    _, am2, _, _ = mv.get_embedding(ids, ids > 0, img, imask, seq2seq_mask=True)
+    assert bool((am2[0] == am2[1]).all())
+    out["vl_seq2seq_mask"] = am2[0].to(torch.int8)
+    ext = mv.get_extended_attention_mask(am)
+    out["vl_ext_mask_vals"] = torch.tensor([ext.min().item(), ext.max().item()])
+    out["vl_ext_mask_shape"] = torch.tensor(list(ext.shape))
+    for past in (51, 60):
+        pk = [(torch.zeros(B, 12, past, 64), torch.zeros(B, 12, past, 64))]
+        e2, m2, _, _ = mv.get_embedding(ids[:, :2], None, img, imask, seq2seq_mask=True, past_key_values=pk)
+        out[f"cache_pos_{past}"] = (e2[0, :, 0].round().long() % 1000)
+        out[f"cache_type_{past}"] = (e2[0, :, 0].round().long() // 1000)
+        out[f"cache_mask_{past}"] = m2[0].to(torch.int8)
+    return out
+
+
+def swin_full(M):
+    import modules.visual_feature_extractor as V
+    torch.manual_seed(0)
+    sw = V.SwinTransformer(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], drop_path_rate=0.3)
+    fill_formula(sw, 'swin_s')
+    sw.eval()
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(2, 3, 224, 224, generator=g)
+    taps = {}
+    with torch.no_grad():
+        x = sw.patch_embed(img)
+        taps["patch_embed_head"] = x[:, :8].clone()
+        for s, layer in enumerate(sw.layers):
+            x = layer(x)
+            taps[f"stage{s}_head"] = x[:, :4].clone()
+        out = sw.norm(x)
+    taps["out"] = out
+    taps["img_seed"] = torch.tensor(11)
+    # one isolated block of each kind at stage-2 width, B_=8 windows
+    blk_taps = {}
+    for H, C, nH, tag in ((56, 96, 3, "s0"), (28, 192, 6, "s1"), (14, 384, 12, "s2"), (7, 768, 24, "s3")):
+        for shift in (0, 3):
+            b = V.SwinTransformerBlock(C, (H, H), nH, window_size=7, shift_size=shift, drop_path=0.0)
+            fill_formula(b, f'block_{tag}_shift{shift}')
+            b.eval()
+            xin = torch.randn(1, H * H, C, generator=torch.Generator().manual_seed(100 + H + shift))
+            with torch.no_grad():
+                y = b(xin)
+                xw = V.window_partition(b.norm1(xin).view(1, H, H, C), b.window_size).view(-1, 49, C)
+                aw = b.attn(xw, mask=b.attn_mask)
+            blk_taps[f"block_{tag}_shift{shift}_out_head"] = y[:, :49].clone()
+            blk_taps[f"block_{tag}_shift{shift}_out_sum"] = y.double().sum().float()
+            blk_taps[f"wattn_{tag}_shift{shift}_win0"] = aw[0].clone()
+            blk_taps[f"wattn_{tag}_shift{shift}_winlast"] = aw[-1].clone()
+    for H, C, tag in ((56, 96, "s0"), (28, 192, "s1"), (14, 384, "s2")):
+        pm = V.PatchMerging((H, H), C)
+        fill_formula(pm, f'merge_{tag}')
+        xin = torch.randn(1, H * H, C, generator=torch.Generator().manual_seed(200 + H))
+        with torch.no_grad():
+            blk_taps[f"merge_{tag}_head"] = pm(xin)[:, :16].clone()
+    taps.update(blk_taps)
+    return taps
+
+
+def full_models(M):
+    out = {}
+    # ---------------- pretrain model, full size -----------------
+    cfg = make_config(M, "MVLBertPretrainConfig")
+    cfg.ITM_task = True
+    torch.manual_seed(0)
+    model = M.MVLBertForPretraining(cfg)
+    spec = fill_formula(model, 'pretrain')
+    out["pretrain_param_count"] = torch.tensor(sum(p.numel() for p in model.parameters()))
+    model.eval()
+    image, ids, labels, itm = synth_batch(2, 80, seed=21)
+    out["pretrain_ids"], out["pretrain_labels"], out["pretrain_itm"] = ids, labels, itm
+    grad_names = [
+        "conv.conv.0.patch_embed.proj.weight", "conv.conv.0.layers.0.blocks.0.attn.qkv.weight",
+        "conv.conv.0.layers.0.blocks.1.attn.relative_position_bias_table",
+        "conv.conv.0.layers.0.blocks.1.attn.proj.weight", "conv.conv.0.layers.0.downsample.reduction.weight",
+        "conv.conv.0.layers.2.blocks.5.mlp.fc1.weight", "conv.conv.0.layers.2.blocks.17.attn.qkv.bias",
+        "conv.conv.0.layers.3.blocks.1.mlp.fc2.weight", "conv.conv.0.norm.weight",
+        "MVLBert.position_embeddings.weight", "MVLBert.token_type_embeddings.weight",
+        "MVLBert.encoder.layer.0.attention.self.query.weight", "MVLBert.encoder.layer.0.attention.self.key.bias",
+        "MVLBert.encoder.layer.0.attention.output.LayerNorm.weight",
+        "MVLBert.encoder.layer.11.attention.self.value.weight", "MVLBert.encoder.layer.11.intermediate.dense.weight",
+        "MVLBert.encoder.layer.11.output.dense.weight", "MVLBert.pooler.dense.weight",
+        "ITM_mlp.weight",
+    ]
+    for flip, name in ((0.1, "seq2seq"), (0.9, "bidir")):
+        M.random.random = lambda v=flip: v
+        for itm_on in (False, True):
+            cfg.ITM_task = itm_on
+            model.zero_grad(set_to_none=True)
+            loss = model(image, ids, labels, itm)
+            out[f"pretrain_loss_{name}_itm{int(itm_on)}"] = loss.detach().reshape(())
+            if itm_on:
+                loss.backward()
+                sd = dict(model.named_parameters())
+                for gn in grad_names:
+                    g = sd[gn].grad
+                    out[f"grad_{name}_{gn}"] = g.reshape(-1)[:64].clone()
+                    out[f"gradnorm_{name}_{gn}"] = g.double().norm().float()
+                head = "MLM_head_seq2seq" if name == "seq2seq" else "MLM_head_bidir"
+                gdec = sd[f"{head}.predictions.decoder.weight"].grad
+                rows = labels[labels >= 0][:4]
+                out[f"grad_{name}_decoder_rows"] = gdec[rows, :32].clone()
+                gw = sd["MVLBert.word_embeddings.weight"].grad
+                out[f"grad_{name}_wordemb_rows"] = gw[torch.tensor([101, 102, 103, 0, int(ids[0, 0])]), :32].clone()
+        # forward taps (eval): hidden / pooled / logits at labelled rows
+        with torch.no_grad():
+            feat = model.conv(image)
+            t, im, pooled, sep = model.MVLBert(ids, ids > 0, feat, torch.ones(2, 49, dtype=torch.bool),
+                                               seq2seq_mask=(name == "seq2seq"), output_text_image_seperate=True)
+            head = model.MLM_head_seq2seq if name == "seq2seq" else model.MLM_head_bidir
+            logits = head(t)
+            out["feat_head"] = feat[:, :4].clone()
+            out[f"text_out_head_{name}"] = t[:, :4].clone()
+            out[f"image_out_head_{name}"] = im[:, :2].clone()
+            out[f"pooled_{name}"] = pooled.clone()
+            out[f"sep_{name}"] = sep.clone()
+            bi, ti = torch.nonzero(labels >= 0, as_tuple=True)
+            out[f"logits_rows_{name}"] = logits[bi[:4], ti[:4], :256].clone()
+            out[f"logits_lse_{name}"] = torch.logsumexp(logits[bi[:4], ti[:4]], -1)
+    # ---------------- VQA model (config #1), reuse the same conv/MVLBert weights by formula -------------
+    vcfg = make_config(M, "MVLBertConfigforVQA")
+    vqa = M.MVLBertForVQA(vcfg)
+    fill_formula(vqa, 'vqa')
+    vqa.eval()
+    for T in (23, 80):
+        image, ids, _, _ = synth_batch(2, T, seed=31 + T)
+        with torch.no_grad():
+            prob, logits = vqa(image, ids, None)
+        out[f"vqa_ids_T{T}"] = ids
+        out[f"vqa_prob_T{T}"], out[f"vqa_logits_T{T}"] = prob, logits
+    return out
+
+
+def tiny_models(M):
+    """Reduced-width full model (all outputs + every gradient norm) for fast CI."""
+    out = {}
+    M.parse_option = lambda: (None, swin_ns(32, (2, 2, 2, 2), (1, 2, 4, 8), 0.2))
+    cfg = make_config(M, "MVLBertPretrainConfig", hidden_size=256, num_hidden_layers=2,
+                      num_attention_heads=4, intermediate_size=1024, vocab_size=3000)
+    cfg.ITM_task = True
+    model = M.MVLBertForPretraining(cfg)
+    fill_formula(model, 'tiny_pretrain')
+    model.eval()
+    image, ids, labels, itm = synth_batch(3, 24, seed=41, vocab=3000)
+    out["ids"], out["labels"], out["itm"] = ids, labels, itm
+    for flip, name in ((0.1, "seq2seq"), (0.9, "bidir")):
+        M.random.random = lambda v=flip: v
+        model.zero_grad(set_to_none=True)
+        loss = model(image, ids, labels, itm)
+        loss.backward()
+        out[f"loss_{name}"] = loss.detach().reshape(())
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                out[f"gradnorm_{name}_{n}"] = p.grad.double().norm().float()
+                out[f"gradhead_{name}_{n}"] = p.grad.reshape(-1)[:16].clone()
+            else:
+                out[f"gradnone_{name}_{n}"] = torch.tensor(1)
+        with torch.no_grad():
+            feat = model.conv(image)
+            t, im, pooled, sep = model.MVLBert(ids, ids > 0, feat, torch.ones(3, 49, dtype=torch.bool),
+                                               seq2seq_mask=(name == "seq2seq"), output_text_image_seperate=True)
+            out["feat"] = feat
+            out[f"text_{name}"], out[f"pooled_{name}"] = t, pooled
+            head = model.MLM_head_seq2seq if name == "seq2seq" else model.MLM_head_bidir
+            out[f"logits_{name}"] = head(t)[:, :6]
+    # IU-Xray style 5-D input (model.py:240-253)
+    with torch.no_grad():
+        v5 = torch.stack([image, image.flip(0)], 1)
+        out["feat_5d"] = model.conv(v5)
+    # caption model teacher-forced encode_forward + greedy tokens by full recompute
+    ccfg = make_config(M, "MVLBertConfigForImageCaption", hidden_size=256, num_hidden_layers=2,
+                       num_attention_heads=4, intermediate_size=1024, vocab_size=3000)
+    tok = types.SimpleNamespace(mask_token_id=103, sep_token_id=102)
+    cap = M.MVLBertForImageCaption(ccfg, tokenizer=tok)
+    fill_formula(cap, 'tiny_caption')
+    cap.eval()
+    with torch.no_grad():
+        feat = cap.conv(image)
+        logits = cap.encode_forward(feat, ids, learning_strategy="unilm")
+    out["caption_encode_logits_head"] = logits[:, :64, :8].clone()
+    out["caption_encode_shape"] = torch.tensor(list(logits.shape))
+    return out
+
+
+def main():
+    install_shims()
+    torch.set_num_threads(8)
+    M = import_reference(swin_ns())
+    np.savez_compressed(os.path.join(HERE, "int_tables.npz"), **to_np(int_tables(M)))
+    print("int tables done")
+    if "--int-only" in sys.argv:
+        return
+    np.savez_compressed(os.path.join(HERE, "swin_full.npz"), **to_np(swin_full(M)))
+    print("swin done")
+    np.savez_compressed(os.path.join(HERE, "full_models.npz"), **to_np(full_models(M)))
+    print("full models done")
+    np.savez_compressed(os.path.join(HERE, "tiny_models.npz"), **to_np(tiny_models(M)))
+    print("tiny done")
+    import json
+    with open(os.path.join(HERE, "specs.json"), "w") as f:
+        json.dump(SPECS, f)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,224 @@
+"""Pin the CPU oracle (oracle/mvlt_oracle.py) against vectors captured from
+the real reference by tests/golden/make_golden.py.  CPU only."""
+import pytest
+import torch
+
+from conftest import formula_sd, rel_err, synth_batch
+from oracle import mvlt_oracle as O
+
+torch.set_num_threads(8)
+TOL = 2e-5
+
+
+# ---------------------------------------------------------------- INT rows
+def test_int_tables_bit_exact(golden):
+    g = golden("int_tables")
+    assert torch.equal(O.relative_position_index(7), g["relative_position_index"])
+    for H in (56, 28, 14):
+        m = O.shift_attn_mask(H, H, 7, 3)
+        assert torch.equal((m != 0).to(torch.int8), g[f"attn_mask_{H}"])
+        assert m.min().item() == g[f"attn_mask_val_{H}"][0].item() == -100.0
+        assert torch.equal(O.window_token_map(H, H, 7, 0), g[f"winmap_noshift_{H}"])
+        assert torch.equal(O.window_token_map(H, H, 7, 3), g[f"winmap_shift_{H}"])
+        assert torch.equal(O.patch_merge_map(H, H), g[f"mergemap_{H}"])
+    assert g["stage3_shift"].tolist() == [0, 0]          # 7x7 stage: no shift, no mask
+
+
+def test_vl_layout_bit_exact(golden):
+    g = golden("int_tables")
+    lay = O.vl_layout(80, 49)
+    assert torch.equal(lay["position_ids"], g["vl_position_ids"])
+    assert torch.equal(lay["token_type_ids"], g["vl_token_type_ids"])
+    assert [int(lay["obj_end"]), int(lay["text_end"])] == g["vl_obj_end_text_end"].tolist() == [50, 131]
+    ids = g["vl_text_ids"]
+    assert torch.equal(O.bidir_bool_mask(ids, 3, 49).to(torch.int8), g["vl_bidir_mask"])
+    assert torch.equal(O.seq2seq_bool_mask(131, 50).to(torch.int8), g["vl_seq2seq_mask"])
+    am = O.additive_mask(O.bidir_bool_mask(ids, 3, 49))
+    assert list(am.shape) == g["vl_ext_mask_shape"].tolist()
+    assert [am.min().item(), am.max().item()] == g["vl_ext_mask_vals"].tolist() == [-10000.0, 0.0]
+    for past in (51, 60):
+        pos, rows = O.cached_step_rows(past, 2)
+        assert torch.equal(pos, g[f"cache_pos_{past}"])
+        assert torch.equal(rows.to(torch.int8), g[f"cache_mask_{past}"])
+        assert g[f"cache_type_{past}"].tolist() == [0, 0]
+
+
+# ---------------------------------------------------------------- Swin FP
+def test_swin_blocks_and_merging(golden, specs):
+    g = golden("swin_full")
+    for H, C, nH, tag in ((56, 96, 3, "s0"), (28, 192, 6, "s1"), (14, 384, 12, "s2"), (7, 768, 24, "s3")):
+        for shift in (0, 3):
+            sd = formula_sd(specs[f"block_{tag}_shift{shift}"])
+            sd = {"b." + k: v for k, v in sd.items()}
+            x = torch.randn(1, H * H, C, generator=torch.Generator().manual_seed(100 + H + shift))
+            y = O.swin_block(x, sd, "b", H, H, nH, 7, shift, 0.0, O.EVAL)
+            assert rel_err(y[:, :49], g[f"block_{tag}_shift{shift}_out_head"]) < TOL
+            assert abs(y.double().sum().item() - g[f"block_{tag}_shift{shift}_out_sum"].item()) < 1e-3 * max(1.0, abs(g[f"block_{tag}_shift{shift}_out_sum"].item()))
+            # isolated WindowAttention on window 0 / last window
+            eff_shift = 0 if H <= 7 else shift
+            src = O.window_token_map(H, H, 7, 0)           # reference test partitions the UN-rolled LN output
+            xn = O._ln(x, sd, "b.norm1")
+            xw = xn[:, src].reshape(-1, 49, C)
+            mask = O.shift_attn_mask(H, H, 7, 3) if eff_shift > 0 else None
+            aw = O.window_attention(xw, sd, "b.attn", nH, 7, mask)
+            assert rel_err(aw[0], g[f"wattn_{tag}_shift{shift}_win0"]) < TOL
+            assert rel_err(aw[-1], g[f"wattn_{tag}_shift{shift}_winlast"]) < TOL
+    for H, C, tag in ((56, 96, "s0"), (28, 192, "s1"), (14, 384, "s2")):
+        sd = {"m." + k: v for k, v in formula_sd(specs[f"merge_{tag}"]).items()}
+        x = torch.randn(1, H * H, C, generator=torch.Generator().manual_seed(200 + H))
+        assert rel_err(O.patch_merging(x, sd, "m", H, H)[:, :16], g[f"merge_{tag}_head"]) < TOL
+
+
+def test_swin_s_full(golden, specs):
+    g = golden("swin_full")
+    sd = formula_sd(specs["swin_s"])
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(11))
+    taps = {}
+    with torch.no_grad():
+        out = O.swin_forward(img, sd, "", O.SwinCfg(), taps=taps)
+    assert out.shape == (2, 49, 768)
+    assert rel_err(taps["patch_embed"][:, :8], g["patch_embed_head"]) < TOL
+    for s in range(4):
+        assert rel_err(taps[f"stage{s}"][:, :4], g[f"stage{s}_head"]) < 1e-4
+    assert rel_err(out, g["out"]) < 1e-4
+
+
+# ---------------------------------------------------------------- full models
+@pytest.fixture(scope="module")
+def pretrain_sd(specs):
+    sd = formula_sd(specs["pretrain"])
+    return {k: v.requires_grad_(True) for k, v in sd.items()}
+
+
+def test_pretrain_forward_taps(golden, pretrain_sd):
+    g = golden("full_models")
+    sd = {k: v.detach() for k, v in pretrain_sd.items()}
+    assert sum(v.numel() for k, v in sd.items()) == int(g["pretrain_param_count"]) == 208853340
+    image, ids, labels, itm = synth_batch(2, 80, seed=21)
+    assert torch.equal(ids, g["pretrain_ids"]) and torch.equal(labels, g["pretrain_labels"])
+    scfg, bcfg = O.SwinCfg(), O.BertCfg()
+    with torch.no_grad():
+        feat = O.conv_layer(image, sd, scfg)
+        assert rel_err(feat[:, :4], g["feat_head"]) < 1e-4
+        for name in ("seq2seq", "bidir"):
+            o = O.mvlbert_forward(sd, bcfg, ids, feat, name == "seq2seq")
+            assert rel_err(o["text"][:, :4], g[f"text_out_head_{name}"]) < 1e-4
+            assert rel_err(o["image"][:, :2], g[f"image_out_head_{name}"]) < 1e-4
+            assert rel_err(o["pooled"], g[f"pooled_{name}"]) < 1e-4
+            assert rel_err(o["sep"], g[f"sep_{name}"]) < 1e-4
+            logits = O.mlm_head(o["text"], sd, "MLM_head_" + name, bcfg)
+            bi, ti = torch.nonzero(labels >= 0, as_tuple=True)
+            assert rel_err(logits[bi[:4], ti[:4], :256], g[f"logits_rows_{name}"]) < 1e-4
+            assert rel_err(torch.logsumexp(logits[bi[:4], ti[:4]], -1), g[f"logits_lse_{name}"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["seq2seq", "bidir"])
+def test_pretrain_loss_and_grads(golden, pretrain_sd, name):
+    g = golden("full_models")
+    image, ids, labels, itm = synth_batch(2, 80, seed=21)
+    scfg, bcfg = O.SwinCfg(), O.BertCfg()
+    with torch.no_grad():
+        l0 = O.pretrain_loss(pretrain_sd, scfg, bcfg, image, ids, labels, itm, name == "seq2seq", itm_task=False)
+    assert abs(l0.item() - g[f"pretrain_loss_{name}_itm0"].item()) < 1e-4 * abs(l0.item())
+    for v in pretrain_sd.values():
+        v.grad = None
+    loss = O.pretrain_loss(pretrain_sd, scfg, bcfg, image, ids, labels, itm, name == "seq2seq", itm_task=True)
+    assert abs(loss.item() - g[f"pretrain_loss_{name}_itm1"].item()) < 1e-4 * abs(loss.item())
+    loss.backward()
+    keys = [k for k in g if k.startswith(f"gradnorm_{name}_")]
+    assert len(keys) >= 19
+    for k in keys:
+        pn = k[len(f"gradnorm_{name}_"):]
+        gr = pretrain_sd[pn].grad
+        assert abs(gr.double().norm().item() - g[k].item()) < 2e-3 * g[k].item() + 1e-9, pn
+        assert rel_err(gr.reshape(-1)[:64], g[f"grad_{name}_{pn}"]) < 2e-3, pn
+    head = "MLM_head_" + name
+    rows = labels[labels >= 0][:4]
+    assert rel_err(pretrain_sd[f"{head}.predictions.decoder.weight"].grad[rows, :32], g[f"grad_{name}_decoder_rows"]) < 2e-3
+    gw = pretrain_sd["MVLBert.word_embeddings.weight"].grad
+    assert rel_err(gw[torch.tensor([101, 102, 103, 0, int(ids[0, 0])]), :32], g[f"grad_{name}_wordemb_rows"]) < 2e-3
+    # statically unused parameters get no gradient (SURVEY section 7 DDP hazards)
+    for pn in ("conv.conv.0.head.weight", "conv.resnet_fc.weight", "MVLBert.embedding_LayerNorm.weight"):
+        assert pretrain_sd[pn].grad is None
+    other = "MLM_head_bidir" if name == "seq2seq" else "MLM_head_seq2seq"
+    assert pretrain_sd[f"{other}.predictions.decoder.weight"].grad is None
+
+
+def test_vqa_forward(golden, specs):
+    g = golden("full_models")
+    sd = formula_sd(specs["vqa"])
+    for T in (23, 80):
+        image, ids, _, _ = synth_batch(2, T, seed=31 + T)
+        assert torch.equal(ids, g[f"vqa_ids_T{T}"])
+        with torch.no_grad():
+            prob, logits = O.vqa_forward(sd, O.SwinCfg(), O.BertCfg(), image, ids)
+        assert rel_err(logits, g[f"vqa_logits_T{T}"]) < 1e-4
+        assert rel_err(prob, g[f"vqa_prob_T{T}"]) < 1e-4
+
+
+# ---------------------------------------------------------------- tiny models: everything
+TINY_S = O.SwinCfg(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), drop_path_rate=0.2)
+TINY_B = O.BertCfg(vocab_size=3000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4,
+                   intermediate_size=1024)
+
+
+@pytest.mark.parametrize("name", ["seq2seq", "bidir"])
+def test_tiny_all_outputs_and_grads(golden, specs, name):
+    g = golden("tiny_models")
+    sd = {k: v.requires_grad_(True) for k, v in formula_sd(specs["tiny_pretrain"]).items()}
+    image, ids, labels, itm = synth_batch(3, 24, seed=41, vocab=3000)
+    assert torch.equal(ids, g["ids"])
+    taps = {}
+    loss = O.pretrain_loss(sd, TINY_S, TINY_B, image, ids, labels, itm, name == "seq2seq", itm_task=True, taps=taps)
+    assert abs(loss.item() - g[f"loss_{name}"].item()) < 1e-5 * abs(loss.item())
+    assert rel_err(taps["feat"], g["feat"]) < TOL
+    assert rel_err(taps["pooled"], g[f"pooled_{name}"]) < TOL
+    assert rel_err(taps["logits"][:, :6], g[f"logits_{name}"]) < TOL
+    loss.backward()
+    n_checked = 0
+    for k, v in sd.items():
+        if not v.dtype.is_floating_point:
+            continue
+        if f"gradnone_{name}_{k}" in g:
+            assert v.grad is None, k
+        elif f"gradnorm_{name}_{k}" in g:
+            ref = g[f"gradnorm_{name}_{k}"].item()
+            assert abs(v.grad.double().norm().item() - ref) < 1e-3 * ref + 1e-10, k
+            assert rel_err(v.grad.reshape(-1)[:16], g[f"gradhead_{name}_{k}"]) < 1e-3 or ref < 1e-8, k
+            n_checked += 1
+    assert n_checked > 150
+
+
+def test_tiny_5d_and_caption(golden, specs):
+    g = golden("tiny_models")
+    sd = formula_sd(specs["tiny_pretrain"])
+    image, ids, labels, itm = synth_batch(3, 24, seed=41, vocab=3000)
+    with torch.no_grad():
+        f5 = O.conv_layer(torch.stack([image, image.flip(0)], 1), sd, TINY_S)
+    assert f5.shape == (3, 98, 256) and rel_err(f5, g["feat_5d"]) < TOL
+    csd = formula_sd(specs["tiny_caption"])
+    with torch.no_grad():
+        feat = O.conv_layer(image, csd, TINY_S)
+        o = O.mvlbert_forward(csd, TINY_B, ids, feat, True)
+        logits = O.mlm_head(o["text"], csd, "MLM_head_seq2seq", TINY_B).transpose(1, 2)   # [B, V, T] model.py:546
+    assert list(logits.shape) == g["caption_encode_shape"].tolist()
+    assert rel_err(logits[:, :64, :8], g["caption_encode_logits_head"]) < TOL
+
+
+def test_cached_step_equals_recompute(specs):
+    """KV-cache 2-token step (model.py:82-108, :890-894) == full recompute."""
+    csd = formula_sd(specs["tiny_caption"])
+    image, ids, _, _ = synth_batch(2, 6, seed=5, vocab=3000)
+    with torch.no_grad():
+        feat = O.conv_layer(image, csd, TINY_S)
+        # step 0: [CLS] img [SEP] [MASK]
+        inp0 = torch.full((2, 1), 103)
+        o0 = O.mvlbert_forward(csd, TINY_B, inp0, feat, True, return_kv=True)
+        kv = [(k[:, :, :-1], v[:, :, :-1]) for k, v in o0["kv"]]          # drop the MASK slot
+        tok = ids[:, :3]
+        for t in range(3):
+            new = torch.stack([tok[:, t], torch.full((2,), 103)], 1)
+            h, kv2 = O.mvlbert_cached_step(csd, TINY_B, new, kv)
+            full = O.mvlbert_forward(csd, TINY_B, torch.cat([tok[:, :t + 1], inp0], 1), feat, True)
+            assert rel_err(h[:, -1], full["hidden"][:, -1]) < 1e-5
+            kv = [(k[:, :, :-1], v[:, :, :-1]) for k, v in kv2]
