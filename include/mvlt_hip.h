@@ -1,0 +1,230 @@
+/* mvlt_hip.h -- C-ABI of the MI355X (gfx950) kernels for the MVLT hot path.
+ *
+ * The reference (Control-xl/Medical-Vision-Langauge-Transformer) has no
+ * FFI/plugin seam: its hot path is eager PyTorch.  This
+ * header is therefore the boundary a maintainer would bind (ctypes stub in
+ * INTEGRATION.md): one entry point per fused op, each citing the reference
+ * lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    marked host; the caller owns every buffer (inputs, outputs, saved
+ *    tensors, workspace) -- the library allocates nothing.
+ *  - `stream` is a hipStream_t passed as void*; every launch goes on it.
+ *  - return 0 on success, a negative MVLT_ERR_* otherwise; no exceptions.
+ *  - re-entrant, no global mutable state; one process per GPU.
+ *  - `dtype` selects storage/MFMA input type of activations and of the
+ *    compute copies of weight matrices: MVLT_F32 (exact f32 MFMA,
+ *    v_mfma_f32_16x16x4_f32) or MVLT_BF16 (v_mfma_f32_16x16x32_bf16, f32
+ *    accumulate).  Biases, LayerNorm affine parameters, the relative position
+ *    bias table, statistics and gradients of parameters are always f32.
+ */
+#ifndef MVLT_HIP_H
+#define MVLT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MVLT_F32 = 0, MVLT_BF16 = 1 };
+enum { MVLT_OK = 0, MVLT_ERR_ARG = -1, MVLT_ERR_LAUNCH = -2, MVLT_ERR_UNSUPPORTED = -3 };
+
+/* loader checks */
+int mvlt_version(void);            /* ABI version, currently 1 */
+const char* mvlt_arch(void);       /* "gfx950" */
+
+/* ------------------------------------------------------------------ GEMM
+ * C[M,N] = epilogue(A[M,K] * B[K,N]).  Replaces every nn.Linear on the path:
+ * qkv/proj (visual_feature_extractor.py:231,252), Mlp fc1/fc2 (:135-141),
+ * PatchMerging.reduction (:443), PatchEmbed.proj as im2col GEMM (:562), HF
+ * BERT query/key/value/dense (modeling_bert.py:175-177,289,337,348), pooler,
+ * MLM transform/decoder (:466-506) and all their dgrad/wgrad products.
+ *   a_kmajor = 0: A[m*lda + k]          1: A[k*lda + m]   (wgrad: A = dY^T)
+ *   b_kmajor = 0: B[n*ldb + k] (torch Linear weight [N,K])   1: B[k*ldb + n]
+ * Epilogue, in this order (v = accumulator, m' = rowmap ? rowmap[m] : m):
+ *   BIAS      v += bias[n]
+ *   GELU      (SAVE_PRE: pre[m',n] = v)  v = gelu_erf(v)
+ *   DROPOUT   v = keep(seed,tag,m*N+n) ? v/(1-p) : 0
+ *   ROWSCALE  v *= rowscale[m' / rows_per_scale]            (DropPath)
+ *   MUL_GELU_GRAD  v *= gelu'(aux[m',n])
+ *   RESIDUAL  v += residual[m'*ldr + n]
+ *   ACCUM     v += C[m',n]
+ *   store C[m'*ldc + n]  (dtype, or f32 when OUT_F32)
+ * split_k > 1 computes K-slices into `workspace` (f32 slabs) and a second
+ * kernel reduces them and applies the epilogue (deterministic, no atomics). */
+enum {
+    MVLT_EPI_BIAS = 1, MVLT_EPI_GELU = 2, MVLT_EPI_SAVE_PRE = 4, MVLT_EPI_DROPOUT = 8,
+    MVLT_EPI_ROWSCALE = 16, MVLT_EPI_RESIDUAL = 32, MVLT_EPI_ROWMAP = 64,
+    MVLT_EPI_MUL_GELU_GRAD = 128, MVLT_EPI_OUT_F32 = 256, MVLT_EPI_ACCUM = 512
+};
+typedef struct MvltGemm {
+    int dtype, M, N, K;
+    const void* A; int64_t lda; int a_kmajor;
+    const void* B; int64_t ldb; int b_kmajor;
+    void* C; int64_t ldc;
+    int epilogue;
+    const float* bias;
+    void* pre;                       /* ldc */
+    const void* residual; int64_t ldr;
+    const void* aux;                 /* ldc */
+    const float* rowscale; int rows_per_scale;
+    const int32_t* rowmap;
+    float dropout_p; uint64_t seed; uint32_t tag;
+    int split_k; void* workspace; size_t workspace_bytes;
+} MvltGemm;
+int mvlt_gemm(const MvltGemm* p, void* stream);
+size_t mvlt_gemm_workspace_bytes(const MvltGemm* p);
+
+/* column sums: out[n] = sum_m x[m*ld + n]  (bias gradients), f32 out.
+ * workspace: f32 [mvlt_colsum_workspace_rows(M)][N]. */
+int mvlt_colsum(int dtype, const void* x, int64_t ld, int M, int N, float* out, int accumulate,
+                float* workspace, void* stream);
+int mvlt_colsum_workspace_rows(int M);
+
+/* ------------------------------------------------------------------ LayerNorm
+ * y = LN(x)*gamma + beta over the last dim C (nn.LayerNorm at
+ * visual_feature_extractor.py:308,314,422,553,653 eps 1e-5; HF BERT
+ * LayerNorm eps 1e-12, modeling_bert.py:287,346,480).
+ *  - merge_H/W != 0: input row r = (b,i,j) is the PatchMerging gather
+ *    cat(x[2i,2j], x[2i+1,2j], x[2i,2j+1], x[2i+1,2j+1]) of x:[B,H*W,C/4]
+ *    (visual_feature_extractor.py:435-440).
+ *  - out_rowmap: y row = out_rowmap[r] (fuses roll(-s)+window_partition,
+ *    :360-367, into the store).
+ *  - gelu: y = gelu(LN(x)) (Swin final norm + Conv_layer nn.GELU, model.py:232-235);
+ *    y_pre (optional) receives LN(x) for the backward pass.
+ *  - mean/rstd (optional, f32 [rows]) are saved for the backward pass. */
+typedef struct MvltLayerNorm {
+    int dtype, rows, C; float eps;
+    const void* x; const float* gamma; const float* beta;
+    void* y; void* y_pre; float* mean; float* rstd;
+    const int32_t* out_rowmap; int merge_H, merge_W; int gelu;
+} MvltLayerNorm;
+int mvlt_layernorm_fwd(const MvltLayerNorm* p, void* stream);
+
+/* backward: dx (+= dres) ; dgamma/dbeta f32 [C].
+ *  - dy_rowmap: dy row for logical row r is dy[dy_rowmap[r]].
+ *  - gelu: dy is the gradient of gelu(LN(x)); y_pre must be given.
+ *  - merge_H/W: dx is scattered back to x:[B,H*W,C/4].
+ * workspace: f32 [2][mvlt_layernorm_bwd_workspace_rows()][C]. */
+typedef struct MvltLayerNormBwd {
+    int dtype, rows, C;
+    const void* dy; const int32_t* dy_rowmap;
+    const void* x; const float* mean; const float* rstd; const float* gamma;
+    const void* y_pre; int gelu;
+    const void* dres; void* dx;
+    int merge_H, merge_W;
+    float* dgamma; float* dbeta; int accumulate;
+    float* workspace;
+} MvltLayerNormBwd;
+int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream);
+int mvlt_layernorm_bwd_workspace_rows(void);
+
+/* ------------------------------------------------------------------ attention
+ * One (sequence, head) problem per workgroup; Q,K,V come from a fused
+ * projection buffer qkv[rows, 3*nH*hd] laid out [3][nH][hd] per row.
+ * mode MVLT_ATTN_SWIN  : WindowAttention core (visual_feature_extractor.py:234-251):
+ *      softmax(q*scale @ k^T + table[relidx(q,k)][h] + shift_mask) @ v, N=49,
+ *      relidx and the 0/-100 shift mask (:318-344) computed in-kernel from
+ *      (win_res, shift); sequences are windows, nW per image.
+ * mode MVLT_ATTN_BIDIR : HF eager attention (modeling_bert.py:111-136) with the
+ *      MVLBert bidirectional key mask cat(1,image_mask,1,text>0) (model.py:125-128)
+ *      rebuilt in-kernel from text_ids (int64 [B,T]) and optional image_mask (u8 [B,n_img]);
+ *      masked keys get -10000 (model.py:182).
+ * mode MVLT_ATTN_SEQ2SEQ : key allowed iff k<=q or k<=obj_end (model.py:118-123).
+ * Dropout on the probabilities (attention_probs_dropout_prob) uses the counter RNG.
+ * lse (f32 [nseq,nH,L]) is saved for the backward pass. */
+enum { MVLT_ATTN_SWIN = 0, MVLT_ATTN_BIDIR = 1, MVLT_ATTN_SEQ2SEQ = 2 };
+typedef struct MvltAttn {
+    int dtype, mode;
+    int nseq, L, nH, hd;
+    const void* qkv; void* out;          /* out: [nseq*L, nH*hd] */
+    float* lse;
+    float scale;
+    /* swin */
+    const float* bias_table; int nW, win_res, shift;
+    /* bert */
+    const int64_t* text_ids; int T; const uint8_t* image_mask; int obj_end;
+    float dropout_p; uint64_t seed; uint32_t tag;
+    /* backward only */
+    const void* dout; void* dqkv; float* dbias_table; float* delta_ws;
+} MvltAttn;
+int mvlt_attn_fwd(const MvltAttn* p, void* stream);
+int mvlt_attn_bwd(const MvltAttn* p, void* stream);   /* delta_ws: f32 [nseq,nH,L] */
+
+/* ------------------------------------------------------------------ data movement / embeddings
+ * PatchEmbed im2col (visual_feature_extractor.py:562): img f32 NCHW [B,3,S,S]
+ * -> cols [B*(S/P)^2, 3*P*P] in (c,dy,dx) order = Conv2d weight.view(96,-1). */
+int mvlt_im2col_patch(int dtype, const float* img, void* cols, int B, int Cin, int S, int P, void* stream);
+
+/* MVLBert.get_embedding (model.py:133-158): out[b,pos] = src(pos) + type_emb[pos<=obj_end] + pos_emb[pos]
+ * with src = word_emb[cls] | image_feature | word_emb[sep] | word_emb[text];
+ * NO LayerNorm/dropout.  Tables are f32 masters. */
+typedef struct MvltEmbed {
+    int dtype, B, n_img, T, H;
+    const int64_t* text_ids;            /* [B,T] or NULL when T==0 */
+    const void* image_feature;          /* [B,n_img,H] dtype */
+    const float* word_emb; const float* pos_emb; const float* type_emb;
+    int cls_id, sep_id, pos_offset, type_override;  /* cached step: pos_offset=past, type_override=0, n_img=-1 */
+    void* out;                          /* [B, L, H] */
+    /* backward */
+    const void* dout; void* dimage; float* dword; float* dpos; float* dtype_emb;
+} MvltEmbed;
+int mvlt_embed_fwd(const MvltEmbed* p, void* stream);
+int mvlt_embed_bwd(const MvltEmbed* p, void* stream);  /* dword/dpos/dtype_emb are ACCUMULATED (zero them first) */
+
+/* out[i,:] = scale[i_src / rows_per_scale] * mask(in[src,:]) where src = rowmap ? rowmap[i] : i;
+ * dropout mask (p>0) indexed by src*C + c.  Used for DropPath / dropout backward
+ * and window-order gathers of gradients. */
+int mvlt_rows_transform(int dtype, const void* in, void* out, int rows, int C, const int32_t* rowmap,
+                        const float* rowscale, int rows_per_scale,
+                        float dropout_p, uint64_t seed, uint32_t tag, void* stream);
+
+/* elementwise helpers */
+int mvlt_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+int mvlt_gelu_fwd(int dtype, const void* x, void* y, int64_t n, void* stream);
+int mvlt_tanh_fwd(int dtype, const void* x, void* y, int64_t n, void* stream);
+int mvlt_tanh_bwd(int dtype, const void* y, const void* dy, void* dx, int64_t n, void* stream);
+int mvlt_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint32_t tag, void* stream);
+int mvlt_droppath_scale(float* scale, int B, float p, uint64_t seed, uint32_t tag, void* stream);
+
+/* ------------------------------------------------------------------ losses
+ * F.cross_entropy(logits, labels, ignore_index=-100) (model.py:410,418):
+ * logits [rows, ld>=V] dtype; loss_sum/count are f32 scalars (device),
+ * lse f32 [rows].  bwd writes dlogits = scale*(softmax - onehot) for valid
+ * rows and 0 for ignored rows, where scale = grad_scale / max(count,1)
+ * (mean reduction), in place over logits when dlogits == logits. */
+int mvlt_ce_fwd(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
+                float* lse, float* loss_sum, float* count, void* stream);
+int mvlt_ce_bwd(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
+                const float* lse, const float* count, float grad_scale, void* dlogits, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * torch.optim.AdamW step (run_pretrain.py:165-166: lr 4e-5, betas (0.9,0.999),
+ * eps 1e-6, weight_decay 1e-4) over one flat f32 segment; also refreshes the
+ * bf16 compute copy (shadow, may be NULL).  grad_scale multiplies g first
+ * (1/world_size for DDP averaging). */
+int mvlt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+               int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+               int step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ decode (greedy, KV cache)
+ * 2-token cached step attention (model.py:82-108): q rows = n_new new tokens,
+ * keys = cache[0..past) + new; causal over the new tokens. */
+typedef struct MvltAttnCached {
+    int dtype, B, nH, hd, past, n_new, cache_cap;
+    const void* qkv_new;                /* [B*n_new, 3*nH*hd] */
+    void* k_cache; void* v_cache;       /* [B, nH, cache_cap, hd]; new K/V appended at `past` */
+    void* out;                          /* [B*n_new, nH*hd] */
+    float scale;
+} MvltAttnCached;
+int mvlt_attn_cached(const MvltAttnCached* p, void* stream);
+/* argmax over V of logits [rows, ld] -> int64 ids (greedy_search, model.py:896-900) */
+int mvlt_argmax(int dtype, const void* logits, int64_t ld, int rows, int V, int64_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVLT_HIP_H */

@@ -1,0 +1,131 @@
+"""ctypes binding of the C-ABI in include/mvlt_hip.h (libmvlt_hip.so).
+
+The HIP library is the product: if it is missing this module raises -- there
+is no eager/CPU fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvlt_hip.so")
+
+F32, BF16 = 0, 1
+OK = 0
+ERRORS = {-1: "MVLT_ERR_ARG", -2: "MVLT_ERR_LAUNCH", -3: "MVLT_ERR_UNSUPPORTED"}
+
+EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_DROPOUT = 1, 2, 4, 8
+EPI_ROWSCALE, EPI_RESIDUAL, EPI_ROWMAP, EPI_MUL_GELU_GRAD = 16, 32, 64, 128
+EPI_OUT_F32, EPI_ACCUM = 256, 512
+ATTN_SWIN, ATTN_BIDIR, ATTN_SEQ2SEQ = 0, 1, 2
+
+vp, i32, i64, u64, u32, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32, C.c_float, C.c_size_t
+
+
+class MvltGemm(C.Structure):
+    _fields_ = [("dtype", i32), ("M", i32), ("N", i32), ("K", i32),
+                ("A", vp), ("lda", i64), ("a_kmajor", i32),
+                ("B", vp), ("ldb", i64), ("b_kmajor", i32),
+                ("C", vp), ("ldc", i64), ("epilogue", i32),
+                ("bias", vp), ("pre", vp), ("residual", vp), ("ldr", i64), ("aux", vp),
+                ("rowscale", vp), ("rows_per_scale", i32), ("rowmap", vp),
+                ("dropout_p", f32), ("seed", u64), ("tag", u32),
+                ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz)]
+
+
+class MvltLayerNorm(C.Structure):
+    _fields_ = [("dtype", i32), ("rows", i32), ("C", i32), ("eps", f32),
+                ("x", vp), ("gamma", vp), ("beta", vp),
+                ("y", vp), ("y_pre", vp), ("mean", vp), ("rstd", vp),
+                ("out_rowmap", vp), ("merge_H", i32), ("merge_W", i32), ("gelu", i32)]
+
+
+class MvltLayerNormBwd(C.Structure):
+    _fields_ = [("dtype", i32), ("rows", i32), ("C", i32),
+                ("dy", vp), ("dy_rowmap", vp),
+                ("x", vp), ("mean", vp), ("rstd", vp), ("gamma", vp),
+                ("y_pre", vp), ("gelu", i32),
+                ("dres", vp), ("dx", vp),
+                ("merge_H", i32), ("merge_W", i32),
+                ("dgamma", vp), ("dbeta", vp), ("accumulate", i32),
+                ("workspace", vp)]
+
+
+class MvltAttn(C.Structure):
+    _fields_ = [("dtype", i32), ("mode", i32),
+                ("nseq", i32), ("L", i32), ("nH", i32), ("hd", i32),
+                ("qkv", vp), ("out", vp), ("lse", vp), ("scale", f32),
+                ("bias_table", vp), ("nW", i32), ("win_res", i32), ("shift", i32),
+                ("text_ids", vp), ("T", i32), ("image_mask", vp), ("obj_end", i32),
+                ("dropout_p", f32), ("seed", u64), ("tag", u32),
+                ("dout", vp), ("dqkv", vp), ("dbias_table", vp), ("delta_ws", vp)]
+
+
+class MvltEmbed(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("n_img", i32), ("T", i32), ("H", i32),
+                ("text_ids", vp), ("image_feature", vp),
+                ("word_emb", vp), ("pos_emb", vp), ("type_emb", vp),
+                ("cls_id", i32), ("sep_id", i32), ("pos_offset", i32), ("type_override", i32),
+                ("out", vp),
+                ("dout", vp), ("dimage", vp), ("dword", vp), ("dpos", vp), ("dtype_emb", vp)]
+
+
+class MvltAttnCached(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("nH", i32), ("hd", i32), ("past", i32), ("n_new", i32),
+                ("cache_cap", i32),
+                ("qkv_new", vp), ("k_cache", vp), ("v_cache", vp), ("out", vp), ("scale", f32)]
+
+
+# every symbol include/mvlt_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mvlt_version": (i32, []),
+    "mvlt_arch": (C.c_char_p, []),
+    "mvlt_gemm": (i32, [C.POINTER(MvltGemm), vp]),
+    "mvlt_gemm_workspace_bytes": (sz, [C.POINTER(MvltGemm)]),
+    "mvlt_colsum": (i32, [i32, vp, i64, i32, i32, vp, i32, vp, vp]),
+    "mvlt_colsum_workspace_rows": (i32, [i32]),
+    "mvlt_layernorm_fwd": (i32, [C.POINTER(MvltLayerNorm), vp]),
+    "mvlt_layernorm_bwd": (i32, [C.POINTER(MvltLayerNormBwd), vp]),
+    "mvlt_layernorm_bwd_workspace_rows": (i32, []),
+    "mvlt_attn_fwd": (i32, [C.POINTER(MvltAttn), vp]),
+    "mvlt_attn_bwd": (i32, [C.POINTER(MvltAttn), vp]),
+    "mvlt_im2col_patch": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
+    "mvlt_embed_fwd": (i32, [C.POINTER(MvltEmbed), vp]),
+    "mvlt_embed_bwd": (i32, [C.POINTER(MvltEmbed), vp]),
+    "mvlt_rows_transform": (i32, [i32, vp, vp, i32, i32, vp, vp, i32, f32, u64, u32, vp]),
+    "mvlt_cast": (i32, [i32, vp, i32, vp, i64, vp]),
+    "mvlt_gelu_fwd": (i32, [i32, vp, vp, i64, vp]),
+    "mvlt_tanh_fwd": (i32, [i32, vp, vp, i64, vp]),
+    "mvlt_tanh_bwd": (i32, [i32, vp, vp, vp, i64, vp]),
+    "mvlt_dropout_mask": (i32, [vp, i64, f32, u64, u32, vp]),
+    "mvlt_droppath_scale": (i32, [vp, i32, f32, u64, u32, vp]),
+    "mvlt_ce_fwd": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
+    "mvlt_ce_bwd": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, f32, vp, vp]),
+    "mvlt_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
+    "mvlt_attn_cached": (i32, [C.POINTER(MvltAttnCached), vp]),
+    "mvlt_argmax": (i32, [i32, vp, i64, i32, i32, vp, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libmvlt_hip.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP kernels first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C medical-vision-langauge-transformer_amd/csrc). There is no fallback path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if L.mvlt_version() != 1 or L.mvlt_arch() != b"gfx950":
+            raise RuntimeError("libmvlt_hip.so ABI/arch mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != OK:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")

@@ -1,0 +1,495 @@
+// Fused attention cores for gfx950: Swin (S)W-MSA windows and the MVLBert
+// single-stream BERT attention, forward and backward (MvltAttn in
+// include/mvlt_hip.h).
+//
+// One workgroup (4 waves) = one (sequence, head).  Q, K, V (and dO) of that
+// head are staged once into LDS ([token][d], padded rows); every product is an
+// MFMA over 16x16 tiles and all intermediates (scores, probabilities, dS) live
+// in accumulator registers -- nothing of size L x L ever touches LDS or HBM.
+//
+// Orientation trick: scores are computed TRANSPOSED (first operand = K rows,
+// second = Q rows), so a lane owns 4*NT keys of ONE query: the softmax row
+// reduction is in-register plus two xor-shuffles, and the probability
+// accumulators are directly the second MFMA operand of O^T = V^T P^T (the
+// k-slot <-> key permutation is mirrored on the V^T fragment, which is read
+// with the gfx950 transposed LDS read).  The backward pass computes both
+// orientations (keys-on-rows for dQ, queries-on-rows for dK/dV) instead of
+// transposing dS through LDS.
+//
+// Masks are never materialised: the Swin shift mask (0/-100) and relative
+// position index are computed from (window, slot); the MVLBert key mask from
+// text ids; the seq2seq mask from (row, col, obj_end).
+#include "common.h"
+
+namespace {
+
+struct AttnDev {
+    int mode, nseq, L, nH, hd, NT;
+    const void* qkv; void* out; float* lse; float scale;
+    const float* bias_table; int nW, res, shift;
+    const int64_t* text_ids; int T; const uint8_t* image_mask; int obj_end;
+    uint32_t drop_thresh; float drop_scale; uint64_t seed; uint32_t tag;
+    const void* dout; void* dqkv; float* dbias;
+    int ld;          // LDS row stride (elements)
+    int rows_alloc;  // LDS rows per image
+};
+
+constexpr float NEG_BIG = -1.0e30f;
+
+template <typename T> struct Tok;   // token tiles per MFMA k-block
+template <> struct Tok<bf16_t> { static constexpr int TPB = 2; };
+template <> struct Tok<float>  { static constexpr int TPB = 1; };
+
+// first-operand fragment: rows = feature d0..d0+15, k-slots = tokens of k-block kb
+MVLT_DEV bf16x8 frag_tok(const bf16_t* img, int ld, int d0, int kb) {
+    const int l = threadIdx.x & 63;
+    const int g = l >> 4, i = l & 15, q = i >> 2, pp = i & 3;
+    const bf16_t* p0 = img + (32 * kb + 4 * g + q) * ld + d0 + 4 * pp;
+    const bf16_t* p1 = p0 + 16 * ld;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+MVLT_DEV f32x4 frag_tok(const float* img, int ld, int d0, int kb) {
+    const int l = threadIdx.x & 63;
+    const float* p = img + (16 * kb + 4 * (l >> 4)) * ld + d0 + (l & 15);
+    f32x4 r; r[0] = p[0]; r[1] = p[ld]; r[2] = p[2 * ld]; r[3] = p[3 * ld];
+    return r;
+}
+// second-operand fragment from token-tile accumulators
+template <int KT> MVLT_DEV bf16x8 frag_acc(const f32x4 (&a)[KT], int kb, bf16_t) {
+    bf16x8 r;
+    const int t0 = 2 * kb, t1 = 2 * kb + 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = (bf16_t)a[t0][e];
+        r[4 + e] = (t1 < KT) ? (bf16_t)a[t1 < KT ? t1 : 0][e] : (bf16_t)0.0f;
+    }
+    return r;
+}
+template <int KT> MVLT_DEV f32x4 frag_acc(const f32x4 (&a)[KT], int kb, float) { return a[kb]; }
+
+MVLT_DEV int swin_region(int tok, int wy, int wx, int res, int shift) {
+    const int h = wy * 7 + tok / 7, w = wx * 7 + tok % 7;
+    const int bh = h < res - 7 ? 0 : (h < res - shift ? 1 : 2);
+    const int bw = w < res - 7 ? 0 : (w < res - shift ? 1 : 2);
+    return bh * 3 + bw;
+}
+MVLT_DEV int rel_index(int q, int k) { return (q / 7 - k / 7 + 6) * 13 + (q % 7 - k % 7 + 6); }
+
+// LDS carve-up (all float-aligned): images Q,K,V,(dO) then small arrays
+template <typename T> struct Smem {
+    T* q; T* k; T* v; T* d; float* kmask; float* lse; float* delta; float* tbl; float* tblg;
+};
+template <typename T>
+MVLT_DEV Smem<T> carve(char* base, const AttnDev& p, bool bwd) {
+    Smem<T> s;
+    const size_t img = (size_t)p.rows_alloc * p.ld * sizeof(T);
+    s.q = reinterpret_cast<T*>(base); s.k = reinterpret_cast<T*>(base + img);
+    s.v = reinterpret_cast<T*>(base + 2 * img); s.d = reinterpret_cast<T*>(base + 3 * img);
+    float* f = reinterpret_cast<float*>(base + (bwd ? 4 : 3) * img);
+    s.kmask = f; s.lse = f + p.rows_alloc; s.delta = f + 2 * p.rows_alloc;
+    s.tbl = f + 3 * p.rows_alloc; s.tblg = s.tbl + 176;
+    return s;
+}
+static size_t smem_bytes(int dtype, int rows_alloc, int ld, bool bwd) {
+    const size_t es = dtype == MVLT_BF16 ? 2 : 4;
+    return (size_t)(bwd ? 4 : 3) * rows_alloc * ld * es + (3 * (size_t)rows_alloc + 352) * sizeof(float);
+}
+
+template <typename T, int HD>
+MVLT_DEV void stage_images(const AttnDev& p, const Smem<T>& s, int seq, int h, bool bwd) {
+    constexpr int E = TypeInfo<T>::E;
+    constexpr int CPR = HD / E;                         // 16-byte chunks per row
+    using Vec = typename TypeInfo<T>::Vec;
+    const int C = p.nH * HD;
+    const T* qkv = reinterpret_cast<const T*>(p.qkv);
+    const T* dout = reinterpret_cast<const T*>(p.dout);
+    const int nimg = bwd ? 4 : 3;
+    const int total = nimg * p.rows_alloc * CPR;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int which = idx / (p.rows_alloc * CPR);
+        const int rem = idx % (p.rows_alloc * CPR);
+        const int tok = rem / CPR, ch = rem % CPR;
+        Vec v = zero_vec<T>();
+        if (tok < p.L) {
+            if (which < 3) v = *reinterpret_cast<const Vec*>(qkv + ((long)seq * p.L + tok) * 3 * C + which * C + h * HD + ch * E);
+            else v = *reinterpret_cast<const Vec*>(dout + ((long)seq * p.L + tok) * C + h * HD + ch * E);
+        }
+        T* img = which == 0 ? s.q : which == 1 ? s.k : which == 2 ? s.v : s.d;
+        *reinterpret_cast<Vec*>(img + tok * p.ld + ch * E) = v;
+    }
+}
+
+// additive logit term for (query q, key k); also folds key padding
+template <bool SWIN>
+MVLT_DEV float logit_bias(const AttnDev& p, const float* kmask, const float* tbl, int q, int k,
+                          int wy, int wx) {
+    if (k >= p.L) return NEG_BIG;
+    if (SWIN) {
+        float b = tbl[rel_index(min(q, 48), k)];
+        if (p.shift > 0 && swin_region(min(q, 48), wy, wx, p.res, p.shift) != swin_region(k, wy, wx, p.res, p.shift))
+            b += -100.0f;
+        return b;
+    }
+    if (p.mode == MVLT_ATTN_SEQ2SEQ) return (k <= q || k <= p.obj_end) ? 0.0f : -10000.0f;
+    return kmask[k];
+}
+
+template <bool SWIN>
+MVLT_DEV void stage_small(const AttnDev& p, float* kmask, float* tbl, float* tblg, int seq, int h, bool bwd) {
+    if (SWIN) {
+        for (int i = threadIdx.x; i < 169; i += 256) {
+            tbl[i] = p.bias_table[i * p.nH + h];
+        }
+    } else if (p.mode == MVLT_ATTN_BIDIR) {
+        const int n_img = p.obj_end - 1;
+        for (int k = threadIdx.x; k < p.L; k += 256) {
+            bool ok = true;
+            if (k >= 1 && k <= n_img) ok = p.image_mask ? p.image_mask[(long)seq * n_img + k - 1] != 0 : true;
+            else if (k > p.obj_end) ok = p.text_ids[(long)seq * p.T + (k - p.obj_end - 1)] > 0;
+            kmask[k] = ok ? 0.0f : -10000.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T, int HD, int KT, bool SWIN>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using M = Mma<T>;
+    constexpr int KBD = HD / M::KB;                     // k-blocks over the head dim
+    constexpr int TPB = Tok<T>::TPB;
+    constexpr int KBT = (KT + TPB - 1) / TPB;           // k-blocks over tokens
+    constexpr int TD = HD / 16;
+    const Smem<T> s = carve<T>(smem_raw, p, false);
+    const int h = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c15 = lane & 15;
+    const int C = p.nH * HD;
+    T* out = reinterpret_cast<T*>(p.out);
+    for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
+        __syncthreads();
+        stage_images<T, HD>(p, s, seq, h, false);
+        stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, false);
+        __syncthreads();
+        int wy = 0, wx = 0;
+        if (SWIN) { const int w = seq % p.nW, nwx = p.res / 7; wy = w / nwx; wx = w % nwx; }
+        for (int tq = wave; tq < p.NT; tq += 4) {
+            f32x4 acc[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            typename M::Frag fq[KBD];
+#pragma unroll
+            for (int kb = 0; kb < KBD; ++kb) fq[kb] = frag_rowmajor<T>(s.q, p.ld, 16 * tq, kb * M::KB);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                if (t < p.NT) {
+#pragma unroll
+                    for (int kb = 0; kb < KBD; ++kb)
+                        M::mma(acc[t], frag_rowmajor<T>(s.k, p.ld, 16 * t, kb * M::KB), fq[kb]);
+                }
+            }
+            const int q = 16 * tq + c15;
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 16 * t + 4 * g + j;
+                    float v = (t < p.NT) ? acc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx) : NEG_BIG;
+                    acc[t][j] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float e = __expf(acc[t][j] - mx); acc[t][j] = e; sum += e; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            if (g == 0 && q < p.L && p.lse) p.lse[((long)seq * p.nH + h) * p.L + q] = mx + __logf(sum);
+            const bool drop = p.drop_thresh != 0;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float pr = acc[t][j] * inv;
+                    if (drop) {
+                        const int k = 16 * t + 4 * g + j;
+                        const uint32_t idx = (uint32_t)((((long)seq * p.nH + h) * p.L + q) * p.L + k);
+                        pr = rng_keep(p.seed, p.tag, idx, p.drop_thresh) ? pr * p.drop_scale : 0.0f;
+                    }
+                    acc[t][j] = pr;
+                }
+            f32x4 o[TD];
+#pragma unroll
+            for (int td = 0; td < TD; ++td) o[td] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KBT; ++kb) {
+                if (kb * TPB < p.NT) {
+                    const typename M::Frag fp = frag_acc<KT>(acc, kb, T());
+#pragma unroll
+                    for (int td = 0; td < TD; ++td) M::mma(o[td], frag_tok(s.v, p.ld, 16 * td, kb), fp);
+                }
+            }
+            if (q < p.L) {
+#pragma unroll
+                for (int td = 0; td < TD; ++td)
+                    store4f(out + ((long)seq * p.L + q) * C + h * HD + 16 * td + 4 * g, o[td]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward
+template <typename T, int HD, int KT, bool SWIN>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using M = Mma<T>;
+    constexpr int KBD = HD / M::KB;
+    constexpr int TPB = Tok<T>::TPB;
+    constexpr int KBT = (KT + TPB - 1) / TPB;
+    constexpr int TD = HD / 16;
+    const Smem<T> s = carve<T>(smem_raw, p, true);
+    const int h = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c15 = lane & 15;
+    const int C = p.nH * HD;
+    T* dqkv = reinterpret_cast<T*>(p.dqkv);
+    const T* outp = reinterpret_cast<const T*>(p.out);
+    const T* dout = reinterpret_cast<const T*>(p.dout);
+    const bool drop = p.drop_thresh != 0;
+    if (SWIN) { for (int i = threadIdx.x; i < 176; i += 256) s.tblg[i] = 0.f; }
+    for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
+        __syncthreads();
+        stage_images<T, HD>(p, s, seq, h, true);
+        stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, true);
+        // delta_q = sum_d dO[q,d] * O[q,d];  lse_q
+        for (int q = threadIdx.x; q < p.rows_alloc; q += 256) {
+            float dl = 0.f, ls = 0.f;
+            if (q < p.L) {
+                const T* o = outp + ((long)seq * p.L + q) * C + h * HD;
+                const T* d = dout + ((long)seq * p.L + q) * C + h * HD;
+                for (int i = 0; i < HD; i += 4) {
+                    const f32x4 a = load4f(o + i), b = load4f(d + i);
+                    dl += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+                }
+                ls = p.lse[((long)seq * p.nH + h) * p.L + q];
+            }
+            s.delta[q] = dl; s.lse[q] = ls;
+        }
+        __syncthreads();
+        int wy = 0, wx = 0;
+        if (SWIN) { const int w = seq % p.nW, nwx = p.res / 7; wy = w / nwx; wx = w % nwx; }
+
+        // ---- phase A: keys on accumulator rows, one query tile per wave -> dQ, dBias
+        for (int tq = wave; tq < p.NT; tq += 4) {
+            f32x4 sc[KT], dp[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = sc[t]; }
+            typename M::Frag fq[KBD], fd[KBD];
+#pragma unroll
+            for (int kb = 0; kb < KBD; ++kb) {
+                fq[kb] = frag_rowmajor<T>(s.q, p.ld, 16 * tq, kb * M::KB);
+                fd[kb] = frag_rowmajor<T>(s.d, p.ld, 16 * tq, kb * M::KB);
+            }
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                if (t < p.NT) {
+#pragma unroll
+                    for (int kb = 0; kb < KBD; ++kb) {
+                        M::mma(sc[t], frag_rowmajor<T>(s.k, p.ld, 16 * t, kb * M::KB), fq[kb]);
+                        M::mma(dp[t], frag_rowmajor<T>(s.v, p.ld, 16 * t, kb * M::KB), fd[kb]);
+                    }
+                }
+            }
+            const int q = 16 * tq + c15;
+            const float lse_q = s.lse[q], delta_q = s.delta[q];
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 16 * t + 4 * g + j;
+                    float ds = 0.f;
+                    if (t < p.NT && k < p.L && q < p.L) {
+                        const float lg = sc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx);
+                        const float pr = __expf(lg - lse_q);
+                        float dpv = dp[t][j];
+                        if (drop) {
+                            const uint32_t idx = (uint32_t)((((long)seq * p.nH + h) * p.L + q) * p.L + k);
+                            dpv = rng_keep(p.seed, p.tag, idx, p.drop_thresh) ? dpv * p.drop_scale : 0.0f;
+                        }
+                        ds = pr * (dpv - delta_q);
+                        if (SWIN) atomicAdd(&s.tblg[rel_index(q, k)], ds);
+                    }
+                    sc[t][j] = ds * p.scale;
+                }
+            f32x4 dq[TD];
+#pragma unroll
+            for (int td = 0; td < TD; ++td) dq[td] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KBT; ++kb) {
+                if (kb * TPB < p.NT) {
+                    const typename M::Frag fs = frag_acc<KT>(sc, kb, T());
+#pragma unroll
+                    for (int td = 0; td < TD; ++td) M::mma(dq[td], frag_tok(s.k, p.ld, 16 * td, kb), fs);
+                }
+            }
+            if (q < p.L) {
+#pragma unroll
+                for (int td = 0; td < TD; ++td)
+                    store4f(dqkv + ((long)seq * p.L + q) * 3 * C + h * HD + 16 * td + 4 * g, dq[td]);
+            }
+        }
+
+        // ---- phase B: queries on accumulator rows, one key tile per wave -> dK, dV
+        for (int tk = wave; tk < p.NT; tk += 4) {
+            f32x4 sc[KT], dp[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = sc[t]; }
+            typename M::Frag fk[KBD], fv[KBD];
+#pragma unroll
+            for (int kb = 0; kb < KBD; ++kb) {
+                fk[kb] = frag_rowmajor<T>(s.k, p.ld, 16 * tk, kb * M::KB);
+                fv[kb] = frag_rowmajor<T>(s.v, p.ld, 16 * tk, kb * M::KB);
+            }
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                if (t < p.NT) {
+#pragma unroll
+                    for (int kb = 0; kb < KBD; ++kb) {
+                        M::mma(sc[t], frag_rowmajor<T>(s.q, p.ld, 16 * t, kb * M::KB), fk[kb]);
+                        M::mma(dp[t], frag_rowmajor<T>(s.d, p.ld, 16 * t, kb * M::KB), fv[kb]);
+                    }
+                }
+            }
+            const int k = 16 * tk + c15;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = 16 * t + 4 * g + j;
+                    float pd = 0.f, ds = 0.f;
+                    if (t < p.NT && k < p.L && q < p.L) {
+                        const float lg = sc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx);
+                        const float pr = __expf(lg - s.lse[q]);
+                        float dpv = dp[t][j];
+                        pd = pr;
+                        if (drop) {
+                            const uint32_t idx = (uint32_t)((((long)seq * p.nH + h) * p.L + q) * p.L + k);
+                            const bool keep = rng_keep(p.seed, p.tag, idx, p.drop_thresh);
+                            dpv = keep ? dpv * p.drop_scale : 0.0f;
+                            pd = keep ? pr * p.drop_scale : 0.0f;
+                        }
+                        ds = pr * (dpv - s.delta[q]) * p.scale;
+                    }
+                    sc[t][j] = ds; dp[t][j] = pd;
+                }
+            f32x4 dk[TD], dv[TD];
+#pragma unroll
+            for (int td = 0; td < TD; ++td) { dk[td] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[td] = dk[td]; }
+#pragma unroll
+            for (int kb = 0; kb < KBT; ++kb) {
+                if (kb * TPB < p.NT) {
+                    const typename M::Frag fs = frag_acc<KT>(sc, kb, T());
+                    const typename M::Frag fp = frag_acc<KT>(dp, kb, T());
+#pragma unroll
+                    for (int td = 0; td < TD; ++td) {
+                        M::mma(dk[td], frag_tok(s.q, p.ld, 16 * td, kb), fs);
+                        M::mma(dv[td], frag_tok(s.d, p.ld, 16 * td, kb), fp);
+                    }
+                }
+            }
+            if (k < p.L) {
+#pragma unroll
+                for (int td = 0; td < TD; ++td) {
+                    T* base = dqkv + ((long)seq * p.L + k) * 3 * C + h * HD + 16 * td + 4 * g;
+                    store4f(base + C, dk[td]);
+                    store4f(base + 2 * C, dv[td]);
+                }
+            }
+        }
+    }
+    if (SWIN && p.dbias) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 169; i += 256) atomicAdd(&p.dbias[i * p.nH + h], s.tblg[i]);
+    }
+}
+
+template <typename T, int HD, int KT, bool SWIN>
+int launch(const AttnDev& d, bool bwd, int dtype, hipStream_t s) {
+    const size_t sh = smem_bytes(dtype, d.rows_alloc, d.ld, bwd);
+    if (sh > 160 * 1024) return MVLT_ERR_UNSUPPORTED;
+    int gx = d.nseq;
+    if (SWIN) {   // several windows per workgroup: the LDS bias-gradient table is flushed once
+        const int target = 2048 / (d.nH > 0 ? d.nH : 1);
+        if (gx > target) gx = target < 1 ? 1 : target;
+    }
+    dim3 grid(gx, d.nH);
+    if (bwd) {
+        auto k = attn_bwd_kernel<T, HD, KT, SWIN>;
+        if (sh > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k, grid, dim3(256), sh, s, d);
+    } else {
+        auto k = attn_fwd_kernel<T, HD, KT, SWIN>;
+        if (sh > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(k, grid, dim3(256), sh, s, d);
+    }
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+template <typename T>
+int dispatch(AttnDev d, bool bwd, int dtype, hipStream_t s) {
+    constexpr int TPB = Tok<T>::TPB;
+    d.NT = ceil_div(d.L, 16);
+    d.rows_alloc = ceil_div(d.NT, TPB) * TPB * 16;
+    d.ld = d.hd + (sizeof(T) == 2 ? 8 : 4);
+    if (d.mode == MVLT_ATTN_SWIN) {
+        if (d.hd != 32 || d.L != 49) return MVLT_ERR_UNSUPPORTED;
+        return launch<T, 32, 4, true>(d, bwd, dtype, s);
+    }
+    if (d.hd != 64) return MVLT_ERR_UNSUPPORTED;
+    if (d.NT <= 5) return launch<T, 64, 5, false>(d, bwd, dtype, s);
+    if (d.NT <= 9) return launch<T, 64, 9, false>(d, bwd, dtype, s);
+    if (d.NT <= 13 && !bwd) return launch<T, 64, 13, false>(d, bwd, dtype, s);
+    return MVLT_ERR_UNSUPPORTED;
+}
+
+int run(const MvltAttn* p, bool bwd, void* stream) {
+    MVLT_CHECK(p && p->qkv && p->out, MVLT_ERR_ARG);
+    MVLT_CHECK(p->nseq > 0 && p->L > 0 && p->nH > 0, MVLT_ERR_ARG);
+    MVLT_CHECK(aligned16(p->qkv) && aligned16(p->out), MVLT_ERR_ARG);
+    if (p->mode == MVLT_ATTN_SWIN) MVLT_CHECK(p->bias_table && p->nW > 0 && p->win_res % 7 == 0 &&
+                                              p->nW == (p->win_res / 7) * (p->win_res / 7), MVLT_ERR_ARG);
+    else if (p->mode == MVLT_ATTN_BIDIR) MVLT_CHECK((p->T == 0 || p->text_ids) && p->obj_end + 1 + p->T == p->L, MVLT_ERR_ARG);
+    else if (p->mode == MVLT_ATTN_SEQ2SEQ) MVLT_CHECK(p->obj_end < p->L, MVLT_ERR_ARG);
+    else return MVLT_ERR_ARG;
+    MVLT_CHECK(p->dropout_p >= 0.f && p->dropout_p < 1.f, MVLT_ERR_ARG);
+    MVLT_CHECK((double)p->nseq * p->nH * p->L * p->L < 4294967296.0 || p->dropout_p == 0.f, MVLT_ERR_ARG);
+    if (bwd) MVLT_CHECK(p->dout && p->dqkv && p->lse && aligned16(p->dout) && aligned16(p->dqkv), MVLT_ERR_ARG);
+    AttnDev d{};
+    d.mode = p->mode; d.nseq = p->nseq; d.L = p->L; d.nH = p->nH; d.hd = p->hd;
+    d.qkv = p->qkv; d.out = p->out; d.lse = p->lse; d.scale = p->scale;
+    d.bias_table = p->bias_table; d.nW = p->nW; d.res = p->win_res; d.shift = p->shift;
+    d.text_ids = p->text_ids; d.T = p->T; d.image_mask = p->image_mask; d.obj_end = p->obj_end;
+    double th = (double)p->dropout_p * 4294967296.0;
+    d.drop_thresh = (uint32_t)th;
+    d.drop_scale = 1.0f / (1.0f - p->dropout_p);
+    d.seed = p->seed; d.tag = p->tag;
+    d.dout = p->dout; d.dqkv = p->dqkv; d.dbias = p->dbias_table;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p->dtype == MVLT_F32) return dispatch<float>(d, bwd, MVLT_F32, s);
+    if (p->dtype == MVLT_BF16) return dispatch<bf16_t>(d, bwd, MVLT_BF16, s);
+    return MVLT_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int mvlt_attn_fwd(const MvltAttn* p, void* stream) { return run(p, false, stream); }
+extern "C" int mvlt_attn_bwd(const MvltAttn* p, void* stream) { return run(p, true, stream); }

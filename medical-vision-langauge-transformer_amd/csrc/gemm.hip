@@ -1,0 +1,361 @@
+// MFMA GEMM for gfx950 with fused epilogues (see include/mvlt_hip.h, MvltGemm).
+//
+// Structure: 256 threads = 4 waves (2 x 2), workgroup tile BM x BN, k-tile of
+// 128 bytes per row (64 bf16 / 32 f32 = two MFMA k-blocks), register-staged
+// double-buffered LDS (global loads for tile t+1 are issued before the MFMAs
+// of tile t and written to the other LDS buffer after them: one barrier per
+// k-tile).  k-contiguous operands use an XOR-swizzled [row][128 B] image read
+// with ds_read_b128 (conflict-free); k-strided operands (dgrad weights, both
+// wgrad operands) are staged as they lie in memory ([k][row], padded rows) and
+// transposed for free by ds_read_b64_tr_b16 (bf16) when the fragment is read.
+// The MFMA is issued as (B-fragment, A-fragment) so each lane owns 4
+// consecutive n of one output row -> 8/16-byte epilogue loads and stores.
+#include "common.h"
+
+namespace {
+
+struct GemmDev {
+    int M, N, K;
+    const void* A; long lda; const void* B; long ldb;
+    void* C; long ldc;
+    int epi;
+    const float* bias; void* pre; const void* residual; long ldr; const void* aux;
+    const float* rowscale; int rps; const int* rowmap;
+    uint32_t drop_thresh; float drop_scale; uint64_t seed; uint32_t tag;
+    int split_k; int k_per_split; float* ws;
+    int a_vec, b_vec, epi_vec;
+};
+
+template <typename T>
+MVLT_DEV typename TypeInfo<T>::Vec load_chunk(const T* base, long ld, int outer, int inner,
+                                              int outer_lim, int inner_lim, bool vec_ok) {
+    using Vec = typename TypeInfo<T>::Vec;
+    constexpr int E = TypeInfo<T>::E;
+    Vec v = zero_vec<T>();
+    if (outer >= outer_lim || inner >= inner_lim) return v;
+    const T* p = base + (long)outer * ld + inner;
+    if (vec_ok && inner + E <= inner_lim) return *reinterpret_cast<const Vec*>(p);
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (inner + e < inner_lim) v[e] = p[e];
+    return v;
+}
+
+template <typename T>
+MVLT_DEV void epilogue4(const GemmDev& p, int m, int n, f32x4 v) {
+    if (m >= p.M || n >= p.N) return;
+    const int epi = p.epi;
+    const int mo = (epi & MVLT_EPI_ROWMAP) ? p.rowmap[m] : m;
+    const int nv = min(4, p.N - n);
+    const bool vec = p.epi_vec && nv == 4;
+    T* Ct = reinterpret_cast<T*>(p.C);
+    float* Cf = reinterpret_cast<float*>(p.C);
+    const long co = (long)mo * p.ldc + n;
+    if (epi & MVLT_EPI_BIAS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < nv) v[j] += p.bias[n + j];
+    }
+    if (epi & MVLT_EPI_GELU) {
+        if (epi & MVLT_EPI_SAVE_PRE) {
+            T* pre = reinterpret_cast<T*>(p.pre) + co;
+            if (vec) store4f(pre, v);
+            else for (int j = 0; j < nv; ++j) pre[j] = from_f<T>(v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
+    }
+    if (epi & MVLT_EPI_DROPOUT) {
+        const uint32_t base = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = rng_keep(p.seed, p.tag, base + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.0f;
+    }
+    if (epi & MVLT_EPI_ROWSCALE) {
+        const float s = p.rowscale[mo / p.rps];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= s;
+    }
+    if (epi & MVLT_EPI_MUL_GELU_GRAD) {
+        const T* aux = reinterpret_cast<const T*>(p.aux) + co;
+        if (vec) { f32x4 a = load4f(aux);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_f(a[j]);
+        } else for (int j = 0; j < nv; ++j) v[j] *= gelu_grad_f(to_f(aux[j]));
+    }
+    if (epi & MVLT_EPI_RESIDUAL) {
+        const T* r = reinterpret_cast<const T*>(p.residual) + (long)mo * p.ldr + n;
+        if (vec) { f32x4 a = load4f(r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += a[j];
+        } else for (int j = 0; j < nv; ++j) v[j] += to_f(r[j]);
+    }
+    if (epi & MVLT_EPI_OUT_F32) {
+        if (epi & MVLT_EPI_ACCUM) for (int j = 0; j < nv; ++j) v[j] += Cf[co + j];
+        if (vec) store4f(Cf + co, v);
+        else for (int j = 0; j < nv; ++j) Cf[co + j] = v[j];
+    } else {
+        if (epi & MVLT_EPI_ACCUM) for (int j = 0; j < nv; ++j) v[j] += to_f(Ct[co + j]);
+        if (vec) store4f(Ct + co, v);
+        else for (int j = 0; j < nv; ++j) Ct[co + j] = from_f<T>(v[j]);
+    }
+}
+
+template <typename T, int R, bool KMAJOR> struct TileGeom {
+    static constexpr int E = TypeInfo<T>::E;
+    static constexpr int BKE = 128 / (int)sizeof(T);          // k elements per tile
+    static constexpr int PAD = KMAJOR ? (sizeof(T) == 2 ? 16 : 4) : 0;
+    static constexpr int LD = KMAJOR ? (R + PAD) : BKE;        // elements per LDS row
+    static constexpr int ELEMS = KMAJOR ? BKE * LD : R * BKE;
+    static constexpr int CHUNKS = R * 8;                        // 16-byte chunks per tile
+    static constexpr int PER_THREAD = CHUNKS / 256;
+    static constexpr int CPR = KMAJOR ? (R / E) : 8;            // chunks per LDS row
+};
+
+template <typename T, int R, bool KMAJOR>
+MVLT_DEV void tile_load(typename TypeInfo<T>::Vec* __restrict__ regs, const T* base,
+                        long ld, int row0, int row_lim, int k0, int k_lim, bool vec_ok) {
+    using G = TileGeom<T, R, KMAJOR>;
+#pragma unroll
+    for (int i = 0; i < G::PER_THREAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int lr = idx / G::CPR, ch = idx % G::CPR;
+        if (KMAJOR) regs[i] = load_chunk<T>(base, ld, k0 + lr, row0 + ch * G::E, k_lim, row_lim, vec_ok);
+        else        regs[i] = load_chunk<T>(base, ld, row0 + lr, k0 + ch * G::E, row_lim, k_lim, vec_ok);
+    }
+}
+
+template <typename T, int R, bool KMAJOR>
+MVLT_DEV void tile_store(const typename TypeInfo<T>::Vec* __restrict__ regs, T* lds) {
+    using G = TileGeom<T, R, KMAJOR>;
+    using Vec = typename TypeInfo<T>::Vec;
+#pragma unroll
+    for (int i = 0; i < G::PER_THREAD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int lr = idx / G::CPR, ch = idx % G::CPR;
+        if (KMAJOR) *reinterpret_cast<Vec*>(lds + lr * G::LD + ch * G::E) = regs[i];
+        else        *reinterpret_cast<Vec*>(lds + lr * G::BKE + ((ch ^ (lr & 7)) * G::E)) = regs[i];
+    }
+}
+
+// fragment for rows [row0,row0+16) and k-block kb (0/1) of the tile
+template <typename T, int R, bool KMAJOR>
+MVLT_DEV typename Mma<T>::Frag tile_frag(const T* lds, int row0, int kb) {
+    using G = TileGeom<T, R, KMAJOR>;
+    if (KMAJOR) return frag_kmajor(lds, G::LD, row0, kb * Mma<T>::KB);
+    const int l = threadIdx.x & 63;
+    const int row = row0 + (l & 15);
+    const int ch = (kb * 4 + (l >> 4)) ^ (row & 7);
+    return *reinterpret_cast<const typename Mma<T>::Frag*>(lds + row * G::BKE + ch * G::E);
+}
+
+template <typename T, int BM, int BN, bool AK, bool BK_>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmDev p) {
+    using GA = TileGeom<T, BM, AK>;
+    using GB = TileGeom<T, BN, BK_>;
+    using Vec = typename TypeInfo<T>::Vec;
+    constexpr int FM = BM / 32, FN = BN / 32;
+    __shared__ __attribute__((aligned(16))) T sA[2][GA::ELEMS];
+    __shared__ __attribute__((aligned(16))) T sB[2][GB::ELEMS];
+
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int ks = blockIdx.z * p.k_per_split;
+    const int ke = min(p.K, ks + p.k_per_split);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Vec ra[GA::PER_THREAD], rb[GB::PER_THREAD];
+    const int nkt = (ke - ks + GA::BKE - 1) / GA::BKE;
+    if (nkt > 0) {
+        tile_load<T, BM, AK>(ra, A, p.lda, m0, p.M, ks, ke, p.a_vec);
+        tile_load<T, BN, BK_>(rb, B, p.ldb, n0, p.N, ks, ke, p.b_vec);
+        tile_store<T, BM, AK>(ra, sA[0]);
+        tile_store<T, BN, BK_>(rb, sB[0]);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) {
+            const int k0 = ks + (kt + 1) * GA::BKE;
+            tile_load<T, BM, AK>(ra, A, p.lda, m0, p.M, k0, ke, p.a_vec);
+            tile_load<T, BN, BK_>(rb, B, p.ldb, n0, p.N, k0, ke, p.b_vec);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            typename Mma<T>::Frag fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = tile_frag<T, BM, AK>(sA[cur], wm * (BM / 2) + i * 16, kb);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = tile_frag<T, BN, BK_>(sB[cur], wn * (BN / 2) + j * 16, kb);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
+        }
+        if (more) {
+            tile_store<T, BM, AK>(ra, sA[cur ^ 1]);
+            tile_store<T, BN, BK_>(rb, sB[cur ^ 1]);
+        }
+        __syncthreads();
+    }
+
+    // acc[i][j][r] <-> n = nb + 4*(lane>>4) + r, m = mb + (lane & 15)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4);
+            if (p.split_k > 1) {
+                if (m < p.M && n < p.N) {
+                    float* w = p.ws + ((long)blockIdx.z * p.M + m) * p.N + n;
+                    if ((p.N & 3) == 0) store4f(w, acc[i][j]);
+                    else for (int r = 0; r < 4; ++r) if (n + r < p.N) w[r] = acc[i][j][r];
+                }
+            } else {
+                epilogue4<T>(p, m, n, acc[i][j]);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDev p) {
+    const int nq = (p.N + 3) / 4;
+    const long total = (long)p.M * nq;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int m = (int)(idx / nq), n = (int)(idx % nq) * 4;
+        f32x4 v{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.split_k; ++s) {
+            const float* w = p.ws + ((long)s * p.M + m) * p.N + n;
+            if ((p.N & 3) == 0) { f32x4 t = load4f(w); v += t; }
+            else for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += w[r];
+        }
+        epilogue4<T>(p, m, n, v);
+    }
+}
+
+template <typename T, int BM, int BN>
+int launch_layout(const GemmDev& d, bool ak, bool bk, dim3 grid, hipStream_t s) {
+    if (!ak && !bk) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false>), grid, dim3(256), 0, s, d);
+    else if (!ak && bk) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true>), grid, dim3(256), 0, s, d);
+    else if (ak && bk) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, false>), grid, dim3(256), 0, s, d);
+    return 0;
+}
+
+struct Plan { int bm, bn, split; };
+
+Plan choose_plan(const MvltGemm* p) {
+    // tile: BN = 128 when N is a multiple of 128 (or large), else 96 (all model
+    // widths are multiples of 96), 64 for tiny N.  BM = 128 unless that leaves
+    // the 256 CUs under-filled.  split-K only when requested (>1) or auto (0).
+    Plan pl;
+    pl.bn = (p->N % 128 == 0) ? 128 : (p->N % 96 == 0 || p->N > 512) ? 96 : (p->N <= 64 ? 64 : (p->N <= 96 ? 96 : 128));
+    if (p->N > 512 && p->N % 128 != 0 && p->N % 96 != 0) pl.bn = 128;
+    long tiles128 = (long)ceil_div(p->M, 128) * ceil_div(p->N, pl.bn);
+    pl.bm = (tiles128 >= 384 || p->M > 64 * 1024) ? 128 : 64;
+    if (pl.bn == 64) pl.bm = 64;
+    long tiles = (long)ceil_div(p->M, pl.bm) * ceil_div(p->N, pl.bn);
+    int split = p->split_k;
+    if (split == 0) {
+        split = 1;
+        const int bke = (p->dtype == MVLT_BF16) ? 64 : 32;
+        const int nkt = ceil_div(p->K, bke);
+        if (tiles < 192 && nkt >= 8) {
+            split = (int)((512 + tiles - 1) / tiles);
+            if (split > nkt / 4) split = nkt / 4;
+            if (split > 256) split = 256;
+            if (split < 1) split = 1;
+        }
+    }
+    pl.split = split;
+    return pl;
+}
+
+}  // namespace
+
+extern "C" size_t mvlt_gemm_workspace_bytes(const MvltGemm* p) {
+    if (!p) return 0;
+    Plan pl = choose_plan(p);
+    return pl.split > 1 ? (size_t)pl.split * p->M * p->N * sizeof(float) : 0;
+}
+
+template <typename T>
+static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
+    Plan pl = choose_plan(p);
+    GemmDev d;
+    d.M = p->M; d.N = p->N; d.K = p->K;
+    d.A = p->A; d.lda = p->lda; d.B = p->B; d.ldb = p->ldb; d.C = p->C; d.ldc = p->ldc;
+    d.epi = p->epilogue; d.bias = p->bias; d.pre = p->pre; d.residual = p->residual; d.ldr = p->ldr;
+    d.aux = p->aux; d.rowscale = p->rowscale; d.rps = p->rows_per_scale > 0 ? p->rows_per_scale : 1;
+    d.rowmap = p->rowmap;
+    double th = (double)p->dropout_p * 4294967296.0;
+    d.drop_thresh = th >= 4294967295.0 ? 4294967295u : (uint32_t)th;
+    d.drop_scale = p->dropout_p < 1.0f ? 1.0f / (1.0f - p->dropout_p) : 0.0f;
+    d.seed = p->seed; d.tag = p->tag;
+    constexpr int E = TypeInfo<T>::E;
+    const int bke = 128 / (int)sizeof(T);
+    d.split_k = pl.split;
+    int kps = ceil_div(ceil_div(p->K, bke), pl.split) * bke;
+    d.k_per_split = pl.split > 1 ? kps : ((p->K + bke - 1) / bke) * bke;
+    if (pl.split > 1) {
+        // drop empty trailing splits
+        d.split_k = ceil_div(p->K, kps);
+        size_t need = (size_t)d.split_k * p->M * p->N * sizeof(float);
+        MVLT_CHECK(p->workspace && p->workspace_bytes >= need, MVLT_ERR_ARG);
+        if (d.split_k == 1) d.k_per_split = ((p->K + bke - 1) / bke) * bke;
+    }
+    d.ws = reinterpret_cast<float*>(p->workspace);
+    d.a_vec = (p->lda % E == 0) && aligned16(p->A);
+    d.b_vec = (p->ldb % E == 0) && aligned16(p->B);
+    const int epi = p->epilogue;
+    bool ev = (p->ldc % 4 == 0) && aligned16(p->C);
+    if (epi & MVLT_EPI_RESIDUAL) ev = ev && (p->ldr % 4 == 0) && aligned16(p->residual);
+    if (epi & MVLT_EPI_SAVE_PRE) ev = ev && aligned16(p->pre);
+    if (epi & MVLT_EPI_MUL_GELU_GRAD) ev = ev && aligned16(p->aux);
+    d.epi_vec = ev;
+    dim3 grid(ceil_div(p->N, pl.bn), ceil_div(p->M, pl.bm), d.split_k);
+    const bool ak = p->a_kmajor != 0, bk = p->b_kmajor != 0;
+    if (pl.bm == 128 && pl.bn == 128) launch_layout<T, 128, 128>(d, ak, bk, grid, s);
+    else if (pl.bm == 128 && pl.bn == 96) launch_layout<T, 128, 96>(d, ak, bk, grid, s);
+    else if (pl.bm == 64 && pl.bn == 128) launch_layout<T, 64, 128>(d, ak, bk, grid, s);
+    else if (pl.bm == 64 && pl.bn == 96) launch_layout<T, 64, 96>(d, ak, bk, grid, s);
+    else launch_layout<T, 64, 64>(d, ak, bk, grid, s);
+    MVLT_LAUNCH_CHECK();
+    if (d.split_k > 1) {
+        long total = (long)p->M * ((p->N + 3) / 4);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, s, d);
+        MVLT_LAUNCH_CHECK();
+    }
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_gemm(const MvltGemm* p, void* stream) {
+    MVLT_CHECK(p && p->A && p->B && p->C, MVLT_ERR_ARG);
+    MVLT_CHECK(p->M > 0 && p->N > 0 && p->K > 0, MVLT_ERR_ARG);
+    MVLT_CHECK(p->lda > 0 && p->ldb > 0 && p->ldc >= p->N, MVLT_ERR_ARG);
+    MVLT_CHECK((long)p->M * p->N < (1L << 32) || !(p->epilogue & MVLT_EPI_DROPOUT), MVLT_ERR_ARG);
+    const int e = p->epilogue;
+    if (e & MVLT_EPI_BIAS) MVLT_CHECK(p->bias, MVLT_ERR_ARG);
+    if (e & MVLT_EPI_SAVE_PRE) MVLT_CHECK(p->pre && (e & MVLT_EPI_GELU), MVLT_ERR_ARG);
+    if (e & MVLT_EPI_RESIDUAL) MVLT_CHECK(p->residual && p->ldr >= p->N, MVLT_ERR_ARG);
+    if (e & MVLT_EPI_ROWSCALE) MVLT_CHECK(p->rowscale, MVLT_ERR_ARG);
+    if (e & MVLT_EPI_ROWMAP) MVLT_CHECK(p->rowmap, MVLT_ERR_ARG);
+    if (e & MVLT_EPI_MUL_GELU_GRAD) MVLT_CHECK(p->aux, MVLT_ERR_ARG);
+    if (e & MVLT_EPI_DROPOUT) MVLT_CHECK(p->dropout_p >= 0.f && p->dropout_p < 1.f, MVLT_ERR_ARG);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p->dtype == MVLT_F32) return gemm_dispatch<float>(p, s);
+    if (p->dtype == MVLT_BF16) return gemm_dispatch<bf16_t>(p, s);
+    return MVLT_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,509 @@
+// HBM-bound data-movement / elementwise / loss / optimizer kernels for gfx950.
+// Every kernel moves 8-16 bytes per lane per access, coalesced, and is
+// launched with enough workgroups to cover the 256 CUs (grid-stride beyond).
+#include "common.h"
+
+namespace {
+
+inline int grid_for(long n_items, int per_block, int cap = 8192) {
+    long b = (n_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------ im2col (PatchEmbed)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* img, T* cols, int B, int Cin, int S, int P) {
+    // one thread = one (token, c, dy): P contiguous pixels -> P contiguous cols
+    const int G = S / P, K = Cin * P * P;
+    const long total = (long)B * G * G * Cin * P;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int dy = (int)(idx % P);
+        const int c = (int)((idx / P) % Cin);
+        const long tok = idx / ((long)P * Cin);
+        const int pw = (int)(tok % G), ph = (int)((tok / G) % G), b = (int)(tok / ((long)G * G));
+        const float* src = img + (((long)b * Cin + c) * S + ph * P + dy) * S + pw * P;
+        T* dst = cols + tok * K + (c * P + dy) * P;
+        if (P == 4) { store4f(dst, load4f(src)); }
+        else for (int dx = 0; dx < P; ++dx) dst[dx] = from_f<T>(src[dx]);
+    }
+}
+
+// ------------------------------------------------------------------ VL embeddings
+struct EmbDev {
+    int B, n_img, T, H, L;
+    const int64_t* text; const void* img; const float* word; const float* pos; const float* type;
+    int cls_id, sep_id, pos_offset, type_override;
+    void* out; const void* dout; void* dimage; float* dword; float* dpos; float* dtype_emb;
+};
+
+MVLT_DEV int emb_word_id(const EmbDev& p, int b, int posi) {
+    // returns word id, or -1 when the source is the image feature
+    if (p.n_img < 0) return (int)p.text[(long)b * p.T + posi];            // cached step: text only
+    if (posi == 0) return p.cls_id;
+    if (posi <= p.n_img) return -1;
+    if (posi == p.n_img + 1) return p.sep_id;
+    return (int)p.text[(long)b * p.T + (posi - p.n_img - 2)];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbDev p) {
+    const int HV = p.H / 4;
+    const long total = (long)p.B * p.L * HV;
+    const T* img = reinterpret_cast<const T*>(p.img);
+    T* out = reinterpret_cast<T*>(p.out);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % HV) * 4;
+        const int posi = (int)((idx / HV) % p.L), b = (int)(idx / ((long)HV * p.L));
+        const int wid = emb_word_id(p, b, posi);
+        f32x4 v = wid >= 0 ? load4f(p.word + (long)wid * p.H + c)
+                           : load4f(img + ((long)b * p.n_img + (posi - 1)) * p.H + c);
+        const int ty = p.type_override >= 0 ? p.type_override : (posi <= p.n_img + 1 ? 1 : 0);
+        v += load4f(p.type + (long)ty * p.H + c);
+        v += load4f(p.pos + (long)(posi + p.pos_offset) * p.H + c);
+        store4f(out + ((long)b * p.L + posi) * p.H + c, v);
+    }
+}
+
+// dimage copy + scatter-add of word rows (f32 atomics, one contiguous row per wave-instruction group)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_tokens_kernel(const EmbDev p) {
+    const int HV = p.H / 4;
+    const long total = (long)p.B * p.L * HV;
+    const T* dout = reinterpret_cast<const T*>(p.dout);
+    T* dimg = reinterpret_cast<T*>(p.dimage);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % HV) * 4;
+        const int posi = (int)((idx / HV) % p.L), b = (int)(idx / ((long)HV * p.L));
+        const f32x4 g = load4f(dout + ((long)b * p.L + posi) * p.H + c);
+        const int wid = emb_word_id(p, b, posi);
+        if (wid < 0) { if (dimg) store4f(dimg + ((long)b * p.n_img + (posi - 1)) * p.H + c, g); }
+        else if (p.dword && posi != 0 && posi != p.n_img + 1) {
+            float* d = p.dword + (long)wid * p.H + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(d + e, g[e]);
+        }
+    }
+}
+// dpos[pos] += sum_b dout[b,pos]; CLS / SEP word rows and the two type rows follow from it
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const EmbDev p) {
+    const long total = (long)p.L * p.H;
+    const T* dout = reinterpret_cast<const T*>(p.dout);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % p.H), posi = (int)(idx / p.H);
+        float s = 0.f;
+        for (int b = 0; b < p.B; ++b) s += to_f(dout[((long)b * p.L + posi) * p.H + c]);
+        if (p.dpos) p.dpos[(long)(posi + p.pos_offset) * p.H + c] += s;
+        if (p.dword && p.n_img >= 0) {
+            if (posi == 0) atomicAdd(&p.dword[(long)p.cls_id * p.H + c], s);
+            if (posi == p.n_img + 1) atomicAdd(&p.dword[(long)p.sep_id * p.H + c], s);
+        }
+        if (p.dtype_emb) {
+            const int ty = p.type_override >= 0 ? p.type_override : (posi <= p.n_img + 1 ? 1 : 0);
+            atomicAdd(&p.dtype_emb[(long)ty * p.H + c], s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ row transform
+template <typename T>
+__global__ __launch_bounds__(256) void rows_transform_kernel(const T* in, T* out, int rows, int C, const int* rowmap,
+                                                            const float* rowscale, int rps, uint32_t thresh,
+                                                            float dscale, uint64_t seed, uint32_t tag) {
+    const int CV = C / 4;
+    const long total = (long)rows * CV;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % CV) * 4, i = (int)(idx / CV);
+        const int src = rowmap ? rowmap[i] : i;
+        f32x4 v = load4f(in + (long)src * C + c);
+        if (thresh) {
+            const uint32_t base = (uint32_t)src * (uint32_t)C + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rng_keep(seed, tag, base + e, thresh) ? v[e] * dscale : 0.f;
+        }
+        if (rowscale) { const float s = rowscale[src / rps];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= s; }
+        store4f(out + (long)i * C + c, v);
+    }
+}
+
+// ------------------------------------------------------------------ elementwise
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* src, D* dst, long n) {
+    const long nv = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256)
+        store4f(dst + 4 * i, load4f(src + 4 * i));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[nv * 4 + threadIdx.x] = from_f<D>(to_f(src[nv * 4 + threadIdx.x]));
+}
+template <typename T, int OP>   // 0 gelu, 1 tanh, 2 tanh-bwd (y, dy -> dx)
+__global__ __launch_bounds__(256) void unary_kernel(const T* a, const T* b, T* o, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float x = to_f(a[i]);
+        float r;
+        if (OP == 0) r = gelu_f(x);
+        else if (OP == 1) r = tanhf(x);
+        else r = to_f(b[i]) * (1.0f - x * x);
+        o[i] = from_f<T>(r);
+    }
+}
+__global__ void dropout_mask_kernel(uint8_t* keep, long n, uint32_t thresh, uint64_t seed, uint32_t tag) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        keep[i] = rng_keep(seed, tag, (uint32_t)i, thresh) ? 1 : 0;
+}
+__global__ void droppath_kernel(float* scale, int B, uint32_t thresh, float inv_keep, uint64_t seed, uint32_t tag) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) scale[b] = rng_keep(seed, tag, (uint32_t)b, thresh) ? inv_keep : 0.f;
+}
+
+// ------------------------------------------------------------------ column sums
+constexpr int COLSUM_ROWS = 128;   // partial rows
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* x, long ld, int M, int N, float* part) {
+    // block (bx over 4-column groups x 64, by over row slices): thread = 4 columns x row slice
+    const int cg = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rsub = threadIdx.x >> 6;                       // 4 row sub-slices per block
+    __shared__ f32x4 red[4][64];
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+    const int c = cg * 4;
+    if (c < N) {
+        const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+        const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+        for (int r = r0 + rsub; r < r1; r += 4) {
+            if (c + 3 < N && (ld & 3) == 0) acc += load4f(x + (long)r * ld + c);
+            else for (int e = 0; e < 4; ++e) if (c + e < N) acc[e] += to_f(x[(long)r * ld + c + e]);
+        }
+    }
+    red[rsub][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rsub == 0 && c < N) {
+        f32x4 s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        for (int e = 0; e < 4; ++e) if (c + e < N) part[(long)blockIdx.y * N + c + e] = s[e];
+    }
+}
+__global__ void colsum_final_kernel(const float* part, int nparts, int N, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < nparts; ++i) s += part[(long)i * N + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ------------------------------------------------------------------ cross entropy
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* logits, long ld, int rows, int V, const int64_t* labels,
+                                                    float* lse, float* loss_sum, float* count) {
+    // one workgroup per row (rows with ignore_index are skipped entirely)
+    __shared__ float red[8];
+    const int r = blockIdx.x;
+    const long lab = labels[r];
+    if (lab < 0) { if (threadIdx.x == 0 && lse) lse[r] = 0.f; return; }
+    const T* x = logits + (long)r * ld;
+    float mx = -3.0e38f;
+    for (int c = threadIdx.x * 4; c < V; c += 1024) {
+        if (c + 3 < V && (ld & 3) == 0) { const f32x4 v = load4f(x + c); mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); }
+        else for (int e = 0; e < 4 && c + e < V; ++e) mx = fmaxf(mx, to_f(x[c + e]));
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int c = threadIdx.x * 4; c < V; c += 1024) {
+        if (c + 3 < V && (ld & 3) == 0) { const f32x4 v = load4f(x + c); s += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx); }
+        else for (int e = 0; e < 4 && c + e < V; ++e) s += __expf(to_f(x[c + e]) - mx);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l = mx + logf(red[4] + red[5] + red[6] + red[7]);
+        if (lse) lse[r] = l;
+        atomicAdd(loss_sum, l - to_f(x[lab]));
+        atomicAdd(count, 1.0f);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, long ld, int rows, int V, const int64_t* labels,
+                                                    const float* lse, const float* count, float gscale, T* dl) {
+    const int r = blockIdx.x;
+    const long lab = labels[r];
+    const T* x = logits + (long)r * ld;
+    T* d = dl + (long)r * ld;
+    const float sc = gscale / fmaxf(count[0], 1.0f);
+    const float l = lab >= 0 ? lse[r] : 0.f;
+    for (int c = threadIdx.x * 4; c < ld; c += 1024) {
+        f32x4 g{0.f, 0.f, 0.f, 0.f};
+        if (lab >= 0) {
+            if (c + 3 < ld && (ld & 3) == 0) { const f32x4 v = load4f(x + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = (c + e < V) ? sc * (__expf(v[e] - l) - ((long)(c + e) == lab ? 1.f : 0.f)) : 0.f;
+            } else for (int e = 0; e < 4 && c + e < V; ++e) g[e] = sc * (__expf(to_f(x[c + e]) - l) - ((long)(c + e) == lab ? 1.f : 0.f));
+        }
+        if (c + 3 < ld && (ld & 3) == 0) store4f(d + c, g);
+        else for (int e = 0; e < 4 && c + e < ld; ++e) d[c + e] = from_f<T>(g[e]);
+    }
+}
+
+// ------------------------------------------------------------------ AdamW
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* sh, long n,
+                                                   float lr, float b1, float b2, float eps, float wd,
+                                                   float bc1, float bc2_sqrt, float gscale) {
+    // torch.optim.AdamW (single tensor path): p *= 1-lr*wd; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+    const long nv = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        f32x4 pp = load4f(p + 4 * i), gg = load4f(g + 4 * i), mm = load4f(m + 4 * i), vv = load4f(v + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * gscale;
+            pp[e] *= 1.0f - lr * wd;
+            mm[e] = b1 * mm[e] + (1.0f - b1) * gr;
+            vv[e] = b2 * vv[e] + (1.0f - b2) * gr * gr;
+            pp[e] -= (lr / bc1) * mm[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
+        }
+        store4f(p + 4 * i, pp); store4f(m + 4 * i, mm); store4f(v + 4 * i, vv);
+        if (sh) store4f(sh + 4 * i, pp);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = nv * 4 + threadIdx.x;
+        const float gr = g[i] * gscale;
+        float pp = p[i] * (1.0f - lr * wd);
+        const float mm = b1 * m[i] + (1.0f - b1) * gr, vv = b2 * v[i] + (1.0f - b2) * gr * gr;
+        pp -= (lr / bc1) * mm / (sqrtf(vv) / bc2_sqrt + eps);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (sh) sh[i] = (bf16_t)pp;
+    }
+}
+
+// ------------------------------------------------------------------ decode: cached attention + argmax
+template <typename T>
+__global__ __launch_bounds__(64) void attn_cached_kernel(const MvltAttnCached p) {
+    // one wave = one (b, head, new row); hd = 64 -> lane owns one feature; keys streamed from the cache
+    const int lane = threadIdx.x;
+    const int row = blockIdx.x % p.n_new, h = (blockIdx.x / p.n_new) % p.nH, b = blockIdx.x / (p.n_new * p.nH);
+    const int C = p.nH * p.hd;
+    const T* qkv = reinterpret_cast<const T*>(p.qkv_new);
+    T* kc = reinterpret_cast<T*>(p.k_cache) + ((long)b * p.nH + h) * p.cache_cap * p.hd;
+    T* vc = reinterpret_cast<T*>(p.v_cache) + ((long)b * p.nH + h) * p.cache_cap * p.hd;
+    // append this row's K/V (each (b,h,row) wave appends its own row)
+    const T* src = qkv + ((long)b * p.n_new + row) * 3 * C + h * p.hd;
+    if (lane < p.hd) {
+        kc[(long)(p.past + row) * p.hd + lane] = src[C + lane];
+        vc[(long)(p.past + row) * p.hd + lane] = src[2 * C + lane];
+    }
+    const float q = lane < p.hd ? to_f(src[lane]) * p.scale : 0.f;
+    const int nk = p.past + row + 1;                     // causal over the new tokens (model.py:97-104)
+    float m = -3.0e38f, l = 0.f, o = 0.f;
+    for (int k = 0; k < nk; ++k) {
+        float kv, vv;
+        if (k < p.past) { kv = lane < p.hd ? to_f(kc[(long)k * p.hd + lane]) : 0.f; vv = lane < p.hd ? to_f(vc[(long)k * p.hd + lane]) : 0.f; }
+        else {   // rows appended in this launch: read them from qkv_new (other waves may not have stored yet)
+            const T* s2 = qkv + ((long)b * p.n_new + (k - p.past)) * 3 * C + h * p.hd;
+            kv = lane < p.hd ? to_f(s2[C + lane]) : 0.f; vv = lane < p.hd ? to_f(s2[2 * C + lane]) : 0.f;
+        }
+        const float s = wave_sum(q * kv);
+        const float mn = fmaxf(m, s);
+        const float a = __expf(m - mn), e = __expf(s - mn);
+        l = l * a + e; o = o * a + e * vv; m = mn;
+    }
+    if (lane < p.hd) reinterpret_cast<T*>(p.out)[((long)b * p.n_new + row) * C + h * p.hd + lane] = from_f<T>(o / l);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_kernel(const T* logits, long ld, int V, int64_t* out) {
+    __shared__ float bv[4]; __shared__ int bi[4];
+    const T* x = logits + (long)blockIdx.x * ld;
+    float best = -3.0e38f; int idx = 0x7fffffff;
+    for (int c = threadIdx.x; c < V; c += 256) { const float v = to_f(x[c]); if (v > best) { best = v; idx = c; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[blockIdx.x] = idx;
+    }
+}
+
+}  // namespace
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+#define BY_DTYPE(dt, CALL_F32, CALL_BF16) do { if ((dt) == MVLT_F32) { CALL_F32; } else if ((dt) == MVLT_BF16) { CALL_BF16; } else return MVLT_ERR_UNSUPPORTED; } while (0)
+
+extern "C" int mvlt_version(void) { return 1; }
+extern "C" const char* mvlt_arch(void) { return "gfx950"; }
+
+extern "C" int mvlt_im2col_patch(int dtype, const float* img, void* cols, int B, int Cin, int S, int P, void* stream) {
+    MVLT_CHECK(img && cols && B > 0 && Cin > 0 && P > 0 && S % P == 0, MVLT_ERR_ARG);
+    MVLT_CHECK(aligned16(img) && aligned16(cols), MVLT_ERR_ARG);
+    const long total = (long)B * (S / P) * (S / P) * Cin * P;
+    const int g = grid_for(total, 256);
+    BY_DTYPE(dtype,
+             hipLaunchKernelGGL(im2col_kernel<float>, dim3(g), dim3(256), 0, STREAM(stream), img, (float*)cols, B, Cin, S, P),
+             hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(g), dim3(256), 0, STREAM(stream), img, (bf16_t*)cols, B, Cin, S, P));
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+static int fill_emb(const MvltEmbed* p, EmbDev& d) {
+    MVLT_CHECK(p && p->B > 0 && p->H > 0 && p->H % 4 == 0 && p->word_emb && p->pos_emb && p->type_emb, MVLT_ERR_ARG);
+    MVLT_CHECK(p->T == 0 || p->text_ids, MVLT_ERR_ARG);
+    d.B = p->B; d.n_img = p->n_img; d.T = p->T; d.H = p->H;
+    d.L = p->n_img < 0 ? p->T : p->n_img + 2 + p->T;
+    d.text = p->text_ids; d.img = p->image_feature; d.word = p->word_emb; d.pos = p->pos_emb; d.type = p->type_emb;
+    d.cls_id = p->cls_id; d.sep_id = p->sep_id; d.pos_offset = p->pos_offset; d.type_override = p->type_override;
+    d.out = p->out; d.dout = p->dout; d.dimage = p->dimage; d.dword = p->dword; d.dpos = p->dpos; d.dtype_emb = p->dtype_emb;
+    if (p->n_img >= 0) MVLT_CHECK(p->image_feature || p->dout, MVLT_ERR_ARG);
+    return MVLT_OK;
+}
+extern "C" int mvlt_embed_fwd(const MvltEmbed* p, void* stream) {
+    EmbDev d{}; int rc = fill_emb(p, d); if (rc) return rc;
+    MVLT_CHECK(p->out && (p->n_img < 0 || p->image_feature), MVLT_ERR_ARG);
+    const int g = grid_for((long)d.B * d.L * (d.H / 4), 256);
+    BY_DTYPE(p->dtype, hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(g), dim3(256), 0, STREAM(stream), d),
+             hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, STREAM(stream), d));
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+extern "C" int mvlt_embed_bwd(const MvltEmbed* p, void* stream) {
+    EmbDev d{}; int rc = fill_emb(p, d); if (rc) return rc;
+    MVLT_CHECK(p->dout, MVLT_ERR_ARG);
+    const int g = grid_for((long)d.B * d.L * (d.H / 4), 256);
+    const int g2 = grid_for((long)d.L * d.H, 256);
+    BY_DTYPE(p->dtype,
+             { hipLaunchKernelGGL(embed_bwd_tokens_kernel<float>, dim3(g), dim3(256), 0, STREAM(stream), d);
+               hipLaunchKernelGGL(embed_bwd_pos_kernel<float>, dim3(g2), dim3(256), 0, STREAM(stream), d); },
+             { hipLaunchKernelGGL(embed_bwd_tokens_kernel<bf16_t>, dim3(g), dim3(256), 0, STREAM(stream), d);
+               hipLaunchKernelGGL(embed_bwd_pos_kernel<bf16_t>, dim3(g2), dim3(256), 0, STREAM(stream), d); });
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_rows_transform(int dtype, const void* in, void* out, int rows, int C, const int32_t* rowmap,
+                                   const float* rowscale, int rows_per_scale, float dropout_p, uint64_t seed,
+                                   uint32_t tag, void* stream) {
+    MVLT_CHECK(in && out && rows > 0 && C > 0 && C % 4 == 0 && dropout_p >= 0.f && dropout_p < 1.f, MVLT_ERR_ARG);
+    MVLT_CHECK((double)rows * C < 4294967296.0, MVLT_ERR_ARG);
+    const uint32_t th = (uint32_t)((double)dropout_p * 4294967296.0);
+    const float ds = 1.0f / (1.0f - dropout_p);
+    const int rps = rows_per_scale > 0 ? rows_per_scale : 1;
+    const int g = grid_for((long)rows * (C / 4), 256);
+    BY_DTYPE(dtype,
+             hipLaunchKernelGGL(rows_transform_kernel<float>, dim3(g), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, rows, C, rowmap, rowscale, rps, th, ds, seed, tag),
+             hipLaunchKernelGGL(rows_transform_kernel<bf16_t>, dim3(g), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, rows, C, rowmap, rowscale, rps, th, ds, seed, tag));
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_cast(int sd, const void* src, int dd, void* dst, int64_t n, void* stream) {
+    MVLT_CHECK(src && dst && n > 0 && aligned16(src) && aligned16(dst), MVLT_ERR_ARG);
+    const int g = grid_for(n / 4 + 1, 256);
+    hipStream_t s = STREAM(stream);
+    if (sd == MVLT_F32 && dd == MVLT_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, (long)n);
+    else if (sd == MVLT_BF16 && dd == MVLT_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, (long)n);
+    else if (sd == MVLT_F32 && dd == MVLT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, (long)n);
+    else if (sd == MVLT_BF16 && dd == MVLT_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, (long)n);
+    else return MVLT_ERR_UNSUPPORTED;
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+template <int OP>
+static int unary(int dtype, const void* a, const void* b, void* o, int64_t n, void* stream) {
+    MVLT_CHECK(a && o && n > 0, MVLT_ERR_ARG);
+    const int g = grid_for(n, 256);
+    BY_DTYPE(dtype,
+             hipLaunchKernelGGL((unary_kernel<float, OP>), dim3(g), dim3(256), 0, STREAM(stream), (const float*)a, (const float*)b, (float*)o, (long)n),
+             hipLaunchKernelGGL((unary_kernel<bf16_t, OP>), dim3(g), dim3(256), 0, STREAM(stream), (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)o, (long)n));
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+extern "C" int mvlt_gelu_fwd(int dtype, const void* x, void* y, int64_t n, void* stream) { return unary<0>(dtype, x, nullptr, y, n, stream); }
+extern "C" int mvlt_tanh_fwd(int dtype, const void* x, void* y, int64_t n, void* stream) { return unary<1>(dtype, x, nullptr, y, n, stream); }
+extern "C" int mvlt_tanh_bwd(int dtype, const void* y, const void* dy, void* dx, int64_t n, void* stream) {
+    MVLT_CHECK(dy, MVLT_ERR_ARG);
+    return unary<2>(dtype, y, dy, dx, n, stream);
+}
+
+extern "C" int mvlt_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint32_t tag, void* stream) {
+    MVLT_CHECK(keep && n > 0 && n < 4294967296LL && p >= 0.f && p < 1.f, MVLT_ERR_ARG);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM(stream), keep, (long)n,
+                       (uint32_t)((double)p * 4294967296.0), seed, tag);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+extern "C" int mvlt_droppath_scale(float* scale, int B, float p, uint64_t seed, uint32_t tag, void* stream) {
+    MVLT_CHECK(scale && B > 0 && p >= 0.f && p < 1.f, MVLT_ERR_ARG);
+    hipLaunchKernelGGL(droppath_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, STREAM(stream), scale, B,
+                       (uint32_t)((double)p * 4294967296.0), 1.0f / (1.0f - p), seed, tag);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_colsum_workspace_rows(int M) { (void)M; return COLSUM_ROWS; }
+extern "C" int mvlt_colsum(int dtype, const void* x, int64_t ld, int M, int N, float* out, int accumulate,
+                           float* workspace, void* stream) {
+    MVLT_CHECK(x && out && workspace && M > 0 && N > 0 && ld >= N, MVLT_ERR_ARG);
+    int slices = M / 64; if (slices < 1) slices = 1; if (slices > COLSUM_ROWS) slices = COLSUM_ROWS;
+    dim3 grid(ceil_div(ceil_div(N, 4), 64), slices);
+    BY_DTYPE(dtype,
+             hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, STREAM(stream), (const float*)x, (long)ld, M, N, workspace),
+             hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, STREAM(stream), (const bf16_t*)x, (long)ld, M, N, workspace));
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, STREAM(stream), workspace, slices, N, out, accumulate);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_ce_fwd(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
+                           float* lse, float* loss_sum, float* count, void* stream) {
+    MVLT_CHECK(logits && labels && loss_sum && count && rows > 0 && V > 0 && ld >= V, MVLT_ERR_ARG);
+    BY_DTYPE(dtype,
+             hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), (const float*)logits, (long)ld, rows, V, labels, lse, loss_sum, count),
+             hipLaunchKernelGGL(ce_fwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, (long)ld, rows, V, labels, lse, loss_sum, count));
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+extern "C" int mvlt_ce_bwd(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
+                           const float* lse, const float* count, float grad_scale, void* dlogits, void* stream) {
+    MVLT_CHECK(logits && labels && lse && count && dlogits && rows > 0 && V > 0 && ld >= V, MVLT_ERR_ARG);
+    BY_DTYPE(dtype,
+             hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), (const float*)logits, (long)ld, rows, V, labels, lse, count, grad_scale, (float*)dlogits),
+             hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, (long)ld, rows, V, labels, lse, count, grad_scale, (bf16_t*)dlogits));
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                          int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                          float grad_scale, void* stream) {
+    MVLT_CHECK(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, MVLT_ERR_ARG);
+    MVLT_CHECK(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq), MVLT_ERR_ARG);
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, STREAM(stream), param, grad, exp_avg,
+                       exp_avg_sq, (bf16_t*)shadow_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                       (float)sqrt(bc2), grad_scale);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_attn_cached(const MvltAttnCached* p, void* stream) {
+    MVLT_CHECK(p && p->qkv_new && p->k_cache && p->v_cache && p->out, MVLT_ERR_ARG);
+    MVLT_CHECK(p->hd > 0 && p->hd <= 64 && p->B > 0 && p->nH > 0 && p->n_new > 0 && p->past + p->n_new <= p->cache_cap, MVLT_ERR_ARG);
+    dim3 grid(p->B * p->nH * p->n_new);
+    BY_DTYPE(p->dtype, hipLaunchKernelGGL(attn_cached_kernel<float>, grid, dim3(64), 0, STREAM(stream), *p),
+             hipLaunchKernelGGL(attn_cached_kernel<bf16_t>, grid, dim3(64), 0, STREAM(stream), *p));
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+extern "C" int mvlt_argmax(int dtype, const void* logits, int64_t ld, int rows, int V, int64_t* out, void* stream) {
+    MVLT_CHECK(logits && out && rows > 0 && V > 0 && ld >= V, MVLT_ERR_ARG);
+    BY_DTYPE(dtype, hipLaunchKernelGGL(argmax_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), (const float*)logits, (long)ld, V, out),
+             hipLaunchKernelGGL(argmax_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, (long)ld, V, out));
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}

@@ -1,0 +1,269 @@
+// LayerNorm forward / backward for gfx950 (HBM-bound; see MvltLayerNorm in
+// include/mvlt_hip.h).  A row is owned by LPR lanes of one wave (16/32/64) and
+// kept in registers as NV 4-element vectors per lane (8/16-byte coalesced
+// loads), so x is read exactly once: algorithmic traffic = read x + write y.
+// The store can scatter rows (window partition + cyclic shift), the load can
+// gather the PatchMerging 2x2 neighbourhood, and GELU can be fused.
+#include "common.h"
+
+namespace {
+
+struct LnDev {
+    int rows, C; float eps;
+    const void* x; const float* gamma; const float* beta;
+    void* y; void* y_pre; float* mean; float* rstd;
+    const int* rowmap; int mH, mW; int gelu;
+    // backward
+    const void* dy; const void* dres; void* dx;
+    float* part_g; float* part_b; int nparts;
+};
+
+template <int LPR> MVLT_DEV float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// element offset of column c of logical row r
+template <bool MERGE>
+MVLT_DEV long in_offset(const LnDev& p, int r, int c) {
+    if (!MERGE) return (long)r * p.C + c;
+    const int Cq = p.C >> 2, Ho = p.mH >> 1, Wo = p.mW >> 1;
+    const int b = r / (Ho * Wo), rem = r % (Ho * Wo), i = rem / Wo, j = rem % Wo;
+    const int s = c / Cq, within = c % Cq;
+    const int h = 2 * i + (s & 1), w = 2 * j + (s >> 1);
+    return ((long)(b * p.mH + h) * p.mW + w) * Cq + within;
+}
+
+template <typename T, int LPR, int NV, bool MERGE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnDev p) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = lane % LPR;
+    const int r = (blockIdx.x * 4 + wave) * RPW + lane / LPR;
+    const bool rv = r < p.rows;
+    const T* x = reinterpret_cast<const T*>(p.x);
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = 4 * (sl + LPR * j);
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rv && c < p.C) v[j] = load4f(x + in_offset<MERGE>(p, r, c));
+        s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+    const float mean = group_sum<LPR>(s) / p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = 4 * (sl + LPR * j);
+        if (c < p.C) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(group_sum<LPR>(q) / p.C + p.eps);
+    if (!rv) return;
+    if (sl == 0) {
+        if (p.mean) p.mean[r] = mean;
+        if (p.rstd) p.rstd[r] = rstd;
+    }
+    const int ro = p.rowmap ? p.rowmap[r] : r;
+    T* y = reinterpret_cast<T*>(p.y) + (long)ro * p.C;
+    T* yp = p.y_pre ? reinterpret_cast<T*>(p.y_pre) + (long)ro * p.C : nullptr;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = 4 * (sl + LPR * j);
+        if (c < p.C) {
+            const f32x4 g = load4f(p.gamma + c), b = load4f(p.beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * g[e] + b[e];
+            if (p.gelu) {
+                if (yp) store4f(yp + c, o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = gelu_f(o[e]);
+            }
+            store4f(y + c, o);
+        }
+    }
+}
+
+template <typename T, int LPR, int NV, bool MERGE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnDev p) {
+    constexpr int RPW = 64 / LPR;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = lane % LPR;
+    for (int c = threadIdx.x; c < 2 * p.C; c += 256) red[c] = 0.f;
+    __syncthreads();
+    const T* x = reinterpret_cast<const T*>(p.x);
+    const T* dy = reinterpret_cast<const T*>(p.dy);
+    const T* ypre = reinterpret_cast<const T*>(p.y_pre);
+    const T* dres = reinterpret_cast<const T*>(p.dres);
+    T* dx = reinterpret_cast<T*>(p.dx);
+    f32x4 ag[NV], ab[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { ag[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[j] = ag[j]; }
+    const float invC = 1.0f / p.C;
+    for (int r0 = (blockIdx.x * 4 + wave) * RPW; r0 < p.rows; r0 += gridDim.x * 4 * RPW) {
+        const int r = r0 + lane / LPR;
+        const bool rv = r < p.rows;
+        const float mean = rv ? p.mean[r] : 0.f, rstd = rv ? p.rstd[r] : 0.f;
+        const int rd = (rv && p.rowmap) ? p.rowmap[r] : r;
+        f32x4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * (sl + LPR * j);
+            xh[j] = f32x4{0.f, 0.f, 0.f, 0.f}; g[j] = xh[j];
+            if (rv && c < p.C) {
+                f32x4 xv = load4f(x + in_offset<MERGE>(p, r, c));
+                f32x4 d = load4f(dy + (long)rd * p.C + c);
+                if (p.gelu) {
+                    f32x4 yp = load4f(ypre + (long)rd * p.C + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] *= gelu_grad_f(yp[e]);
+                }
+                const f32x4 gm = load4f(p.gamma + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[j][e] = (xv[e] - mean) * rstd;
+                    g[j][e] = d[e] * gm[e];
+                    s1 += g[j][e]; s2 += g[j][e] * xh[j][e];
+                    ag[j][e] += d[e] * xh[j][e]; ab[j][e] += d[e];
+                }
+            }
+        }
+        s1 = group_sum<LPR>(s1) * invC;
+        s2 = group_sum<LPR>(s2) * invC;
+        if (rv) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = 4 * (sl + LPR * j);
+                if (c < p.C) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rstd * (g[j][e] - s1 - xh[j][e] * s2);
+                    const long off = in_offset<MERGE>(p, r, c);
+                    if (dres) { f32x4 a = load4f(dres + off);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += a[e]; }
+                    store4f(dx + off, o);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = 4 * (sl + LPR * j);
+        if (c < p.C) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&red[c + e], ag[j][e]);
+                atomicAdd(&red[p.C + c + e], ab[j][e]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        p.part_g[(long)blockIdx.x * p.C + c] = red[c];
+        p.part_b[(long)blockIdx.x * p.C + c] = red[p.C + c];
+    }
+}
+
+__global__ void ln_param_reduce_kernel(const float* part_g, const float* part_b, int nparts, int C,
+                                       float* dgamma, float* dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, b = 0.f;
+    for (int i = 0; i < nparts; ++i) { g += part_g[(long)i * C + c]; b += part_b[(long)i * C + c]; }
+    if (accumulate) { g += dgamma[c]; b += dbeta[c]; }
+    dgamma[c] = g; dbeta[c] = b;
+}
+
+constexpr int LN_BWD_PARTS = 256;
+
+template <typename T, int LPR, int NV>
+void launch_fwd(const LnDev& d, bool merge, hipStream_t s) {
+    const int rpb = 4 * (64 / LPR);
+    dim3 grid(ceil_div(d.rows, rpb));
+    if (merge) hipLaunchKernelGGL((ln_fwd_kernel<T, LPR, NV, true>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((ln_fwd_kernel<T, LPR, NV, false>), grid, dim3(256), 0, s, d);
+}
+template <typename T, int LPR, int NV>
+void launch_bwd(LnDev d, bool merge, hipStream_t s) {
+    const int rpb = 4 * (64 / LPR);
+    int blocks = ceil_div(d.rows, rpb);
+    if (blocks > LN_BWD_PARTS) blocks = LN_BWD_PARTS;
+    d.nparts = blocks;
+    const size_t sh = 2 * (size_t)d.C * sizeof(float);
+    if (merge) hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, true>), dim3(blocks), dim3(256), sh, s, d);
+    else hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, false>), dim3(blocks), dim3(256), sh, s, d);
+}
+
+template <typename T, bool BWD>
+int dispatch(const LnDev& d, bool merge, hipStream_t s) {
+    const int C = d.C;
+#define LN_CASE(LPR, NV) do { if (BWD) launch_bwd<T, LPR, NV>(d, merge, s); else launch_fwd<T, LPR, NV>(d, merge, s); } while (0)
+    if (C <= 64) LN_CASE(16, 1);
+    else if (C <= 128) LN_CASE(32, 1);
+    else if (C <= 256) LN_CASE(64, 1);
+    else if (C <= 512) LN_CASE(64, 2);
+    else if (C <= 768) LN_CASE(64, 3);
+    else if (C <= 1024) LN_CASE(64, 4);
+    else if (C <= 1536) LN_CASE(64, 6);
+    else if (C <= 2048) LN_CASE(64, 8);
+    else return MVLT_ERR_UNSUPPORTED;
+#undef LN_CASE
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+}  // namespace
+
+extern "C" int mvlt_layernorm_bwd_workspace_rows(void) { return LN_BWD_PARTS; }
+
+extern "C" int mvlt_layernorm_fwd(const MvltLayerNorm* p, void* stream) {
+    MVLT_CHECK(p && p->x && p->y && p->gamma && p->beta, MVLT_ERR_ARG);
+    MVLT_CHECK(p->rows > 0 && p->C > 0 && p->C % 4 == 0, MVLT_ERR_ARG);
+    const bool merge = p->merge_H != 0;
+    if (merge) MVLT_CHECK(p->merge_H % 2 == 0 && p->merge_W % 2 == 0 && p->C % 16 == 0 &&
+                          p->rows % ((p->merge_H / 2) * (p->merge_W / 2)) == 0, MVLT_ERR_ARG);
+    LnDev d{};
+    d.rows = p->rows; d.C = p->C; d.eps = p->eps; d.x = p->x; d.gamma = p->gamma; d.beta = p->beta;
+    d.y = p->y; d.y_pre = p->y_pre; d.mean = p->mean; d.rstd = p->rstd; d.rowmap = p->out_rowmap;
+    d.mH = p->merge_H; d.mW = p->merge_W; d.gelu = p->gelu;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p->dtype == MVLT_F32) return dispatch<float, false>(d, merge, s);
+    if (p->dtype == MVLT_BF16) return dispatch<bf16_t, false>(d, merge, s);
+    return MVLT_ERR_UNSUPPORTED;
+}
+
+extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
+    MVLT_CHECK(p && p->dy && p->x && p->mean && p->rstd && p->gamma && p->dx, MVLT_ERR_ARG);
+    MVLT_CHECK(p->dgamma && p->dbeta && p->workspace, MVLT_ERR_ARG);
+    MVLT_CHECK(p->rows > 0 && p->C > 0 && p->C % 4 == 0, MVLT_ERR_ARG);
+    if (p->gelu) MVLT_CHECK(p->y_pre, MVLT_ERR_ARG);
+    const bool merge = p->merge_H != 0;
+    if (merge) MVLT_CHECK(p->merge_H % 2 == 0 && p->merge_W % 2 == 0 && p->C % 16 == 0 && !p->dres, MVLT_ERR_ARG);
+    LnDev d{};
+    d.rows = p->rows; d.C = p->C; d.x = p->x; d.gamma = p->gamma; d.mean = const_cast<float*>(p->mean);
+    d.rstd = const_cast<float*>(p->rstd); d.rowmap = p->dy_rowmap; d.mH = p->merge_H; d.mW = p->merge_W;
+    d.gelu = p->gelu; d.y_pre = const_cast<void*>(p->y_pre); d.dy = p->dy; d.dres = p->dres; d.dx = p->dx;
+    d.part_g = p->workspace; d.part_b = p->workspace + (size_t)LN_BWD_PARTS * p->C;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    if (p->dtype == MVLT_F32) rc = dispatch<float, true>(d, merge, s);
+    else if (p->dtype == MVLT_BF16) rc = dispatch<bf16_t, true>(d, merge, s);
+    else return MVLT_ERR_UNSUPPORTED;
+    if (rc != MVLT_OK) return rc;
+    // the number of partial rows written == number of blocks launched above
+    int lpr = p->C <= 64 ? 16 : (p->C <= 128 ? 32 : 64);
+    int blocks = ceil_div(p->rows, 4 * (64 / lpr));
+    if (blocks > LN_BWD_PARTS) blocks = LN_BWD_PARTS;
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(p->C, 256)), dim3(256), 0, s, d.part_g, d.part_b,
+                       blocks, p->C, p->dgamma, p->dbeta, p->accumulate);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}

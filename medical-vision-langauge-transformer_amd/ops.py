@@ -1,0 +1,384 @@
+"""Tensor-level wrappers over the C-ABI (include/mvlt_hip.h).
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP
+stream and dtype bookkeeping.  Every function launches hand-written gfx950
+kernels on torch's current stream; nothing falls back to eager torch math.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+_ws = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mvlt_amd ops run on the GPU only (no CPU fallback)")
+
+
+def workspace(name, nbytes, device):
+    key = (name, device.index)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------- GEMM
+def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=None, gelu=False,
+         save_pre=None, dropout=None, rowscale=None, residual=None, rowmap=None, mul_gelu_grad=None,
+         accumulate=False, split_k=0, ldc=None):
+    """C = epilogue(A @ B); see MvltGemm.  A: [M,K] (or [K,M] if a_kmajor);
+    B: [N,K] torch-Linear layout (or [K,N] if b_kmajor)."""
+    _need_cuda(A, B)
+    assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
+    assert A.stride(1) == 1 and B.stride(1) == 1
+    K, M = (A.shape if a_kmajor else A.shape[::-1])
+    if b_kmajor:
+        Kb, N = B.shape
+    else:
+        N, Kb = B.shape
+    assert K == Kb, f"inner dims differ: {K} vs {Kb}"
+    odt = torch.float32 if out_f32 else A.dtype
+    if out is None:
+        rows = M if rowmap is None else int(rowmap.numel())
+        out = torch.empty((rows, N if ldc is None else ldc), dtype=odt, device=A.device)
+    assert out.dtype == odt and out.stride(-1) == 1
+    p = L.MvltGemm()
+    p.dtype, p.M, p.N, p.K = _dt(A), M, N, K
+    p.A, p.lda, p.a_kmajor = _p(A), A.stride(0), int(a_kmajor)
+    p.B, p.ldb, p.b_kmajor = _p(B), B.stride(0), int(b_kmajor)
+    p.C, p.ldc = _p(out), out.stride(0) if out.dim() == 2 else N
+    epi = 0
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+        epi |= L.EPI_BIAS
+        p.bias = _p(bias)
+    if gelu:
+        epi |= L.EPI_GELU
+        if save_pre is not None:
+            assert save_pre.dtype == A.dtype and save_pre.stride(0) == p.ldc
+            epi |= L.EPI_SAVE_PRE
+            p.pre = _p(save_pre)
+    if dropout is not None and dropout[0] > 0.0:
+        epi |= L.EPI_DROPOUT
+        p.dropout_p, p.seed, p.tag = float(dropout[0]), int(dropout[1]), int(dropout[2])
+    if rowscale is not None:
+        epi |= L.EPI_ROWSCALE
+        p.rowscale, p.rows_per_scale = _p(rowscale[0]), int(rowscale[1])
+    if residual is not None:
+        assert residual.dtype == A.dtype and residual.stride(-1) == 1
+        epi |= L.EPI_RESIDUAL
+        p.residual, p.ldr = _p(residual), residual.stride(0)
+    if rowmap is not None:
+        assert rowmap.dtype == torch.int32
+        epi |= L.EPI_ROWMAP
+        p.rowmap = _p(rowmap)
+    if mul_gelu_grad is not None:
+        assert mul_gelu_grad.dtype == A.dtype and mul_gelu_grad.stride(0) == p.ldc
+        epi |= L.EPI_MUL_GELU_GRAD
+        p.aux = _p(mul_gelu_grad)
+    if out_f32:
+        epi |= L.EPI_OUT_F32
+    if accumulate:
+        epi |= L.EPI_ACCUM
+    p.epilogue = epi
+    p.split_k = split_k
+    lib = L.lib()
+    need = lib.mvlt_gemm_workspace_bytes(C.byref(p))
+    if need:
+        ws = workspace("gemm", need, A.device)
+        p.workspace, p.workspace_bytes = _p(ws), ws.numel()
+    L.check(lib.mvlt_gemm(C.byref(p), _stream()), "mvlt_gemm")
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    """out[n] = sum_m x[m,n] (f32) -- bias gradients."""
+    _need_cuda(x)
+    M, N = x.shape
+    lib = L.lib()
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = workspace("colsum", lib.mvlt_colsum_workspace_rows(M) * N * 4, x.device)
+    L.check(lib.mvlt_colsum(_dt(x), _p(x), x.stride(0), M, N, _p(out), int(accumulate), _p(ws), _stream()),
+            "mvlt_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, gamma, beta, eps, *, rows=None, C_=None, out=None, out_rowmap=None, merge=None, gelu=False,
+                  save_pre=False, save_stats=True):
+    """x: [..., C] contiguous (or the un-merged [B,H*W,C/4] tensor when merge=(H,W))."""
+    _need_cuda(x)
+    assert x.is_contiguous() and gamma.dtype == torch.float32
+    Cn = gamma.numel()
+    if merge is None:
+        nrows = x.numel() // Cn
+        oshape = x.shape
+    else:
+        H, W = merge
+        nrows = x.numel() // Cn
+        oshape = (x.shape[0], (H // 2) * (W // 2), Cn)
+    y = out if out is not None else torch.empty(oshape, dtype=x.dtype, device=x.device)
+    p = L.MvltLayerNorm()
+    p.dtype, p.rows, p.C, p.eps = _dt(x), nrows, Cn, float(eps)
+    p.x, p.gamma, p.beta, p.y = _p(x), _p(gamma), _p(beta), _p(y)
+    mean = rstd = ypre = None
+    if save_stats:
+        mean = torch.empty(nrows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(nrows, dtype=torch.float32, device=x.device)
+        p.mean, p.rstd = _p(mean), _p(rstd)
+    if gelu:
+        p.gelu = 1
+        if save_pre:
+            ypre = torch.empty_like(y)
+            p.y_pre = _p(ypre)
+    if out_rowmap is not None:
+        assert out_rowmap.dtype == torch.int32 and out_rowmap.numel() == nrows
+        p.out_rowmap = _p(out_rowmap)
+    if merge is not None:
+        p.merge_H, p.merge_W = merge
+    L.check(L.lib().mvlt_layernorm_fwd(C.byref(p), _stream()), "mvlt_layernorm_fwd")
+    return y, mean, rstd, ypre
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_pre=None, dres=None, merge=None,
+                  accumulate=False, dx=None):
+    _need_cuda(dy, x)
+    Cn = gamma.numel()
+    nrows = mean.numel()
+    if dx is None:
+        dx = torch.empty_like(x)
+    lib = L.lib()
+    ws = workspace("ln_bwd", 2 * lib.mvlt_layernorm_bwd_workspace_rows() * Cn * 4, x.device)
+    p = L.MvltLayerNormBwd()
+    p.dtype, p.rows, p.C = _dt(x), nrows, Cn
+    p.dy, p.x, p.mean, p.rstd, p.gamma = _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma)
+    if dy_rowmap is not None:
+        p.dy_rowmap = _p(dy_rowmap)
+    if y_pre is not None:
+        p.y_pre, p.gelu = _p(y_pre), 1
+    if dres is not None:
+        p.dres = _p(dres)
+    p.dx = _p(dx)
+    if merge is not None:
+        p.merge_H, p.merge_W = merge
+    p.dgamma, p.dbeta, p.accumulate, p.workspace = _p(dgamma), _p(dbeta), int(accumulate), _p(ws)
+    L.check(lib.mvlt_layernorm_bwd(C.byref(p), _stream()), "mvlt_layernorm_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_struct(qkv, out, lse, mode, nseq, Lq, nH, hd, scale, *, bias_table=None, nW=0, win_res=0, shift=0,
+                 text_ids=None, image_mask=None, obj_end=0, dropout=None):
+    p = L.MvltAttn()
+    p.dtype, p.mode, p.nseq, p.L, p.nH, p.hd = _dt(qkv), mode, nseq, Lq, nH, hd
+    p.qkv, p.out, p.lse, p.scale = _p(qkv), _p(out), _p(lse), float(scale)
+    if bias_table is not None:
+        assert bias_table.dtype == torch.float32
+        p.bias_table, p.nW, p.win_res, p.shift = _p(bias_table), nW, win_res, shift
+    if text_ids is not None:
+        assert text_ids.dtype == torch.int64 and text_ids.is_contiguous()
+        p.text_ids, p.T = _p(text_ids), text_ids.shape[1]
+    if image_mask is not None:
+        p.image_mask = _p(image_mask)
+    p.obj_end = obj_end
+    if dropout is not None and dropout[0] > 0.0:
+        p.dropout_p, p.seed, p.tag = float(dropout[0]), int(dropout[1]), int(dropout[2])
+    return p
+
+
+def attn_fwd(qkv, mode, nseq, Lq, nH, hd, scale, **kw):
+    """qkv: [nseq*L, 3*nH*hd] -> (out [nseq*L, nH*hd], lse [nseq,nH,L])."""
+    _need_cuda(qkv)
+    assert qkv.is_contiguous() and qkv.shape == (nseq * Lq, 3 * nH * hd)
+    out = torch.empty((nseq * Lq, nH * hd), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((nseq, nH, Lq), dtype=torch.float32, device=qkv.device)
+    p = _attn_struct(qkv, out, lse, mode, nseq, Lq, nH, hd, scale, **kw)
+    L.check(L.lib().mvlt_attn_fwd(C.byref(p), _stream()), "mvlt_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(dout, qkv, out, lse, mode, nseq, Lq, nH, hd, scale, dbias_table=None, **kw):
+    _need_cuda(qkv, dout)
+    assert dout.is_contiguous() and dout.shape == out.shape
+    dqkv = torch.empty_like(qkv)
+    p = _attn_struct(qkv, out, lse, mode, nseq, Lq, nH, hd, scale, **kw)
+    p.dout, p.dqkv = _p(dout), _p(dqkv)
+    if dbias_table is not None:
+        assert dbias_table.dtype == torch.float32
+        p.dbias_table = _p(dbias_table)
+    L.check(L.lib().mvlt_attn_bwd(C.byref(p), _stream()), "mvlt_attn_bwd")
+    return dqkv
+
+
+# ----------------------------------------------------------------------------- data movement
+def im2col_patch(img, dtype, patch):
+    _need_cuda(img)
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4 and img.shape[2] == img.shape[3]
+    B, Cin, S, _ = img.shape
+    G = S // patch
+    cols = torch.empty((B * G * G, Cin * patch * patch), dtype=dtype, device=img.device)
+    L.check(L.lib().mvlt_im2col_patch(_DT[dtype], _p(img), _p(cols), B, Cin, S, patch, _stream()), "mvlt_im2col_patch")
+    return cols
+
+
+def _embed_struct(dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_id, pos_offset, type_override):
+    p = L.MvltEmbed()
+    p.dtype, p.B, p.n_img, p.T, p.H = _DT[dtype], B, n_img, T, H
+    if text_ids is not None:
+        assert text_ids.dtype == torch.int64 and text_ids.is_contiguous()
+        p.text_ids = _p(text_ids)
+    p.word_emb, p.pos_emb, p.type_emb = _p(word), _p(pos), _p(typ)
+    p.cls_id, p.sep_id, p.pos_offset, p.type_override = cls_id, sep_id, pos_offset, type_override
+    return p
+
+
+def embed_fwd(text_ids, image_feature, word, pos, typ, cls_id, sep_id, *, dtype=None, pos_offset=0,
+              type_override=-1):
+    """MVLBert.get_embedding sum.  image_feature None -> cached-step (text only) layout."""
+    if image_feature is not None:
+        B, n_img, H = image_feature.shape
+        dtype = image_feature.dtype
+        assert image_feature.is_contiguous()
+    else:
+        B, n_img, H = text_ids.shape[0], -1, word.shape[1]
+    T = 0 if text_ids is None else text_ids.shape[1]
+    Lq = T if n_img < 0 else n_img + 2 + T
+    out = torch.empty((B, Lq, H), dtype=dtype, device=word.device)
+    p = _embed_struct(dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_id, pos_offset, type_override)
+    p.image_feature, p.out = _p(image_feature), _p(out)
+    L.check(L.lib().mvlt_embed_fwd(C.byref(p), _stream()), "mvlt_embed_fwd")
+    return out
+
+
+def embed_bwd(dout, text_ids, n_img, word, pos, typ, cls_id, sep_id, dword, dpos, dtype_emb, *, want_dimage=True,
+              pos_offset=0, type_override=-1):
+    B, Lq, H = dout.shape
+    T = 0 if text_ids is None else text_ids.shape[1]
+    dimg = torch.empty((B, n_img, H), dtype=dout.dtype, device=dout.device) if (want_dimage and n_img > 0) else None
+    p = _embed_struct(dout.dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_id, pos_offset, type_override)
+    assert dout.is_contiguous()
+    p.dout, p.dimage, p.dword, p.dpos, p.dtype_emb = _p(dout), _p(dimg), _p(dword), _p(dpos), _p(dtype_emb)
+    L.check(L.lib().mvlt_embed_bwd(C.byref(p), _stream()), "mvlt_embed_bwd")
+    return dimg
+
+
+def rows_transform(x, *, rowmap=None, rowscale=None, dropout=None, out=None):
+    """out[i] = scale * mask(x[rowmap[i]]) (DropPath / dropout backward, window gathers)."""
+    _need_cuda(x)
+    assert x.is_contiguous() and x.dim() == 2
+    rows = x.shape[0] if rowmap is None else rowmap.numel()
+    if out is None:
+        out = torch.empty((rows, x.shape[1]), dtype=x.dtype, device=x.device)
+    dp, seed, tag = (dropout if dropout is not None else (0.0, 0, 0))
+    rs, rps = (rowscale if rowscale is not None else (None, 1))
+    L.check(L.lib().mvlt_rows_transform(_dt(x), _p(x), _p(out), rows, x.shape[1], _p(rowmap), _p(rs), rps,
+                                        float(dp), int(seed), int(tag), _stream()), "mvlt_rows_transform")
+    return out
+
+
+def cast(x, dtype, out=None):
+    _need_cuda(x)
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    L.check(L.lib().mvlt_cast(_dt(x), _p(x), _DT[dtype], _p(out), x.numel(), _stream()), "mvlt_cast")
+    return out
+
+
+def gelu(x):
+    y = torch.empty_like(x)
+    L.check(L.lib().mvlt_gelu_fwd(_dt(x), _p(x), _p(y), x.numel(), _stream()), "mvlt_gelu_fwd")
+    return y
+
+
+def tanh_fwd(x):
+    y = torch.empty_like(x)
+    L.check(L.lib().mvlt_tanh_fwd(_dt(x), _p(x), _p(y), x.numel(), _stream()), "mvlt_tanh_fwd")
+    return y
+
+
+def tanh_bwd(y, dy):
+    dx = torch.empty_like(y)
+    L.check(L.lib().mvlt_tanh_bwd(_dt(y), _p(y), _p(dy), _p(dx), y.numel(), _stream()), "mvlt_tanh_bwd")
+    return dx
+
+
+def dropout_mask(n, p, seed, tag, device):
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    L.check(L.lib().mvlt_dropout_mask(_p(keep), n, float(p), int(seed), int(tag), _stream()), "mvlt_dropout_mask")
+    return keep
+
+
+def droppath_scale(B, p, seed, tag, device):
+    s = torch.empty(B, dtype=torch.float32, device=device)
+    L.check(L.lib().mvlt_droppath_scale(_p(s), B, float(p), int(seed), int(tag), _stream()), "mvlt_droppath_scale")
+    return s
+
+
+# ----------------------------------------------------------------------------- loss / optimizer / decode
+def ce_fwd(logits, V, labels):
+    """logits [rows, ld>=V]; returns (loss_sum, count, lse) device tensors (mean = sum/count)."""
+    _need_cuda(logits)
+    rows = logits.shape[0]
+    assert labels.dtype == torch.int64 and labels.numel() == rows and labels.is_contiguous()
+    acc = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    L.check(L.lib().mvlt_ce_fwd(_dt(logits), _p(logits), logits.stride(0), rows, V, _p(labels), _p(lse),
+                                C.c_void_p(acc.data_ptr()), C.c_void_p(acc.data_ptr() + 4), _stream()), "mvlt_ce_fwd")
+    return acc, lse
+
+
+def ce_bwd(logits, V, labels, lse, acc, grad_scale=1.0, out=None):
+    if out is None:
+        out = logits
+    L.check(L.lib().mvlt_ce_bwd(_dt(logits), _p(logits), logits.stride(0), logits.shape[0], V, _p(labels), _p(lse),
+                                C.c_void_p(acc.data_ptr() + 4), float(grad_scale), _p(out), _stream()), "mvlt_ce_bwd")
+    return out
+
+
+def adamw(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _need_cuda(param)
+    L.check(L.lib().mvlt_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), param.numel(),
+                               float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                               float(grad_scale), _stream()), "mvlt_adamw")
+
+
+def attn_cached(qkv_new, k_cache, v_cache, past, scale):
+    B, nH, cap, hd = k_cache.shape
+    n_new = qkv_new.shape[0] // B
+    out = torch.empty((B * n_new, nH * hd), dtype=qkv_new.dtype, device=qkv_new.device)
+    p = L.MvltAttnCached()
+    p.dtype, p.B, p.nH, p.hd, p.past, p.n_new, p.cache_cap = _dt(qkv_new), B, nH, hd, past, n_new, cap
+    p.qkv_new, p.k_cache, p.v_cache, p.out, p.scale = _p(qkv_new), _p(k_cache), _p(v_cache), _p(out), float(scale)
+    L.check(L.lib().mvlt_attn_cached(C.byref(p), _stream()), "mvlt_attn_cached")
+    return out
+
+
+def argmax(logits, V):
+    out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    L.check(L.lib().mvlt_argmax(_dt(logits), _p(logits), logits.stride(0), logits.shape[0], V, _p(out), _stream()),
+            "mvlt_argmax")
+    return out

@@ -1,0 +1,376 @@
+"""Kernel-level parity (GPU): every C-ABI entry point against a plain PyTorch
+fp32 statement of the same op on the same seeded inputs.  Tolerances: f32 path
+1e-5 (exact f32 MFMA), bf16 path: inputs are rounded to bf16 first so only the
+output rounding (2^-9) and accumulation order differ."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return 2e-5 if dt == torch.float32 else 6e-3
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(shape, dt, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dt).cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mvlt_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("ak,bk", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(200, 96, 48), (333, 384, 200), (130, 768, 768), (77, 30, 50), (64, 2, 768),
+                                   (1000, 288, 96)])
+def test_gemm_layouts(ops, dt, ak, bk, M, N, K):
+    A = rnd((M, K), dt, 1)
+    B = rnd((N, K), dt, 2)
+    ref = A.float() @ B.float().t()
+    Ain = A.t().contiguous() if ak else A
+    Bin = B.t().contiguous() if bk else B
+    out = ops.gemm(Ain, Bin, a_kmajor=ak, b_kmajor=bk)
+    assert out.shape == (M, N)
+    assert rel(out, ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_asymmetric_integer_exact(ops, dt):
+    """A = I-like / asymmetric B catches row<->col swaps of the MFMA C layout."""
+    M, N, K = 64, 96, 64
+    A = torch.zeros(M, K)
+    A[torch.arange(M), torch.arange(M) % K] = 1.0
+    B = (torch.arange(N * K).reshape(N, K) % 7 - 3).float() + (torch.arange(N)[:, None] % 5).float()
+    out = ops.gemm(A.to(dt).cuda(), B.to(dt).cuda())
+    assert torch.equal(out.float().cpu(), A @ B.t())
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("split", [0, 3, 16])
+def test_gemm_splitk_wgrad_shape(ops, dt, split):
+    # wgrad-like: tiny output, huge reduction
+    Mtok, Nout, Kin = 5000, 96, 192
+    dY = rnd((Mtok, Nout), dt, 3, 0.1)
+    X = rnd((Mtok, Kin), dt, 4, 0.1)
+    ref = dY.float().t() @ X.float()
+    out = ops.gemm(dY, X, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=split)
+    assert out.dtype == torch.float32 and rel(out, ref) < (1e-5 if dt == torch.float32 else 2e-3)
+    out2 = ops.gemm(dY, X, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=split, out=out.clone(), accumulate=True)
+    assert rel(out2, 2 * ref) < (1e-5 if dt == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_epilogues(ops, dt):
+    M, N, K = 300, 192, 96
+    A, W = rnd((M, K), dt, 5), rnd((N, K), dt, 6, 0.2)
+    bias = rnd((N,), torch.float32, 7)
+    res = rnd((M, N), dt, 8)
+    base = A.float() @ W.float().t() + bias
+    # bias + gelu + save_pre
+    pre = torch.empty((M, N), dtype=dt, device="cuda")
+    out = ops.gemm(A, W, bias=bias, gelu=True, save_pre=pre)
+    assert rel(pre, base) < tol(dt) and rel(out, F.gelu(base)) < tol(dt)
+    # bias + rowscale + residual with output row scatter (Swin proj)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(1)).int().cuda()
+    rs = torch.tensor([0.0, 1.25, 1.25], device="cuda")
+    out = ops.gemm(A, W, bias=bias, rowscale=(rs, 100), residual=res, rowmap=perm)
+    exp = res.float().clone()
+    sc = rs[(perm.long() // 100)]
+    exp[perm.long()] += base * sc[:, None]
+    assert rel(out, exp) < tol(dt)
+    # dropout + residual (BERT self-output): mask regenerated through mvlt_dropout_mask
+    out = ops.gemm(A, W, bias=bias, dropout=(0.1, 1234, 77), residual=res)
+    keep = ops.dropout_mask(M * N, 0.1, 1234, 77, A.device).view(M, N).float()
+    assert 0.85 < keep.mean().item() < 0.95
+    assert rel(out, res.float() + base * keep / 0.9) < tol(dt)
+    # dgrad with fused GELU'
+    h = rnd((M, N), dt, 9)
+    dY = rnd((M, K), dt, 10)
+    dA = rnd((M, K), dt, 11)
+    Wt = rnd((K, N), dt, 12, 0.2)      # [K_red, N] k-major B
+    out = ops.gemm(dA, Wt, b_kmajor=True, mul_gelu_grad=h)
+    hf = h.float().requires_grad_(True)
+    F.gelu(hf).backward(dA.float() @ Wt.float())
+    assert rel(out, hf.grad) < tol(dt)
+
+
+def test_gemm_bad_args(ops):
+    A = torch.zeros(4, 4, device="cuda")
+    with pytest.raises(AssertionError):
+        ops.gemm(A, torch.zeros(4, 5, device="cuda"))
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))      # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_colsum(ops, dt):
+    x = rnd((3000, 388), dt, 13)
+    assert rel(ops.colsum(x), x.float().sum(0)) < 1e-4
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("C", [32, 96, 192, 384, 768, 1536])
+def test_layernorm_fwd_bwd(ops, dt, C):
+    rows = 523
+    x = rnd((rows, C), dt, 20, 2.0)
+    g = (1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(21))).cuda()
+    b = (0.1 * torch.randn(C, generator=torch.Generator().manual_seed(22))).cuda()
+    y, mean, rstd, _ = ops.layernorm_fwd(x, g, b, 1e-5)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    assert rel(y, yr) < tol(dt)
+    dy = rnd((rows, C), dt, 23)
+    dres = rnd((rows, C), dt, 24)
+    yr.backward(dy.float())
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dgam, dbet, dres=dres)
+    assert rel(dx, xr.grad + dres.float()) < tol(dt)
+    assert rel(dgam, gr.grad) < 1e-4 and rel(dbet, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_layernorm_rowmap_gelu_merge(ops, dt):
+    B, H, W, Cq = 2, 8, 8, 32
+    C = 4 * Cq
+    x = rnd((B, H * W, Cq), dt, 30)
+    g = (1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(31))).cuda()
+    b = (0.1 * torch.randn(C, generator=torch.Generator().manual_seed(32))).cuda()
+    # patch-merging gather + LN
+    y, mean, rstd, _ = ops.layernorm_fwd(x, g, b, 1e-5, merge=(H, W))
+    x4 = x.float().view(B, H, W, Cq).requires_grad_(True)
+    cat = torch.cat([x4[:, 0::2, 0::2], x4[:, 1::2, 0::2], x4[:, 0::2, 1::2], x4[:, 1::2, 1::2]], -1).view(B, -1, C)
+    yr = F.layer_norm(cat, (C,), g, b, 1e-5)
+    assert y.shape == (B, 16, C) and rel(y, yr) < tol(dt)
+    dy = rnd((B, 16, C), dt, 33)
+    yr.backward(dy.float())
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dgam, dbet, merge=(H, W))
+    assert rel(dx, x4.grad.view(B, H * W, Cq)) < tol(dt)
+    # row scatter + fused GELU
+    rows = 200
+    x2 = rnd((rows, C), dt, 34)
+    perm = torch.randperm(rows, generator=torch.Generator().manual_seed(2)).int().cuda()
+    y2, mean2, rstd2, ypre = ops.layernorm_fwd(x2, g, b, 1e-5, out_rowmap=perm, gelu=True, save_pre=True)
+    x2r = x2.float().requires_grad_(True)
+    ln = F.layer_norm(x2r, (C,), g, b, 1e-5)
+    exp = torch.empty_like(ln)
+    exp[perm.long()] = F.gelu(ln)
+    assert rel(y2, exp) < tol(dt)
+    dy2 = rnd((rows, C), dt, 35)
+    exp.backward(dy2.float())
+    dx2 = ops.layernorm_bwd(dy2, x2, mean2, rstd2, g, dgam, dbet, dy_rowmap=perm, y_pre=ypre)
+    assert rel(dx2, x2r.grad) < tol(dt) * 2
+
+
+# ------------------------------------------------------------------ attention
+def swin_ref(qkv, table, nW, res, shift, nH, scale):
+    from oracle import mvlt_oracle as O
+    B_ = qkv.shape[0] // 49
+    hd = qkv.shape[1] // (3 * nH)
+    q, k, v = qkv.view(B_, 49, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    att = (q * scale) @ k.transpose(-1, -2)
+    idx = O.relative_position_index(7).to(qkv.device)
+    att = att + table[idx.view(-1)].view(49, 49, nH).permute(2, 0, 1)[None]
+    if shift:
+        m = O.shift_attn_mask(res, res, 7, shift).to(qkv.device)
+        att = (att.view(B_ // nW, nW, nH, 49, 49) + m[None, :, None]).view(B_, nH, 49, 49)
+    return (att.softmax(-1) @ v).transpose(1, 2).reshape(B_ * 49, nH * hd)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("res,nH,shift", [(14, 12, 3), (14, 12, 0), (28, 6, 3), (56, 3, 3), (7, 24, 0)])
+def test_swin_attention(ops, dt, res, nH, shift):
+    from mvlt_amd._lib import ATTN_SWIN
+    nW = (res // 7) ** 2
+    B_ = 2 * nW
+    qkv = rnd((B_ * 49, 3 * nH * 32), dt, 40)
+    table = (0.5 * torch.randn(169, nH, generator=torch.Generator().manual_seed(41))).cuda()
+    scale = 32 ** -0.5
+    out, lse = ops.attn_fwd(qkv, ATTN_SWIN, B_, 49, nH, 32, scale, bias_table=table, nW=nW, win_res=res, shift=shift)
+    qr = qkv.float().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    ref = swin_ref(qr, tr, nW, res, shift, nH, scale)
+    assert rel(out, ref) < tol(dt)
+    dout = rnd(out.shape, dt, 42)
+    ref.backward(dout.float())
+    dtab = torch.zeros_like(table)
+    dqkv = ops.attn_bwd(dout, qkv, out, lse, ATTN_SWIN, B_, 49, nH, 32, scale, dbias_table=dtab, bias_table=table,
+                        nW=nW, win_res=res, shift=shift)
+    assert rel(dqkv, qr.grad) < tol(dt) * 3
+    assert rel(dtab, tr.grad) < (1e-4 if dt == torch.float32 else 2e-2)
+
+
+def bert_ref(qkv, B, Lq, nH, mask_add, scale, keep=None, p=0.0):
+    hd = qkv.shape[1] // (3 * nH)
+    q, k, v = qkv.view(B, Lq, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-1, -2)) * scale + mask_add
+    pr = att.softmax(-1)
+    if keep is not None:
+        pr = pr * keep / (1 - p)
+    return (pr @ v).transpose(1, 2).reshape(B * Lq, nH * hd)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("T,seq2seq,p", [(80, False, 0.0), (80, True, 0.0), (23, False, 0.0), (24, True, 0.1),
+                                         (80, False, 0.1)])
+def test_bert_attention(ops, dt, T, seq2seq, p):
+    from mvlt_amd._lib import ATTN_BIDIR, ATTN_SEQ2SEQ
+    from oracle import mvlt_oracle as O
+    B, nH, n_img = 3, 4, 49
+    Lq = n_img + 2 + T
+    qkv = rnd((B * Lq, 3 * nH * 64), dt, 50)
+    ids = torch.zeros(B, T, dtype=torch.long)
+    for b, ln in enumerate((T, max(1, T // 3), 1)):
+        ids[b, :ln] = 5 + torch.arange(ln)
+    if seq2seq:
+        mask = O.additive_mask(O.seq2seq_bool_mask(Lq, n_img + 1)[None].expand(B, Lq, Lq)).cuda()
+        mode = ATTN_SEQ2SEQ
+    else:
+        mask = O.additive_mask(O.bidir_bool_mask(ids, B, n_img)).cuda()
+        mode = ATTN_BIDIR
+    kw = dict(text_ids=ids.cuda(), obj_end=n_img + 1, dropout=(p, 99, 5))
+    out, lse = ops.attn_fwd(qkv, mode, B, Lq, nH, 64, 0.125, **kw)
+    keep = None
+    if p > 0:
+        keep = ops.dropout_mask(B * nH * Lq * Lq, p, 99, 5, qkv.device).view(B, nH, Lq, Lq).float()
+    qr = qkv.float().requires_grad_(True)
+    ref = bert_ref(qr, B, Lq, nH, mask, 0.125, keep, p)
+    assert rel(out, ref) < tol(dt)
+    dout = rnd(out.shape, dt, 51)
+    ref.backward(dout.float())
+    dqkv = ops.attn_bwd(dout, qkv, out, lse, mode, B, Lq, nH, 64, 0.125, **kw)
+    assert rel(dqkv, qr.grad) < tol(dt) * 3
+
+
+# ------------------------------------------------------------------ data movement, loss, optimizer
+@pytest.mark.parametrize("dt", DT)
+def test_im2col_and_embed(ops, dt):
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(60)).cuda()
+    cols = ops.im2col_patch(img, dt, 4)
+    w = torch.randn(96, 3, 4, 4, generator=torch.Generator().manual_seed(61)).cuda()
+    ref = F.conv2d(img, w, stride=4).flatten(2).transpose(1, 2).reshape(-1, 96)
+    assert rel(cols.float() @ w.view(96, -1).t(), ref) < tol(dt)
+    # embeddings
+    B, n_img, T, H = 3, 49, 24, 256
+    word = torch.randn(3001, H, generator=torch.Generator().manual_seed(62)).cuda()
+    pos = torch.randn(512, H, generator=torch.Generator().manual_seed(63)).cuda()
+    typ = torch.randn(3, H, generator=torch.Generator().manual_seed(64)).cuda()
+    ids = torch.randint(0, 3000, (B, T), generator=torch.Generator().manual_seed(65)).cuda()
+    ids[0, 5:] = 0
+    feat = rnd((B, n_img, H), dt, 66)
+    out = ops.embed_fwd(ids, feat, word, pos, typ, 101, 102)
+    wr, pr, tr = word.clone().requires_grad_(True), pos.clone().requires_grad_(True), typ.clone().requires_grad_(True)
+    fr = feat.float().requires_grad_(True)
+    Lq = n_img + 2 + T
+    src = torch.cat([wr[101].expand(B, 1, H), fr, wr[102].expand(B, 1, H), wr[ids]], 1)
+    tt = (torch.arange(Lq, device="cuda") <= n_img + 1).long()
+    ref = src + tr[tt][None] + pr[:Lq][None]
+    assert rel(out, ref) < tol(dt)
+    dout = rnd((B, Lq, H), dt, 67)
+    ref.backward(dout.float())
+    dw, dp_, dt_ = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
+    dimg = ops.embed_bwd(dout, ids, n_img, word, pos, typ, 101, 102, dw, dp_, dt_)
+    assert rel(dimg, fr.grad) < tol(dt)
+    assert rel(dw, wr.grad) < 1e-4 and rel(dp_, pr.grad) < 1e-4 and rel(dt_, tr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_rows_transform_cast_unary(ops, dt):
+    x = rnd((120, 64), dt, 70)
+    perm = torch.randperm(120, generator=torch.Generator().manual_seed(3)).int().cuda()
+    rs = torch.tensor([0.0, 2.0, 1.5], device="cuda")
+    out = ops.rows_transform(x, rowmap=perm, rowscale=(rs, 40))
+    exp = x.float()[perm.long()] * rs[perm.long() // 40][:, None]
+    assert rel(out, exp) < tol(dt)
+    out = ops.rows_transform(x, dropout=(0.3, 5, 6))
+    keep = ops.dropout_mask(120 * 64, 0.3, 5, 6, x.device).view(120, 64).float()
+    assert rel(out, x.float() * keep / 0.7) < tol(dt)
+    assert rel(ops.gelu(x), F.gelu(x.float())) < tol(dt)
+    y = ops.tanh_fwd(x)
+    assert rel(y, torch.tanh(x.float())) < tol(dt)
+    assert rel(ops.tanh_bwd(y, x), x.float() * (1 - y.float() ** 2)) < tol(dt)
+    z = torch.randn(1003, generator=torch.Generator().manual_seed(71)).cuda()
+    zb = ops.cast(z, torch.bfloat16)
+    assert torch.equal(zb, z.to(torch.bfloat16))
+    assert torch.equal(ops.cast(zb, torch.float32), zb.float())
+    s = ops.droppath_scale(1000, 0.3, 11, 12, z.device)
+    assert all(v == 0.0 or abs(v - 1 / 0.7) < 1e-6 for v in s.unique().tolist())
+    assert 0.6 < (s > 0).float().mean().item() < 0.8
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("V,ld", [(3000, 3008), (30522, 30528), (2, 4)])
+def test_cross_entropy(ops, dt, V, ld):
+    rows = 37
+    logits = torch.zeros(rows, ld, dtype=dt, device="cuda")
+    logits[:, :V] = rnd((rows, V), dt, 80, 3.0)
+    labels = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(81))
+    labels[::3] = -100
+    labels = labels.cuda()
+    acc, lse = ops.ce_fwd(logits, V, labels)
+    lr = logits[:, :V].float().requires_grad_(True)
+    ref = F.cross_entropy(lr, labels, ignore_index=-100)
+    assert abs(acc[0].item() / acc[1].item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert acc[1].item() == (labels >= 0).sum().item()
+    ref.backward()
+    d = ops.ce_bwd(logits.clone(), V, labels, lse, acc)
+    assert rel(d[:, :V], lr.grad) < (1e-5 if dt == torch.float32 else 1e-2)
+    assert float(d[:, V:].float().abs().sum()) == 0.0
+
+
+def test_adamw_matches_torch(ops):
+    n = 10007
+    p0 = torch.randn(n, generator=torch.Generator().manual_seed(90))
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=4e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=1e-4)
+    p = torch.zeros(n + 1, device="cuda")[:n].copy_(p0)          # 16B-aligned base
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    sh = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    for step in range(1, 4):
+        g = torch.randn(n, generator=torch.Generator().manual_seed(90 + step))
+        pt.grad = g.clone()
+        opt.step()
+        ops.adamw(p, g.cuda(), m, v, sh, 4e-5, 0.9, 0.999, 1e-6, 1e-4, step)
+    assert rel(p, pt.detach()) < 1e-6
+    assert torch.equal(sh, p.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_cached_attention_and_argmax(ops, dt):
+    B, nH, hd, past, cap = 2, 4, 64, 51, 80
+    kc = torch.zeros(B, nH, cap, hd, dtype=dt, device="cuda")
+    vc = torch.zeros_like(kc)
+    kc[:, :, :past] = rnd((B, nH, past, hd), dt, 100)
+    vc[:, :, :past] = rnd((B, nH, past, hd), dt, 101)
+    qkv = rnd((B * 2, 3 * nH * hd), dt, 102)
+    kref, vref = kc.clone(), vc.clone()
+    out = ops.attn_cached(qkv, kc, vc, past, 0.125)
+    q, k, v = qkv.float().view(B, 2, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    K = torch.cat([kref[:, :, :past].float(), k], 2)
+    V_ = torch.cat([vref[:, :, :past].float(), v], 2)
+    att = (q @ K.transpose(-1, -2)) * 0.125
+    causal = torch.ones(2, past + 2, dtype=torch.bool, device="cuda")
+    causal[0, -1] = False
+    att = att.masked_fill(~causal[None, None], float("-inf")).softmax(-1)
+    ref = (att @ V_).transpose(1, 2).reshape(B * 2, nH * hd)
+    assert rel(out, ref) < tol(dt)
+    assert rel(kc[:, :, past:past + 2], k) < 1e-6 and rel(vc[:, :, past:past + 2], v) < 1e-6
+    logits = rnd((5, 3008), dt, 103)
+    assert torch.equal(ops.argmax(logits, 3000), logits[:, :3000].float().argmax(-1))
