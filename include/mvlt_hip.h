@@ -185,6 +185,8 @@ int mvlt_rows_transform(int dtype, const void* in, void* out, int rows, int C, c
 /* elementwise helpers */
 int mvlt_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
 int mvlt_gelu_fwd(int dtype, const void* x, void* y, int64_t n, void* stream);
+int mvlt_gelu_bwd(int dtype, const void* x, const void* dy, void* dx, int64_t n, void* stream); /* dx = dy*gelu'(x) */
+int mvlt_softmax_rows(int dtype, const void* x, int64_t ld, int rows, int V, float* out, void* stream); /* f32 [rows,V] */
 int mvlt_tanh_fwd(int dtype, const void* x, void* y, int64_t n, void* stream);
 int mvlt_tanh_bwd(int dtype, const void* y, const void* dy, void* dx, int64_t n, void* stream);
 int mvlt_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint32_t tag, void* stream);
@@ -199,7 +201,8 @@ int mvlt_droppath_scale(float* scale, int B, float p, uint64_t seed, uint32_t ta
 int mvlt_ce_fwd(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
                 float* lse, float* loss_sum, float* count, void* stream);
 int mvlt_ce_bwd(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
-                const float* lse, const float* count, float grad_scale, void* dlogits, void* stream);
+                const float* lse, const float* count, float grad_scale, const float* grad_scale_dev,
+                void* dlogits, void* stream);   /* grad_scale_dev (optional): upstream dL/dloss on the device */
 
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.AdamW step (run_pretrain.py:165-166: lr 4e-5, betas (0.9,0.999),

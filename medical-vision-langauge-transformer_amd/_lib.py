@@ -99,7 +99,9 @@ SYMBOLS = {
     "mvlt_dropout_mask": (i32, [vp, i64, f32, u64, u32, vp]),
     "mvlt_droppath_scale": (i32, [vp, i32, f32, u64, u32, vp]),
     "mvlt_ce_fwd": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
-    "mvlt_ce_bwd": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, f32, vp, vp]),
+    "mvlt_ce_bwd": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, f32, vp, vp, vp]),
+    "mvlt_gelu_bwd": (i32, [i32, vp, vp, vp, i64, vp]),
+    "mvlt_softmax_rows": (i32, [i32, vp, i64, i32, i32, vp, vp]),
     "mvlt_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "mvlt_attn_cached": (i32, [C.POINTER(MvltAttnCached), vp]),
     "mvlt_argmax": (i32, [i32, vp, i64, i32, i32, vp, vp]),

@@ -1,0 +1,172 @@
+"""Flat parameter arena: memory laid out for one MI355X (288 GB HBM3E).
+
+All parameters of a model live in ONE contiguous f32 buffer (``flat``); the
+``nn.Parameter`` objects (reference state-dict names and shapes) are views
+into it, so ``state_dict()`` / ``load_state_dict()`` / ``torch.save`` keep
+working.  Alongside: one flat f32 gradient buffer (``grad``; ``p.grad`` are
+views) and, in bf16 mode, one flat bf16 *compute copy* (``shadow``) that the
+MFMA kernels read.  Consequences:
+
+* query/key/value weights of a BERT layer are adjacent -> the fused QKV GEMM
+  reads them as one [3H, H] matrix without a concat;
+* AdamW is a handful of launches over contiguous ranges (one per run of
+  parameters that received a gradient this step) and refreshes the bf16 copy
+  in the same pass;
+* gradient all-reduce buckets are plain slices of ``grad``.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+ALIGN = 64  # elements (256 B for f32, 128 B for the bf16 copy)
+
+
+class Arena:
+    def __init__(self, root: nn.Module, compute_dtype: torch.dtype):
+        params: List[Tuple[str, nn.Parameter]] = []
+        seen = set()
+        for name, p in root.named_parameters():
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            params.append((name, p))
+        if not params:
+            raise RuntimeError("module has no parameters")
+        dev = params[0][1].device
+        if dev.type != "cuda":
+            raise RuntimeError("mvlt_amd modules run on the GPU only: call .cuda() first (no CPU fallback)")
+        # fused groups (must be adjacent): declared by modules through _arena_groups()
+        order: List[Tuple[str, nn.Parameter]] = []
+        placed = set()
+        group_of: Dict[int, List[nn.Parameter]] = {}
+        for m in root.modules():
+            for grp in getattr(m, "_arena_groups", lambda: [])():
+                for p in grp:
+                    group_of[id(p)] = grp
+        names = {id(p): n for n, p in params}
+        for name, p in params:
+            if id(p) in placed:
+                continue
+            for q in group_of.get(id(p), [p]):
+                if id(q) not in placed:
+                    placed.add(id(q))
+                    order.append((names[id(q)], q))
+        self.names: List[str] = []
+        self.offset: Dict[int, int] = {}
+        self.numel: Dict[int, int] = {}
+        self.params: List[nn.Parameter] = []
+        off = 0
+        for name, p in order:
+            self.names.append(name)
+            self.params.append(p)
+            self.offset[id(p)] = off
+            self.numel[id(p)] = p.numel()
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.device = dev
+        self.compute_dtype = compute_dtype
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
+        with torch.no_grad():
+            for p in self.params:
+                o, n = self.offset[id(p)], p.numel()
+                view = self.flat[o:o + n].view(p.shape)
+                view.copy_(p.data.to(torch.float32))
+                p.data = view
+        self._ptr0 = self.params[0].data_ptr()
+        self.shadow_fresh = False
+        self.has_grad: Dict[int, bool] = {id(p): False for p in self.params}
+        self.steps: Dict[int, int] = {id(p): 0 for p in self.params}
+        self.exp_avg: Optional[torch.Tensor] = None
+        self.exp_avg_sq: Optional[torch.Tensor] = None
+        for m in root.modules():
+            m.__dict__["_mvlt_arena"] = self
+
+    # ------------------------------------------------------------------ lookup
+    @staticmethod
+    def of(module: nn.Module, compute_dtype: torch.dtype) -> "Arena":
+        a = module.__dict__.get("_mvlt_arena")
+        first = next(module.parameters())
+        if (a is None or id(first) not in a.offset or a.compute_dtype != compute_dtype
+                or first.data_ptr() != a.flat.data_ptr() + 4 * a.offset[id(first)]):
+            a = Arena(module, compute_dtype)
+        return a
+
+    def master(self, p: nn.Parameter) -> torch.Tensor:
+        return p.data
+
+    def compute(self, p: nn.Parameter, rows: Optional[int] = None) -> torch.Tensor:
+        """2-D compute-dtype view of a weight ([out, in]); ``rows`` > p.shape[0]
+        spans the adjacent parameters of a fused group (QKV)."""
+        o = self.offset[id(p)]
+        cols = p.numel() // p.shape[0]
+        r = p.shape[0] if rows is None else rows
+        src = self.flat if self.shadow is None else self.shadow
+        return src[o:o + r * cols].view(r, cols)
+
+    def master_span(self, p: nn.Parameter, n: int) -> torch.Tensor:
+        o = self.offset[id(p)]
+        return self.flat[o:o + n]
+
+    def grad_view(self, p: nn.Parameter, rows: Optional[int] = None) -> torch.Tensor:
+        o = self.offset[id(p)]
+        if p.dim() == 1:
+            n = p.numel() if rows is None else rows
+            return self.grad[o:o + n]
+        cols = p.numel() // p.shape[0]
+        r = p.shape[0] if rows is None else rows
+        return self.grad[o:o + r * cols].view(r, cols)
+
+    def mark(self, *ps: nn.Parameter) -> None:
+        for p in ps:
+            self.has_grad[id(p)] = True
+
+    # ------------------------------------------------------------------ per-step state
+    def begin_backward(self) -> None:
+        for k in self.has_grad:
+            self.has_grad[k] = False
+
+    def publish_grads(self) -> None:
+        """Expose gradients the torch way: p.grad is a view for parameters that
+        received a gradient this step and None for the others (so a stock
+        torch optimizer skips them exactly as it does for the reference)."""
+        for p in self.params:
+            if self.has_grad[id(p)]:
+                if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offset[id(p)]:
+                    o, n = self.offset[id(p)], p.numel()
+                    p.grad = self.grad[o:o + n].view(p.shape)
+            elif p.grad is not None:
+                p.grad = None
+
+    def refresh_shadow(self) -> None:
+        """bf16 compute copy <- f32 master (one pass, 6 B/param)."""
+        if self.shadow is not None and not self.shadow_fresh:
+            from . import ops
+            ops.cast(self.flat, torch.bfloat16, out=self.shadow)
+            self.shadow_fresh = True
+
+    def invalidate_shadow(self) -> None:
+        self.shadow_fresh = False
+
+    def active_ranges(self) -> List[Tuple[int, int, int]]:
+        """Maximal contiguous [start, end) element ranges of parameters that
+        have a gradient and share the same optimizer step count."""
+        out: List[Tuple[int, int, int]] = []
+        cur = None
+        for p in self.params:
+            if not self.has_grad[id(p)]:
+                cur = None
+                continue
+            o = self.offset[id(p)]
+            e = o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            st = self.steps[id(p)]
+            if cur is not None and cur[1] == o and cur[2] == st:
+                cur[1] = e
+            else:
+                cur = [o, e, st]
+                out.append(cur)
+        return [(a, b, c) for a, b, c in out]

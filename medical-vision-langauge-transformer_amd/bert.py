@@ -1,0 +1,278 @@
+"""MVLBert single-stream encoder, drop-in for reference ``modules/model.py:16-183``
+plus the HF ``BertEncoder`` / ``BertPooler`` blocks it imports (model.py:5;
+arithmetic per transformers modeling_bert.py:111-136,164-203,282-293,325-351,451-463).
+
+The nn.Module tree holds parameters under the reference/HF state-dict names;
+the arithmetic is a kernel sequence, 7 launches per layer forward:
+
+    QKV GEMM (one [3H,H] GEMM: query/key/value weights are adjacent in the arena)
+    fused attention (bidirectional key mask from text ids / seq2seq mask from
+        (row, col, obj_end), -10000 additive, probability dropout in-kernel)
+    out-proj GEMM (+bias, hidden dropout, residual) | LayerNorm(1e-12)
+    FFN-in GEMM (+bias, GELU, pre-activation saved)
+    FFN-out GEMM (+bias, hidden dropout, residual) | LayerNorm(1e-12)
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .arena import Arena
+from .runtime import backward_begin, compute_dtype_of, next_seed
+
+
+# ----------------------------------------------------------------------------- parameter holders (HF names)
+class BertSelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        H = config.hidden_size
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = H // config.num_attention_heads
+        self.query, self.key, self.value = nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, H)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+
+    def _arena_groups(self):
+        return [[self.query.weight, self.key.weight, self.value.weight],
+                [self.query.bias, self.key.bias, self.value.bias]]
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.attention = BertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(config) for _ in range(config.num_hidden_layers)])
+
+
+class BertPooler(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.activation = nn.Tanh()
+
+
+class EncoderOutput(tuple):
+    """Stand-in for HF BaseModelOutputWithPastAndCrossAttentions: supports
+    ``out[0]``, ``.last_hidden_state`` and ``.past_key_values`` (model.py:62,:694,:759)."""
+
+    def __new__(cls, last_hidden_state, past_key_values=None):
+        o = super().__new__(cls, (last_hidden_state, past_key_values))
+        o.last_hidden_state = last_hidden_state
+        o.past_key_values = past_key_values
+        return o
+
+
+class _EncFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, token, image_feature, mod, text_idx, mask_ids, image_mask, seq2seq, save):
+        hidden, pooled, saved = mod._forward(image_feature, text_idx, mask_ids, image_mask, seq2seq, save)
+        ctx.mod, ctx.saved = mod, saved
+        ctx.set_materialize_grads(False)     # unused pooled output -> None, so the pooler gets no gradient
+        if pooled is None:
+            pooled = hidden.new_zeros(1)
+            ctx.mark_non_differentiable(pooled)
+        return hidden, pooled
+
+    @staticmethod
+    def backward(ctx, dhidden, dpooled):
+        dimg = ctx.mod._backward(ctx.saved, dhidden, dpooled)
+        ctx.saved = None
+        return None, dimg, None, None, None, None, None, None
+
+
+class MVLBert(nn.Module):
+    """Signature of reference ``MVLBert`` (model.py:16-72)."""
+
+    def __init__(self, config, add_pooling_layer=False):
+        super().__init__()
+        self.config = config
+        self.word_embeddings = nn.Embedding(config.vocab_size + 1, config.hidden_size)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.embedding_LayerNorm = nn.LayerNorm(config.hidden_size, eps=1e-12)   # constructed, never applied (model.py:25,:158)
+        self.embedding_dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.encoder = BertEncoder(config)
+        self.is_decoder = getattr(config, "is_decoder", False)
+        self.pooler = BertPooler(config) if add_pooling_layer else None
+        self.register_buffer("position_ids", torch.arange(512).expand((1, -1)))
+        if config.hidden_size // config.num_attention_heads != 64:
+            raise NotImplementedError("attention kernel is built for head_dim 64 (bert-base)")
+        self.last_seed = None
+
+    # ------------------------------------------------------------------ public forward (model.py:35-72)
+    def forward(self, text_idx, text_mask, image_feature, image_mask, past_key_values=None, use_cache=False,
+                seq2seq_mask=False, output_text_image_seperate=False):
+        if not image_feature.is_cuda:
+            raise RuntimeError("mvlt_amd runs on the GPU only (no CPU fallback)")
+        if past_key_values is not None or use_cache:
+            from .decode import cached_forward
+            return cached_forward(self, text_idx, image_feature, past_key_values, seq2seq_mask)
+        cd = compute_dtype_of(self)
+        B, n_img, _ = image_feature.shape
+        T = 0 if text_idx is None else text_idx.shape[1]
+        obj_end = n_img + 1
+        text_end = obj_end + T + 1
+        tok = self.__dict__.get("_mvlt_token")
+        if tok is None or tok.device != image_feature.device:
+            tok = torch.zeros(1, device=image_feature.device, requires_grad=True)
+            self.__dict__["_mvlt_token"] = tok
+        mask_ids = None
+        if text_idx is not None:
+            text_idx = text_idx.contiguous()
+            # the bidirectional key mask is "text_mask"; callers pass (text_idx > 0) (model.py:337,:384)
+            mask_ids = text_idx if text_mask is None else text_mask.to(torch.int64).contiguous()
+        im = None
+        if image_mask is not None and image_mask.dtype != torch.bool:
+            im = (image_mask != 0)
+        elif image_mask is not None:
+            im = image_mask
+        im_u8 = im.to(torch.uint8).contiguous() if im is not None else None
+        feat = image_feature if image_feature.dtype == cd else image_feature.to(cd)
+        hidden, pooled = _EncFn.apply(tok, feat.contiguous(), self, text_idx, mask_ids, im_u8, bool(seq2seq_mask),
+                                      torch.is_grad_enabled())
+        pooler_output = pooled if self.pooler is not None else None
+        if output_text_image_seperate:
+            return (hidden[:, obj_end + 1:text_end], hidden[:, 1:obj_end], pooler_output, hidden[:, obj_end])
+        return EncoderOutput(hidden), pooler_output
+
+    # ------------------------------------------------------------------ engine
+    def _forward(self, feat, text_idx, mask_ids, image_mask, seq2seq, save):
+        cfg = self.config
+        cd = feat.dtype
+        ar = Arena.of(self, cd)
+        ar.refresh_shadow()
+        B, n_img, H = feat.shape
+        T = 0 if text_idx is None else text_idx.shape[1]
+        Lq = n_img + 2 + T
+        nH = cfg.num_attention_heads
+        train = self.training
+        p_h = cfg.hidden_dropout_prob if train else 0.0
+        p_a = cfg.attention_probs_dropout_prob if train else 0.0
+        seed = next_seed() if (p_h > 0 or p_a > 0) else 0
+        self.last_seed = seed
+        x = ops.embed_fwd(text_idx, feat, self.word_embeddings.weight.data, self.position_embeddings.weight.data,
+                          self.token_type_embeddings.weight.data, cfg.cls_token_id, cfg.sep_token_id).view(B * Lq, H)
+        mode = L.ATTN_SEQ2SEQ if seq2seq else L.ATTN_BIDIR
+        akw = dict(text_ids=mask_ids, image_mask=image_mask, obj_end=n_img + 1)
+        layers = []
+        for i, layer in enumerate(self.encoder.layer):
+            sa, so = layer.attention.self, layer.attention.output
+            qkv = ops.gemm(x, ar.compute(sa.query.weight, 3 * H), bias=ar.master_span(sa.query.bias, 3 * H))
+            ctx, lse = ops.attn_fwd(qkv, mode, B, Lq, nH, H // nH, (H // nH) ** -0.5,
+                                    dropout=(p_a, seed, 8 * i + 0), **akw)
+            y1 = ops.gemm(ctx, ar.compute(so.dense.weight), bias=so.dense.bias.data, dropout=(p_h, seed, 8 * i + 1),
+                          residual=x)
+            x1, m1, r1, _ = ops.layernorm_fwd(y1, so.LayerNorm.weight.data, so.LayerNorm.bias.data, so.LayerNorm.eps,
+                                              save_stats=save)
+            h = torch.empty((B * Lq, cfg.intermediate_size), dtype=cd, device=x.device)
+            a = ops.gemm(x1, ar.compute(layer.intermediate.dense.weight), bias=layer.intermediate.dense.bias.data,
+                         gelu=True, save_pre=h)
+            y2 = ops.gemm(a, ar.compute(layer.output.dense.weight), bias=layer.output.dense.bias.data,
+                          dropout=(p_h, seed, 8 * i + 2), residual=x1)
+            x2, m2, r2, _ = ops.layernorm_fwd(y2, layer.output.LayerNorm.weight.data, layer.output.LayerNorm.bias.data,
+                                              layer.output.LayerNorm.eps, save_stats=save)
+            if save:
+                layers.append((x, qkv, ctx, lse, y1, m1, r1, x1, h, a, y2, m2, r2))
+            x = x2
+        hidden = x.view(B, Lq, H)
+        pooled = None
+        if self.pooler is not None:          # tanh(Linear(h[:,0]))  (modeling_bert.py:451-463)
+            pooled = ops.tanh_fwd(ops.gemm(hidden[:, 0], ar.compute(self.pooler.dense.weight),
+                                           bias=self.pooler.dense.bias.data))
+        saved = None
+        if save:
+            saved = dict(ar=ar, layers=layers, B=B, Lq=Lq, n_img=n_img, text_idx=text_idx, akw=akw, mode=mode,
+                         seed=seed, p_h=p_h, p_a=p_a, hidden=hidden, pooled=pooled)
+        return hidden, pooled, saved
+
+    def _backward(self, sv, dhidden, dpooled):
+        ar: Arena = sv["ar"]
+        backward_begin(ar)
+        g = ar.grad_view
+        cfg = self.config
+        B, Lq, H = sv["B"], sv["Lq"], cfg.hidden_size
+        nH = cfg.num_attention_heads
+        seed, p_h, p_a = sv["seed"], sv["p_h"], sv["p_a"]
+        dx = dhidden.contiguous().view(B * Lq, H)
+        if dx.data_ptr() == dhidden.data_ptr() and self.pooler is not None and sv["pooled"] is not None:
+            dx = dx.clone()                      # we accumulate the pooler gradient into it
+        if self.pooler is not None and sv["pooled"] is not None and dpooled is not None:
+            pd = self.pooler.dense
+            dpre = ops.tanh_bwd(sv["pooled"], dpooled.contiguous())
+            cls = sv["hidden"][:, 0]
+            ops.gemm(dpre, cls, a_kmajor=True, b_kmajor=True, out=g(pd.weight), out_f32=True)
+            ops.colsum(dpre, out=g(pd.bias))
+            ops.gemm(dpre, ar.compute(pd.weight), b_kmajor=True, out=dx.view(B, Lq, H)[:, 0], accumulate=True)
+            ar.mark(pd.weight, pd.bias)
+        for i in range(len(self.encoder.layer) - 1, -1, -1):
+            layer = self.encoder.layer[i]
+            sa, so = layer.attention.self, layer.attention.output
+            (x, qkv, ctx, lse, y1, m1, r1, x1, h, a, y2, m2, r2) = sv["layers"][i]
+            lo, li = layer.output, layer.intermediate
+            dy2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight), g(lo.LayerNorm.bias))
+            dz2 = ops.rows_transform(dy2, dropout=(p_h, seed, 8 * i + 2)) if p_h > 0 else dy2
+            dh = ops.gemm(dz2, ar.compute(lo.dense.weight), b_kmajor=True, mul_gelu_grad=h)
+            ops.gemm(dz2, a, a_kmajor=True, b_kmajor=True, out=g(lo.dense.weight), out_f32=True)
+            ops.colsum(dz2, out=g(lo.dense.bias))
+            dx1 = ops.gemm(dh, ar.compute(li.dense.weight), b_kmajor=True, residual=dy2)
+            ops.gemm(dh, x1, a_kmajor=True, b_kmajor=True, out=g(li.dense.weight), out_f32=True)
+            ops.colsum(dh, out=g(li.dense.bias))
+            dy1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight), g(so.LayerNorm.bias))
+            dz1 = ops.rows_transform(dy1, dropout=(p_h, seed, 8 * i + 1)) if p_h > 0 else dy1
+            dctx = ops.gemm(dz1, ar.compute(so.dense.weight), b_kmajor=True)
+            ops.gemm(dz1, ctx, a_kmajor=True, b_kmajor=True, out=g(so.dense.weight), out_f32=True)
+            ops.colsum(dz1, out=g(so.dense.bias))
+            dqkv = ops.attn_bwd(dctx, qkv, ctx, lse, sv["mode"], B, Lq, nH, H // nH, (H // nH) ** -0.5,
+                                dropout=(p_a, seed, 8 * i + 0), **sv["akw"])
+            dx = ops.gemm(dqkv, ar.compute(sa.query.weight, 3 * H), b_kmajor=True, residual=dy1)
+            ops.gemm(dqkv, x, a_kmajor=True, b_kmajor=True, out=g(sa.query.weight, 3 * H), out_f32=True)
+            ops.colsum(dqkv, out=g(sa.query.bias, 3 * H))
+            ar.mark(lo.LayerNorm.weight, lo.LayerNorm.bias, lo.dense.weight, lo.dense.bias, li.dense.weight,
+                    li.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, so.dense.weight, so.dense.bias,
+                    sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias)
+        # ---- embeddings: dense f32 table gradients, like nn.Embedding in the reference
+        we, pe, te = self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight
+        g(we).zero_(); g(pe).zero_(); g(te).zero_()
+        dimg = ops.embed_bwd(dx.view(B, Lq, H), sv["text_idx"], sv["n_img"], we.data, pe.data, te.data,
+                             cfg.cls_token_id, cfg.sep_token_id, g(we), g(pe), g(te))
+        ar.mark(we, pe, te)
+        return dimg

@@ -138,14 +138,15 @@ __global__ __launch_bounds__(256) void cast_kernel(const S* src, D* dst, long n)
         store4f(dst + 4 * i, load4f(src + 4 * i));
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[nv * 4 + threadIdx.x] = from_f<D>(to_f(src[nv * 4 + threadIdx.x]));
 }
-template <typename T, int OP>   // 0 gelu, 1 tanh, 2 tanh-bwd (y, dy -> dx)
+template <typename T, int OP>   // 0 gelu, 1 tanh, 2 tanh-bwd (y, dy -> dx), 3 gelu-bwd (x, dy -> dx)
 __global__ __launch_bounds__(256) void unary_kernel(const T* a, const T* b, T* o, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float x = to_f(a[i]);
         float r;
         if (OP == 0) r = gelu_f(x);
         else if (OP == 1) r = tanhf(x);
-        else r = to_f(b[i]) * (1.0f - x * x);
+        else if (OP == 2) r = to_f(b[i]) * (1.0f - x * x);
+        else r = to_f(b[i]) * gelu_grad_f(x);
         o[i] = from_f<T>(r);
     }
 }
@@ -227,8 +228,10 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* logits, long ld, i
 }
 template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, long ld, int rows, int V, const int64_t* labels,
-                                                    const float* lse, const float* count, float gscale, T* dl) {
+                                                    const float* lse, const float* count, float gscale,
+                                                    const float* gscale_dev, T* dl) {
     const int r = blockIdx.x;
+    if (gscale_dev) gscale *= gscale_dev[0];
     const long lab = labels[r];
     const T* x = logits + (long)r * ld;
     T* d = dl + (long)r * ld;
@@ -330,6 +333,18 @@ __global__ __launch_bounds__(256) void argmax_kernel(const T* logits, long ld, i
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(64) void softmax_rows_kernel(const T* x, long ld, int V, float* out) {
+    const T* r = x + (long)blockIdx.x * ld;
+    float mx = -3.0e38f;
+    for (int c = threadIdx.x; c < V; c += 64) mx = fmaxf(mx, to_f(r[c]));
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < V; c += 64) s += __expf(to_f(r[c]) - mx);
+    s = wave_sum(s);
+    for (int c = threadIdx.x; c < V; c += 64) out[(long)blockIdx.x * V + c] = __expf(to_f(r[c]) - mx) / s;
+}
+
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -425,6 +440,10 @@ static int unary(int dtype, const void* a, const void* b, void* o, int64_t n, vo
 }
 extern "C" int mvlt_gelu_fwd(int dtype, const void* x, void* y, int64_t n, void* stream) { return unary<0>(dtype, x, nullptr, y, n, stream); }
 extern "C" int mvlt_tanh_fwd(int dtype, const void* x, void* y, int64_t n, void* stream) { return unary<1>(dtype, x, nullptr, y, n, stream); }
+extern "C" int mvlt_gelu_bwd(int dtype, const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+    MVLT_CHECK(dy, MVLT_ERR_ARG);
+    return unary<3>(dtype, x, dy, dx, n, stream);
+}
 extern "C" int mvlt_tanh_bwd(int dtype, const void* y, const void* dy, void* dx, int64_t n, void* stream) {
     MVLT_CHECK(dy, MVLT_ERR_ARG);
     return unary<2>(dtype, y, dy, dx, n, stream);
@@ -469,11 +488,20 @@ extern "C" int mvlt_ce_fwd(int dtype, const void* logits, int64_t ld, int rows, 
     return MVLT_OK;
 }
 extern "C" int mvlt_ce_bwd(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
-                           const float* lse, const float* count, float grad_scale, void* dlogits, void* stream) {
+                           const float* lse, const float* count, float grad_scale, const float* grad_scale_dev,
+                           void* dlogits, void* stream) {
     MVLT_CHECK(logits && labels && lse && count && dlogits && rows > 0 && V > 0 && ld >= V, MVLT_ERR_ARG);
     BY_DTYPE(dtype,
-             hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), (const float*)logits, (long)ld, rows, V, labels, lse, count, grad_scale, (float*)dlogits),
-             hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, (long)ld, rows, V, labels, lse, count, grad_scale, (bf16_t*)dlogits));
+             hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), (const float*)logits, (long)ld, rows, V, labels, lse, count, grad_scale, grad_scale_dev, (float*)dlogits),
+             hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, (long)ld, rows, V, labels, lse, count, grad_scale, grad_scale_dev, (bf16_t*)dlogits));
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_softmax_rows(int dtype, const void* x, int64_t ld, int rows, int V, float* out, void* stream) {
+    MVLT_CHECK(x && out && rows > 0 && V > 0 && ld >= V, MVLT_ERR_ARG);
+    BY_DTYPE(dtype, hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(rows), dim3(64), 0, STREAM(stream), (const float*)x, (long)ld, V, out),
+             hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3(rows), dim3(64), 0, STREAM(stream), (const bf16_t*)x, (long)ld, V, out));
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }

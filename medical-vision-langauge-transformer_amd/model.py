@@ -1,0 +1,457 @@
+"""Task heads and wrappers, drop-in for reference ``modules/model.py:186-546`` and
+``modules/config.py`` (same class names, constructor / forward signatures,
+state-dict keys): Conv_layer, MVLBertForPretraining, MVLBertForVQA,
+MVLBertForRetrieval, MVLBertForImageCaption, and the MVLBertConfig family.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .arena import Arena
+from .bert import MVLBert
+from .runtime import backward_begin, compute_dtype_of, next_seed
+from .swin import SwinTransformer
+
+
+# ----------------------------------------------------------------------------- configs (modules/config.py:4-72)
+class MVLBertConfig:
+    """Plain restatement of ``MVLBertConfig(BertConfig)``: bert-base-uncased
+    defaults plus the reference's extra fields (modules/config.py:4-27)."""
+
+    def __init__(self, **kwargs):
+        self.vocab_size = 30522
+        self.hidden_size = 768
+        self.num_hidden_layers = 12
+        self.num_attention_heads = 12
+        self.intermediate_size = 3072
+        self.hidden_act = "gelu"
+        self.max_position_embeddings = 512
+        self.layer_norm_eps = 1e-12
+        self.initializer_range = 0.02
+        self.is_decoder = False
+        self.pad_token_id = 0
+        self.type_vocab_size = 3
+        self.MLM_task = True
+        self.ITM_task = True
+        self.conv = 'swintransformer'
+        self.result_num = 224
+        self.lr = 4e-5
+        self.max_length = 40
+        self.eos_token_id, self.cls_token_id, self.sep_token_id, self.mask_token_id = 104, 101, 102, 103
+        self.attention_probs_dropout_prob = 0.0
+        self.hidden_dropout_prob = 0.0
+        # Swin-S (modules/swin_small_patch4_window7_224.yaml:1-8 + swin_transformer_config.py:58-76)
+        self.swin = dict(img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96,
+                         depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4.,
+                         qkv_bias=True, qk_scale=None, drop_rate=0.0, drop_path_rate=0.3, ape=False,
+                         patch_norm=True, use_checkpoint=False)
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def update_special_tokens(self, tokenizer):
+        self.eos_token_id, self.cls_token_id, self.sep_token_id, self.mask_token_id = \
+            tokenizer.convert_tokens_to_ids(['[END]', '[CLS]', '[SEP]', '[MASK]'])
+        self.vocab_size = len(tokenizer)
+
+    def to_dict(self):
+        return {k: v for k, v in self.__dict__.items() if isinstance(v, (int, float, str, bool, list, dict, type(None)))}
+
+    @classmethod
+    def from_pretrained(cls, path, **kwargs):
+        cfg = cls(**kwargs)
+        f = os.path.join(path, "config.json")
+        if os.path.isdir(path) and os.path.exists(f):
+            with open(f) as fh:
+                for k, v in json.load(fh).items():
+                    if k in cfg.__dict__ and k not in kwargs:
+                        setattr(cfg, k, v)
+        return cfg
+
+
+class MVLBertConfigforVQA(MVLBertConfig):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.attention_probs_dropout_prob = 0.1
+        self.hidden_dropout_prob = 0.1
+
+
+class MVLBertPretrainConfig(MVLBertConfig):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.ITM_task = kwargs.get("ITM_task", False)
+        self.max_length = kwargs.get("max_length", 150)
+        self.attention_probs_dropout_prob = 0.1
+        self.hidden_dropout_prob = 0.1
+
+
+class MVLBertRetrieval(MVLBertConfig):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.lr = 1e-6
+        self.max_length = kwargs.get("max_length", 80)
+        self.attention_probs_dropout_prob = 0.1
+
+
+class MVLBertConfigForImageCaption(MVLBertConfig):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.lr = 1e-5
+        self.max_length = kwargs.get("max_length", 80)
+        self.is_decoder = True
+        self.attention_probs_dropout_prob = 0.1
+        self.hidden_dropout_prob = 0.1
+
+
+# ----------------------------------------------------------------------------- Conv_layer (model.py:186-266)
+class _GeluMarker(nn.GELU):
+    """nn.GELU placeholder at ``conv.1``; the activation is fused into the
+    final Swin LayerNorm kernel."""
+
+
+class Conv_layer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size if config is not None else 768
+        if config.conv.lower() != 'swintransformer':
+            raise NotImplementedError("only config.conv='swintransformer' is on the MI355X hot path")
+        conv = SwinTransformer(**config.swin)
+        ckpt = getattr(config, "swin_checkpoint", None)
+        if ckpt is not None and os.path.exists(ckpt):     # reference: torch.load(...)['model'], strict=False (model.py:222-226)
+            conv.load_state_dict(torch.load(ckpt, map_location='cpu')['model'], strict=False)
+        if conv.num_features != config.hidden_size:
+            raise ValueError(f"Swin emits {conv.num_features}-d tokens but hidden_size is {config.hidden_size} "
+                             "(the reference has no projection for Swin features either, model.py:263)")
+        self.conv = nn.Sequential(conv, _GeluMarker())
+        self.resnet_fc = nn.Linear(2048, config.hidden_size)    # unused with Swin; kept for state-dict parity
+
+    def forward(self, v):
+        swin = self.conv[0]
+        if torch.is_tensor(v) and v.dim() == 5:       # IU-Xray image pairs (model.py:240-253)
+            return torch.cat((swin(v[:, 0], fuse_gelu=True), swin(v[:, 1], fuse_gelu=True)), dim=1)
+        return swin(v, fuse_gelu=True)
+
+
+# ----------------------------------------------------------------------------- MLM head holders (HF BertOnlyMLMHead)
+class BertPredictionHeadTransform(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class BertLMPredictionHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = nn.Linear(config.hidden_size, config.vocab_size, bias=True)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))   # present in HF state dicts; decoder.bias is what forward uses
+
+
+class BertOnlyMLMHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+
+    def forward(self, sequence_output):
+        """logits [..., V] (differentiable) -- used by the caption head / decode."""
+        shp = sequence_output.shape
+        x = sequence_output.reshape(-1, shp[-1]).contiguous()
+        tok = _token(self, x.device)
+        return _MlmLogitsFn.apply(tok, x, self, torch.is_grad_enabled()).view(*shp[:-1], -1)
+
+    # ---- engine pieces shared by the fused-loss path and the logits path
+    def _transform(self, ar, x, save):
+        pr = self.predictions
+        pre = torch.empty_like(x)
+        t1 = ops.gemm(x, ar.compute(pr.transform.dense.weight), bias=pr.transform.dense.bias.data, gelu=True, save_pre=pre)
+        ln = pr.transform.LayerNorm
+        t2, mean, rstd, _ = ops.layernorm_fwd(t1, ln.weight.data, ln.bias.data, ln.eps, save_stats=save)
+        return pre, t1, t2, mean, rstd
+
+    def _logits(self, ar, t2):
+        pr = self.predictions
+        V = pr.decoder.out_features
+        ld = (V + 63) // 64 * 64
+        logits = ops.gemm(t2, ar.compute(pr.decoder.weight), bias=pr.decoder.bias.data, ldc=ld)
+        return logits, V
+
+    def _backward_from_dlogits(self, ar, dlogits, V, x, pre, t1, t2, mean, rstd):
+        pr = self.predictions
+        g = ar.grad_view
+        dl = dlogits[:, :V]
+        dt2 = ops.gemm(dl, ar.compute(pr.decoder.weight), b_kmajor=True)
+        ops.gemm(dl, t2, a_kmajor=True, b_kmajor=True, out=g(pr.decoder.weight), out_f32=True)
+        ops.colsum(dl, out=g(pr.decoder.bias))
+        ln = pr.transform.LayerNorm
+        dt1 = ops.layernorm_bwd(dt2, t1, mean, rstd, ln.weight.data, g(ln.weight), g(ln.bias))
+        dpre = ops.gelu_bwd(pre, dt1)
+        dx = ops.gemm(dpre, ar.compute(pr.transform.dense.weight), b_kmajor=True)
+        ops.gemm(dpre, x, a_kmajor=True, b_kmajor=True, out=g(pr.transform.dense.weight), out_f32=True)
+        ops.colsum(dpre, out=g(pr.transform.dense.bias))
+        ar.mark(pr.decoder.weight, pr.decoder.bias, ln.weight, ln.bias, pr.transform.dense.weight, pr.transform.dense.bias)
+        return dx
+
+
+def _token(mod, device):
+    tok = mod.__dict__.get("_mvlt_token")
+    if tok is None or tok.device != device:
+        tok = torch.zeros(1, device=device, requires_grad=True)
+        mod.__dict__["_mvlt_token"] = tok
+    return tok
+
+
+class _MlmLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, token, x, head, save):
+        ar = Arena.of(head, x.dtype)
+        ar.refresh_shadow()
+        pre, t1, t2, mean, rstd = head._transform(ar, x, save)
+        logits, V = head._logits(ar, t2)
+        ctx.head, ctx.saved = head, (ar, V, x, pre, t1, t2, mean, rstd) if save else None
+        return logits[:, :V]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ar, V, x, pre, t1, t2, mean, rstd = ctx.saved
+        backward_begin(ar)
+        ld = (V + 63) // 64 * 64
+        dfull = torch.zeros((dlogits.shape[0], ld), dtype=x.dtype, device=x.device)
+        dfull[:, :V] = dlogits
+        dx = ctx.head._backward_from_dlogits(ar, dfull, V, x, pre, t1, t2, mean, rstd)
+        ctx.saved = None
+        return None, dx, None, None
+
+
+class _MlmLossFn(torch.autograd.Function):
+    """MLM head + F.cross_entropy(ignore_index=-100) fused (model.py:399-410):
+    logits stay in one padded [rows, ld] buffer, CE backward overwrites it in place."""
+
+    @staticmethod
+    def forward(ctx, token, x, head, labels, save):
+        ar = Arena.of(head, x.dtype)
+        ar.refresh_shadow()
+        pre, t1, t2, mean, rstd = head._transform(ar, x, save)
+        logits, V = head._logits(ar, t2)
+        acc, lse = ops.ce_fwd(logits, V, labels)
+        loss = acc[0] / acc[1]          # mean over labelled positions (nan if none, as in torch)
+        ctx.head = head
+        ctx.saved = (ar, V, x, pre, t1, t2, mean, rstd, logits, labels, lse, acc) if save else None
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        ar, V, x, pre, t1, t2, mean, rstd, logits, labels, lse, acc = ctx.saved
+        backward_begin(ar)
+        gs = dloss.reshape(1).to(torch.float32).contiguous()
+        dlogits = ops.ce_bwd(logits, V, labels, lse, acc, grad_scale=1.0, grad_scale_dev=gs)
+        dx = ctx.head._backward_from_dlogits(ar, dlogits, V, x, pre, t1, t2, mean, rstd)
+        ctx.saved = None
+        return None, dx, None, None, None
+
+
+class _LinearCEFn(torch.autograd.Function):
+    """Small classifier + cross entropy (ITM, model.py:415-418)."""
+
+    @staticmethod
+    def forward(ctx, token, x, lin, labels, save):
+        ar = Arena.of(lin, x.dtype)
+        ar.refresh_shadow()
+        V = lin.out_features
+        ld = (V + 3) // 4 * 4
+        logits = ops.gemm(x, ar.compute(lin.weight), bias=lin.bias.data, ldc=ld)
+        acc, lse = ops.ce_fwd(logits, V, labels)
+        ctx.lin, ctx.saved = lin, (ar, V, x, logits, labels, lse, acc) if save else None
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        ar, V, x, logits, labels, lse, acc = ctx.saved
+        backward_begin(ar)
+        lin = ctx.lin
+        gs = dloss.reshape(1).to(torch.float32).contiguous()
+        dl = ops.ce_bwd(logits, V, labels, lse, acc, grad_scale_dev=gs)[:, :V]
+        dx = ops.gemm(dl, ar.compute(lin.weight), b_kmajor=True)
+        ops.gemm(dl, x, a_kmajor=True, b_kmajor=True, out=ar.grad_view(lin.weight), out_f32=True)
+        ops.colsum(dl, out=ar.grad_view(lin.bias))
+        ar.mark(lin.weight, lin.bias)
+        ctx.saved = None
+        return None, dx, None, None, None
+
+
+class _LinearFn(torch.autograd.Function):
+    """(dropout ->) Linear producing f32 logits (VQA / retrieval final layer)."""
+
+    @staticmethod
+    def forward(ctx, token, x, lin, p_drop, save):
+        ar = Arena.of(lin, x.dtype)
+        ar.refresh_shadow()
+        seed = next_seed() if p_drop > 0 else 0
+        xd = ops.rows_transform(x, dropout=(p_drop, seed, 4001)) if p_drop > 0 else x
+        V = lin.out_features
+        logits = ops.gemm(xd, ar.compute(lin.weight), bias=lin.bias.data, ldc=(V + 3) // 4 * 4)
+        ctx.lin, ctx.saved = lin, (ar, V, xd, p_drop, seed) if save else None
+        return ops.cast(logits, torch.float32)[:, :V] if logits.dtype != torch.float32 else logits[:, :V]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ar, V, xd, p_drop, seed = ctx.saved
+        backward_begin(ar)
+        lin = ctx.lin
+        dl = dlogits.to(xd.dtype).contiguous()
+        dxd = ops.gemm(dl, ar.compute(lin.weight), b_kmajor=True)
+        ops.gemm(dl, xd, a_kmajor=True, b_kmajor=True, out=ar.grad_view(lin.weight), out_f32=True)
+        ops.colsum(dl, out=ar.grad_view(lin.bias))
+        ar.mark(lin.weight, lin.bias)
+        dx = ops.rows_transform(dxd, dropout=(p_drop, seed, 4001)) if p_drop > 0 else dxd
+        ctx.saved = None
+        return None, dx, None, None, None
+
+
+# ----------------------------------------------------------------------------- base with HF-like persistence
+class MVLBertPretrainedModel(nn.Module):
+    base_model_prefix = "MVLBert"
+    config_class = MVLBertConfig
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, os.path.join(path, "pytorch_model.bin"))
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.config.to_dict(), f)
+
+    @classmethod
+    def from_pretrained(cls, path, config=None, **kwargs):
+        config = config or cls.config_class.from_pretrained(path)
+        model = cls(config, **kwargs)
+        f = os.path.join(path, "pytorch_model.bin")
+        if os.path.exists(f):
+            sd = torch.load(f, map_location="cpu")
+            for head in ("MLM_head_seq2seq", "MLM_head_bidir"):     # HF 4.x ties predictions.bias == decoder.bias
+                b, d = f"{head}.predictions.bias", f"{head}.predictions.decoder.bias"
+                if b in sd and d not in sd:
+                    sd[d] = sd[b].clone()
+            model.load_state_dict(sd, strict=False)
+        return model
+
+
+# ----------------------------------------------------------------------------- heads
+class MVLBertForPretraining(MVLBertPretrainedModel):
+    """model.py:352-420.  The seq2seq/bidirectional coin flip (model.py:390-394)
+    uses Python's ``random`` like the reference; under DDP every rank must draw
+    the same value (mvlt_amd.ddp seeds it)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.config.output_text_and_image_seperately = True
+        self.conv = Conv_layer(config)
+        self.MVLBert = MVLBert(config, add_pooling_layer=True)
+        self.MLM_head_seq2seq = BertOnlyMLMHead(config)
+        self.MLM_head_bidir = BertOnlyMLMHead(config)
+        self.ITM_mlp = nn.Linear(config.hidden_size, 2)
+        self.last_seq2seq = None
+
+    def forward(self, image, caption_masked, caption_label, image_text_label, image_mask=None):
+        Arena.of(self, compute_dtype_of(self))       # one arena for the whole model
+        image_feature = self.conv(image)
+        text_idx = caption_masked
+        text_mask = None          # == (text_idx > 0); rebuilt in-kernel from the ids
+        seq2seq_mask = random.random() < 0.5
+        self.last_seq2seq = seq2seq_mask
+        text_out, _, pooled, _ = self.MVLBert(text_idx, text_mask, image_feature, image_mask,
+                                              seq2seq_mask=seq2seq_mask, output_text_image_seperate=True)
+        head = self.MLM_head_seq2seq if seq2seq_mask else self.MLM_head_bidir
+        dev = image_feature.device
+        mlm_loss = torch.zeros((1, 1))
+        itm_loss = None
+        if self.config.MLM_task:
+            B, T, H = text_out.shape
+            x = text_out.reshape(B * T, H).contiguous()
+            labels = caption_label.reshape(-1).to(torch.int64).contiguous()
+            mlm_loss = _MlmLossFn.apply(_token(head, dev), x, head, labels, torch.is_grad_enabled())
+        if self.config.ITM_task:
+            itm_loss = _LinearCEFn.apply(_token(self.ITM_mlp, dev), pooled, self.ITM_mlp,
+                                         image_text_label.reshape(-1).to(torch.int64).contiguous(),
+                                         torch.is_grad_enabled())
+        return mlm_loss if itm_loss is None else mlm_loss.mean() + itm_loss.mean()
+
+
+class MVLBertForVQA(MVLBertPretrainedModel):
+    """model.py:297-349 -> (prob, logits)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.conv = Conv_layer(config)
+        self.activation = nn.GELU()
+        self.add_pooling_layer = True
+        self.MVLBert = MVLBert(config, add_pooling_layer=True)
+        self.final_mlp = nn.Sequential(nn.Dropout(config.hidden_dropout_prob, inplace=False),
+                                       nn.Linear(config.hidden_size, config.result_num))
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward(self, image, question, label, image_mask=None):
+        Arena.of(self, compute_dtype_of(self))
+        image_feature = self.conv(image)
+        _, pooled = self.MVLBert(text_idx=question, text_mask=None, image_feature=image_feature, image_mask=image_mask)
+        lin = self.final_mlp[1]
+        p = self.final_mlp[0].p if self.training else 0.0
+        logits = _LinearFn.apply(_token(lin, pooled.device), pooled, lin, p, torch.is_grad_enabled())
+        with torch.no_grad():
+            prob = ops.softmax_rows(logits.contiguous(), logits.shape[1])
+        return prob, logits
+
+
+class MVLBertForRetrieval(MVLBertPretrainedModel):
+    """model.py:423-476: transform (dense+GELU+LN) + Linear(768,2)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.conv = Conv_layer(config)
+        self.MVLBert = MVLBert(config, add_pooling_layer=True)
+        self.final_mlp = nn.Sequential(BertPredictionHeadTransform(config), nn.Linear(config.hidden_size, 2))
+
+    def forward(self, image, caption, image_text_label=None, image_mask=None):
+        raise NotImplementedError("retrieval head is outside the MI355X hot-path scope (SURVEY.md section 2); "
+                                  "it reuses Conv_layer + MVLBert, which are drop-ins")
+
+
+class MVLBertForImageCaption(MVLBertPretrainedModel):
+    """model.py:479-546 (+ greedy_search :826-984 in decode.py)."""
+
+    def __init__(self, config, tokenizer=None):
+        super().__init__(config)
+        assert config.is_decoder, 'config.is_decoder should be True if you want to run image caption for testing'
+        self.MVLBert = MVLBert(config, add_pooling_layer=True)
+        self.conv = Conv_layer(config)
+        self.tokenizer = tokenizer
+        self.MLM_head_seq2seq = BertOnlyMLMHead(config)
+
+    def forward(self, image, caption, num_beams, learning_strategy, sample_mode='greedy'):
+        Arena.of(self, compute_dtype_of(self))
+        image_feature = self.conv(image)
+        if num_beams > 1:
+            raise NotImplementedError("beam search needs HF BeamSearchScorer semantics (third-party, unpinned): "
+                                      "parity unpinned -> not built; use num_beams=1 (greedy)")
+        if num_beams == 1:
+            from .decode import greedy_search
+            return greedy_search(self, image_feature, learning_strategy=learning_strategy, sample_mode=sample_mode)
+        return self.encode_forward(image_feature, caption, learning_strategy)
+
+    def encode_forward(self, image_feature, caption, learning_strategy):
+        text_out, _, _, sep_out = self.MVLBert(text_idx=caption, text_mask=None, image_feature=image_feature,
+                                               image_mask=None, seq2seq_mask=True, output_text_image_seperate=True)
+        if learning_strategy == 'unilm':
+            return self.MLM_head_seq2seq(text_out).transpose(1, 2)
+        if learning_strategy == 'normal':
+            return self.MLM_head_seq2seq(torch.cat([sep_out[:, None], text_out[:, :-1]], dim=1)).transpose(1, 2)
+        raise NotImplementedError("learning_strategy:", learning_strategy, "is not implemented! Try 'unilm' or 'normal'.")

@@ -351,11 +351,27 @@ def ce_fwd(logits, V, labels):
     return acc, lse
 
 
-def ce_bwd(logits, V, labels, lse, acc, grad_scale=1.0, out=None):
+def ce_bwd(logits, V, labels, lse, acc, grad_scale=1.0, out=None, grad_scale_dev=None):
     if out is None:
         out = logits
+    if grad_scale_dev is not None:
+        assert grad_scale_dev.dtype == torch.float32 and grad_scale_dev.numel() == 1
     L.check(L.lib().mvlt_ce_bwd(_dt(logits), _p(logits), logits.stride(0), logits.shape[0], V, _p(labels), _p(lse),
-                                C.c_void_p(acc.data_ptr() + 4), float(grad_scale), _p(out), _stream()), "mvlt_ce_bwd")
+                                C.c_void_p(acc.data_ptr() + 4), float(grad_scale), _p(grad_scale_dev), _p(out),
+                                _stream()), "mvlt_ce_bwd")
+    return out
+
+
+def gelu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    L.check(L.lib().mvlt_gelu_bwd(_dt(x), _p(x), _p(dy), _p(dx), x.numel(), _stream()), "mvlt_gelu_bwd")
+    return dx
+
+
+def softmax_rows(logits, V):
+    out = torch.empty((logits.shape[0], V), dtype=torch.float32, device=logits.device)
+    L.check(L.lib().mvlt_softmax_rows(_dt(logits), _p(logits), logits.stride(0), logits.shape[0], V, _p(out),
+                                      _stream()), "mvlt_softmax_rows")
     return out
 
 

@@ -1,0 +1,85 @@
+"""CPU tests of the host-side logic: INT tables of the product package against
+the reference's tables (golden), state-dict contract, C-ABI symbol export."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_int_tables_match_reference(golden):
+    from mvlt_amd import indexing as I
+    g = golden("int_tables")
+    assert torch.equal(I.relative_position_index(7), g["relative_position_index"])
+    for H in (56, 28, 14):
+        m = I.shift_attn_mask(H, H, 7, 3)
+        assert torch.equal((m != 0).to(torch.int8), g[f"attn_mask_{H}"]) and m.min().item() == -100.0
+        assert torch.equal(I.window_token_map(H, H, 7, 0), g[f"winmap_noshift_{H}"])
+        assert torch.equal(I.window_token_map(H, H, 7, 3), g[f"winmap_shift_{H}"])
+        assert torch.equal(I.patch_merge_map(H, H), g[f"mergemap_{H}"])
+        w2n, n2w = I.batched_window_maps(2, H, H, 7, 3, torch.device("cpu"))
+        assert torch.equal(w2n[:H * H].long(), g[f"winmap_shift_{H}"])
+        assert torch.equal(w2n.long()[n2w.long()], torch.arange(2 * H * H))
+
+
+@pytest.mark.parametrize("name,cls", [("pretrain", "MVLBertForPretraining"), ("vqa", "MVLBertForVQA")])
+def test_state_dict_contract(specs, name, cls):
+    """Same keys, shapes, dtypes and order as the reference model's state_dict()."""
+    import mvlt_amd as M
+    cfg = M.MVLBertPretrainConfig() if name == "pretrain" else M.MVLBertConfigforVQA()
+    model = getattr(M, cls)(cfg)
+    ref = [(k, tuple(s), d) for k, s, d in specs[name]]
+    mine = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in model.state_dict().items()]
+    assert [k for k, _, _ in mine] == [k for k, _, _ in ref]
+    assert mine == ref
+    if name == "pretrain":
+        assert sum(p.numel() for p in model.parameters()) == 208853340
+
+
+def test_tiny_caption_contract(specs):
+    import mvlt_amd as M
+    cfg = M.MVLBertConfigForImageCaption(hidden_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                         intermediate_size=1024, vocab_size=3000)
+    cfg.swin.update(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], drop_path_rate=0.2)
+    model = M.MVLBertForImageCaption(cfg)
+    ref = [(k, tuple(s)) for k, s, d in specs["tiny_caption"]]
+    assert [(k, tuple(v.shape)) for k, v in model.state_dict().items()] == ref
+
+
+def test_swin_flops_match_reference_formula():
+    import mvlt_amd as M
+    sw = M.SwinTransformer(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], drop_path_rate=0.3)
+    assert abs(sw.flops() / 1e9 - 8.746) < 0.002          # 8.746 GMAC / image
+
+
+def test_cabi_exports_every_declared_symbol():
+    """libmvlt_hip.so loads on a GPU-less host and exports every function
+    include/mvlt_hip.h declares (no compute calls here)."""
+    from mvlt_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mvlt_hip.h")).read()
+    declared = set(re.findall(r"\b(mvlt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    L = _lib.lib()
+    assert L.mvlt_version() == 1 and L.mvlt_arch() == b"gfx950"
+
+
+def test_no_cpu_fallback():
+    import mvlt_amd as M
+    sw = M.SwinTransformer(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8])
+    with pytest.raises(RuntimeError, match="GPU only"):
+        sw(torch.zeros(1, 3, 224, 224))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "medical-vision-langauge-transformer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "mvlt_oracle" not in src, f
