@@ -1,0 +1,193 @@
+"""Headline benchmark: image-text pairs/sec of one MVLT pre-training step
+(Swin-S + BERT-base, 224 px, seq 80, MLM+ITM, bf16) on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + backward (+ RCCL gradient all-reduce) + AdamW over one
+synthetic batch that is already resident in HBM (B=32 per GPU: weak scaling).
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, timed live with
+HIP events on the launch stream) and `cpu_baseline` (the oracle timed on the
+host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_PAIR = 132.7          # fwd 44.22 GFLOP x 3 (reference-equivalent work)
+PEAK_BF16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PER_GPU_BATCH, SEQ = 32, 80
+
+
+class KernelTimer:
+    """Brackets every launch of one kernel family with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.pairs, self.flops = [], 0.0
+
+    def __call__(self, flops):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.pairs.append((s, e))
+        self.flops += flops
+        return s, e
+
+    def result(self):
+        if not self.pairs:
+            return None
+        ms = sum(s.elapsed_time(e) for s, e in self.pairs)
+        return dict(launches=len(self.pairs), avg_us=1e3 * ms / len(self.pairs), tflops=self.flops / (ms * 1e-3) / 1e12)
+
+
+def _cpu_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_worker():
+    """Child process: the CPU oracle (plain fp32 PyTorch restatement of the reference, train mode
+    with the reference dropouts) timed on this host's cores: fwd + bwd + AdamW."""
+    from oracle import mvlt_oracle as O
+    from mvlt_amd.train import synthetic_batch
+    import mvlt_amd as M
+    threads = _cpu_threads()
+    torch.set_num_threads(threads)
+    B = 2
+    model = M.MVLBertForPretraining(M.MVLBertPretrainConfig())        # parameter container only (CPU); math = oracle
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point else v)
+          for k, v in model.state_dict().items()}
+    del model
+    params = [v for v in sd.values() if v.dtype.is_floating_point]
+    opt = torch.optim.AdamW(params, lr=4e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=1e-4)
+    image, ids, labels, itm = synthetic_batch(B, SEQ, "cpu", 99)
+    drop = O.Dropper("torch")
+    times = []
+    t_start = time.time()
+    for i in range(4):
+        t = time.time()
+        loss = O.pretrain_loss(sd, O.SwinCfg(), O.BertCfg(), image, ids, labels, itm, i % 2 == 0, itm_task=True, drop=drop)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        times.append(time.time() - t)
+        if time.time() - t_start > 30.0:
+            break
+    timed = times[1:] if len(times) > 1 else times          # first step = warm-up when there is more than one
+    print(json.dumps(dict(value=round(B * len(timed) / sum(timed), 3), unit="pairs/s", cores=threads, kind="port",
+                          sample=f"{len(timed)} timed step(s) of B={B}, T={SEQ}, fwd+bwd+AdamW, fp32 train mode "
+                                 f"(oracle/mvlt_oracle.py, {len(times) - len(timed)} warm-up)")), flush=True)
+
+
+def cpu_baseline(timeout_s=150):
+    """Runs the worker as a CHILD process with a hard timeout so the benchmark always finishes."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
+                           text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return dict(value=None, unit="pairs/s", cores=_cpu_threads(), kind="port", sample="worker produced no result: " + r.stderr[-200:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="pairs/s", cores=_cpu_threads(), kind="port", sample=f"timed out after {timeout_s}s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        cpu_baseline_worker()
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import mvlt_amd as M
+    from mvlt_amd import ops
+    from mvlt_amd.ddp import GradReducer, seed_coin_flip
+    from mvlt_amd.train import PretrainStep, synthetic_batch
+
+    torch.manual_seed(1234)                         # same random-init replica on every rank
+    cfg = M.MVLBertPretrainConfig()
+    cfg.ITM_task = True                             # BASELINE config: Pretrain (MLM+ITM)
+    model = M.MVLBertForPretraining(cfg).cuda().train()
+    M.manual_seed(4321 + rank)                      # dropout stream differs per rank
+    seed_coin_flip(5678)                            # seq2seq/bidir flip identical on all ranks
+    reducer = GradReducer(model) if world > 1 else None
+    step = PretrainStep(model, reducer=reducer, world_size=world)
+    batch = synthetic_batch(PER_GPU_BATCH, SEQ, "cuda", 1234 + rank)
+
+    for _ in range(args.warmup):
+        step(batch)
+    timer = KernelTimer()
+    ops.GEMM_TIMER = timer
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        pairs = PER_GPU_BATCH * world * args.steps
+        value = pairs / elapsed
+        kr = timer.result()
+        roofline = None
+        if kr is not None:
+            roofline = {"bound": "mfma", "kernel": "gemm_kernel<bf16> (all Linear fwd/dgrad/wgrad launches)",
+                        "achieved": round(kr["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(kr["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "launches": kr["launches"], "avg_launch_us": round(kr["avg_us"], 2)}
+        out = {"metric": "image-text pairs/sec pretrain step (Swin-S+BERT, 224px, seq80)", "value": round(value, 2),
+               "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "Pretrain (MLM+ITM) Swin-S + BERT-base, batch=32/GPU, 224x224, seq80, bf16 "
+                                      "storage + f32 accumulate/master, fwd+bwd+allreduce+AdamW, random-init weights",
+                          "global_batch": PER_GPU_BATCH * world, "seq_len": SEQ, "parallelism": f"dp{world}",
+                          "loss": round(float(loss.item()), 4)},
+               "step_tflops_per_gpu": round(value / world * GFLOP_PER_PAIR / 1e3, 2),
+               "step_mfma_frac": round(value / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS, 4),
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

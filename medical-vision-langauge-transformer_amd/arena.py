@@ -25,7 +25,8 @@ ALIGN = 64  # elements (256 B for f32, 128 B for the bf16 copy)
 
 
 class Arena:
-    def __init__(self, root: nn.Module, compute_dtype: torch.dtype):
+    def __init__(self, root: nn.Module, compute_dtype: torch.dtype, allow_cpu: bool = False):
+        # allow_cpu: host-logic tests only (bucketing / DDP over gloo); no kernel ever runs on CPU tensors
         params: List[Tuple[str, nn.Parameter]] = []
         seen = set()
         for name, p in root.named_parameters():
@@ -36,7 +37,7 @@ class Arena:
         if not params:
             raise RuntimeError("module has no parameters")
         dev = params[0][1].device
-        if dev.type != "cuda":
+        if dev.type != "cuda" and not allow_cpu:
             raise RuntimeError("mvlt_amd modules run on the GPU only: call .cuda() first (no CPU fallback)")
         # fused groups (must be adjacent): declared by modules through _arena_groups()
         order: List[Tuple[str, nn.Parameter]] = []
@@ -79,6 +80,7 @@ class Arena:
                 p.data = view
         self._ptr0 = self.params[0].data_ptr()
         self.shadow_fresh = False
+        self._flat_version = -1
         self.has_grad: Dict[int, bool] = {id(p): False for p in self.params}
         self.steps: Dict[int, int] = {id(p): 0 for p in self.params}
         self.exp_avg: Optional[torch.Tensor] = None
@@ -122,13 +124,29 @@ class Arena:
         return self.grad[o:o + r * cols].view(r, cols)
 
     def mark(self, *ps: nn.Parameter) -> None:
+        """Gradients of ``ps`` have been written.  The backward pass walks the
+        arena downwards, so everything at or above the lowest offset marked so
+        far is final: that watermark drives the DDP bucket launches."""
+        lo = None
         for p in ps:
             self.has_grad[id(p)] = True
+            o = self.offset[id(p)]
+            lo = o if lo is None or o < lo else lo
+        cb = self.__dict__.get("_on_watermark")
+        if cb is not None and lo is not None:
+            wm = self.__dict__.get("_watermark", self.total)
+            if lo < wm:
+                self._watermark = lo
+                cb(self, lo)
 
     # ------------------------------------------------------------------ per-step state
     def begin_backward(self) -> None:
         for k in self.has_grad:
             self.has_grad[k] = False
+        self._watermark = self.total
+        cb = self.__dict__.get("_on_backward_begin")
+        if cb is not None:
+            cb(self)
 
     def publish_grads(self) -> None:
         """Expose gradients the torch way: p.grad is a view for parameters that
@@ -143,14 +161,18 @@ class Arena:
                 p.grad = None
 
     def refresh_shadow(self) -> None:
-        """bf16 compute copy <- f32 master (one pass, 6 B/param)."""
-        if self.shadow is not None and not self.shadow_fresh:
+        """bf16 compute copy <- f32 master (one pass, 6 B/param) whenever the
+        master was modified through torch (load_state_dict, a torch optimizer:
+        in-place ops on the views bump ``flat._version``).  The fused AdamW
+        kernel refreshes the copy itself and leaves the version untouched."""
+        if self.shadow is not None and (not self.shadow_fresh or self.flat._version != self._flat_version):
             from . import ops
             ops.cast(self.flat, torch.bfloat16, out=self.shadow)
             self.shadow_fresh = True
+            self._flat_version = self.flat._version
 
-    def invalidate_shadow(self) -> None:
-        self.shadow_fresh = False
+    def note_params_written_by_kernel(self) -> None:
+        self._flat_version = self.flat._version
 
     def active_ranges(self) -> List[Tuple[int, int, int]]:
         """Maximal contiguous [start, end) element ranges of parameters that

@@ -184,12 +184,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* x, long ld
         for (int e = 0; e < 4; ++e) if (c + e < N) part[(long)blockIdx.y * N + c + e] = s[e];
     }
 }
-__global__ void colsum_final_kernel(const float* part, int nparts, int N, float* out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, int nparts, int N, float* out, int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += part[(long)i * N + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < N) for (int i = w; i < nparts; i += 4) s += part[(long)i * N + c];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < N) {
+        s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // ------------------------------------------------------------------ cross entropy
@@ -473,7 +479,7 @@ extern "C" int mvlt_colsum(int dtype, const void* x, int64_t ld, int M, int N, f
     BY_DTYPE(dtype,
              hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, STREAM(stream), (const float*)x, (long)ld, M, N, workspace),
              hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, STREAM(stream), (const bf16_t*)x, (long)ld, M, N, workspace));
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, STREAM(stream), workspace, slices, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, STREAM(stream), workspace, slices, N, out, accumulate);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }

@@ -1,0 +1,109 @@
+"""Data-parallel pre-training over RCCL / xGMI: one process per GPU.
+
+The reference has no distributed code; this is the new
+exchange step BASELINE.json asks for.  Design for 8 x MI355X on one node
+(xGMI is point-to-point, 7 links x ~153 GB/s per GPU):
+
+* every rank holds a full replica (0.84 GB f32 + optimizer state: trivial in
+  288 GB), the global batch is sharded across ranks, no data-path collective;
+* the only collective is a SUM all-reduce of the flat f32 gradient buffer,
+  issued in large contiguous buckets (default 64 MiB -- few, large transfers
+  keep RCCL's rings/trees bandwidth-bound rather than latency-bound) as soon
+  as the backward pass has finished the parameters of a bucket.  The backward
+  walks the arena from its end to its start (heads -> BERT 11..0 ->
+  embeddings -> Swin 3..0 -> patch embed), so readiness is a descending
+  watermark and buckets are plain slices of ``arena.grad``;
+* ``dist.all_reduce(async_op=True)`` orders itself after the kernels already
+  queued on the compute stream and runs on RCCL's own stream, i.e. it
+  overlaps the rest of the backward; the end-of-backward hook waits on the
+  outstanding handles; AdamW divides by world_size (grad_scale);
+* parameters without a gradient this step (idle MLM head, unused modules) are
+  not communicated;
+* the seq2seq/bidirectional coin flip of MVLBertForPretraining is drawn from
+  Python's ``random``: ``seed_coin_flip`` gives all ranks the same stream so
+  the same MLM head is active everywhere (otherwise buckets would diverge).
+"""
+from __future__ import annotations
+
+import random
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .arena import ALIGN, Arena
+from .runtime import compute_dtype_of
+
+
+def seed_coin_flip(seed: int) -> None:
+    random.seed(seed)
+
+
+def plan_ranges(arena: Arena, lo: int, hi: int, done: set) -> List[Tuple[int, int]]:
+    """Contiguous element ranges inside [lo, hi) covered by parameters that
+    received a gradient this step and have not been reduced yet (``done`` is
+    updated)."""
+    out: List[List[int]] = []
+    for p in arena.params:
+        o = arena.offset[id(p)]
+        e = o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        if o < lo or e > hi or not arena.has_grad[id(p)] or id(p) in done:
+            continue
+        done.add(id(p))
+        if out and out[-1][1] == o:
+            out[-1][1] = e
+        else:
+            out.append([o, e])
+    return [(a, b) for a, b in out]
+
+
+class GradReducer:
+    def __init__(self, model, bucket_bytes: int = 64 << 20, process_group=None, allow_cpu: bool = False):
+        self.model = model
+        self.bucket_elems = bucket_bytes // 4
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.allow_cpu = allow_cpu
+        self.arena = None
+        self.handles = []
+        self.launched: List[Tuple[int, int]] = []
+        self.done: set = set()
+        self.pending_hi = 0
+        self.attach()
+
+    def attach(self) -> Arena:
+        if self.allow_cpu:
+            ar = self.model.__dict__.get("_mvlt_arena") or Arena(self.model, torch.float32, allow_cpu=True)
+        else:
+            ar = Arena.of(self.model, compute_dtype_of(self.model))
+        if ar is not self.arena:
+            self.arena = ar
+            ar._post_backward = self._finish
+            ar._on_watermark = self._on_watermark
+            ar._on_backward_begin = self._begin
+            dist.broadcast(ar.flat, src=0, group=self.pg)        # identical replicas (bumps flat._version -> bf16 copy refreshed)
+        return ar
+
+    # ---- hooks called by the engines (runtime.backward_begin / arena.watermark / backward_end)
+    def _begin(self, arena: Arena) -> None:
+        self.pending_hi = arena.total
+        self.handles, self.launched, self.done = [], [], set()
+
+    def _on_watermark(self, arena: Arena, lo: int) -> None:
+        if self.pending_hi - lo >= self.bucket_elems:
+            self._launch(arena, lo, self.pending_hi)
+            self.pending_hi = lo
+
+    def _launch(self, arena: Arena, lo: int, hi: int) -> None:
+        for a, b in plan_ranges(arena, lo, hi, self.done):
+            self.handles.append(dist.all_reduce(arena.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self.launched.append((a, b))
+
+    def _finish(self, arena: Arena) -> None:
+        # everything not yet communicated, including parameters whose gradient
+        # arrived out of watermark order (independent head branches)
+        self._launch(arena, 0, arena.total)
+        self.pending_hi = 0
+        for h in self.handles:
+            h.wait()
+        self.handles = []

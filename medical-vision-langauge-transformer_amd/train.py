@@ -1,0 +1,45 @@
+"""Pre-training step driver (reference loop: run_pretrain.py:162-194) and the
+synthetic batch generator of SURVEY.md section 8(d)."""
+import random
+
+import torch
+
+from .optim import FusedAdamW
+
+
+def synthetic_batch(B, T, device, seed, vocab=30522, itm=True):
+    """image N(0,1) [B,3,224,224]; caption ids U{1000..vocab-1}, last real id = [END]=104,
+    zero padded; <=10 MLM labels per sample (20%), 80% of them replaced by [MASK]=103;
+    ITM labels Bernoulli(0.5) (run_pretrain_rgc_roco_medicat.py:134-212)."""
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, 224, 224, generator=g)
+    ids = torch.zeros(B, T, dtype=torch.long)
+    labels = torch.full((B, T), -100, dtype=torch.long)
+    for b in range(B):
+        ln = int(torch.randint(16, T, (1,), generator=g))
+        row = torch.randint(1000, vocab, (ln,), generator=g)
+        row[-1] = 104
+        nm = min(10, max(1, round(0.2 * ln)))
+        pos = torch.randperm(ln, generator=g)[:nm]
+        labels[b, pos] = row[pos]
+        row[pos[: max(1, int(0.8 * nm))]] = 103
+        ids[b, :ln] = row
+    itm_l = torch.randint(0, 2, (B,), generator=g) if itm else torch.ones(B, dtype=torch.long)
+    return tuple(t.to(device) for t in (image, ids, labels, itm_l))
+
+
+class PretrainStep:
+    """loss = model(batch); loss.backward(); optimizer.step()  -- one call per step.
+    ``reducer`` (mvlt_amd.ddp.GradReducer) makes it data parallel."""
+
+    def __init__(self, model, lr=None, reducer=None, world_size=1):
+        self.model = model
+        self.opt = FusedAdamW(model, lr=lr if lr is not None else model.config.lr, betas=(0.9, 0.999), eps=1e-6,
+                              weight_decay=1e-4, grad_scale=1.0 / world_size)
+        self.reducer = reducer
+
+    def __call__(self, batch):
+        loss = self.model(*batch)
+        loss.backward()
+        self.opt.step()
+        return loss

@@ -1,0 +1,23 @@
+"""One-GPU training-step timing / profiling helper (used under rocprofv3)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mvlt_amd as M
+from mvlt_amd.train import PretrainStep, synthetic_batch
+
+B = int(os.environ.get("B", 32)); steps = int(os.environ.get("STEPS", 5)); warm = int(os.environ.get("WARM", 3))
+cfg = M.MVLBertPretrainConfig(); cfg.ITM_task = True
+model = M.MVLBertForPretraining(cfg).cuda().train()
+M.manual_seed(1)
+step = PretrainStep(model)
+batch = synthetic_batch(B, 80, "cuda", 1234)
+import random; random.seed(5678)
+for i in range(warm):
+    l = step(batch)
+torch.cuda.synchronize()
+t0 = time.time()
+for i in range(steps):
+    l = step(batch)
+torch.cuda.synchronize()
+dt = (time.time() - t0) / steps
+print(f"B={B} ms/step={dt*1e3:.2f} pairs/s={B/dt:.1f} loss={l.item():.4f} mem={torch.cuda.max_memory_allocated()/2**30:.2f}GiB", flush=True)
