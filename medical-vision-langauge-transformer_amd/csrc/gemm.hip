@@ -124,6 +124,37 @@ MVLT_DEV void tile_load(typename TypeInfo<T>::Vec* __restrict__ regs, const T* b
     }
 }
 
+// Fast path of the k-loop: per-thread source pointers are computed ONCE (rows /
+// columns beyond the matrix edge are clamped to the last valid one: they only
+// feed output rows/columns that are never stored), then every full k-tile is
+// PER_THREAD unpredicated 16-byte loads and a pointer bump.
+template <typename T, int R, bool KMAJOR> struct FastLoader {
+    using G = TileGeom<T, R, KMAJOR>;
+    using Vec = typename TypeInfo<T>::Vec;
+    const T* ptr[G::PER_THREAD];
+    long step;
+    MVLT_DEV void init(const T* base, long ld, int row0, int row_lim, int k0) {
+#pragma unroll
+        for (int i = 0; i < G::PER_THREAD; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int lr = idx / G::CPR, ch = idx % G::CPR;
+            if (KMAJOR) {
+                int col = row0 + ch * G::E;
+                col = min(col, max(row_lim - G::E, 0));
+                ptr[i] = base + (long)(k0 + lr) * ld + col;
+            } else {
+                const int row = min(row0 + lr, row_lim - 1);
+                ptr[i] = base + (long)row * ld + k0 + ch * G::E;
+            }
+        }
+        step = KMAJOR ? (long)G::BKE * ld : (long)G::BKE;
+    }
+    MVLT_DEV void load(Vec* __restrict__ regs) {
+#pragma unroll
+        for (int i = 0; i < G::PER_THREAD; ++i) { regs[i] = *reinterpret_cast<const Vec*>(ptr[i]); ptr[i] += step; }
+    }
+};
+
 template <typename T, int R, bool KMAJOR>
 MVLT_DEV void tile_store(const typename TypeInfo<T>::Vec* __restrict__ regs, T* lds) {
     using G = TileGeom<T, R, KMAJOR>;
@@ -154,8 +185,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev p) {
     using GB = TileGeom<T, BN, BK_>;
     using Vec = typename TypeInfo<T>::Vec;
     constexpr int FM = BM / 32, FN = BN / 32;
-    __shared__ __attribute__((aligned(16))) T sA[2][GA::ELEMS];
-    __shared__ __attribute__((aligned(16))) T sB[2][GB::ELEMS];
+    __shared__ __attribute__((aligned(16))) T sA[GA::ELEMS];
+    __shared__ __attribute__((aligned(16))) T sB[GB::ELEMS];
 
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int ks = blockIdx.z * p.k_per_split;
@@ -171,38 +202,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Single LDS stage (so 3-4 workgroups fit per CU and hide each other's HBM latency);
+    // the next tile's global loads are in flight in registers while this tile is multiplied.
     Vec ra[GA::PER_THREAD], rb[GB::PER_THREAD];
     const int nkt = (ke - ks + GA::BKE - 1) / GA::BKE;
-    if (nkt > 0) {
-        tile_load<T, BM, AK>(ra, A, p.lda, m0, p.M, ks, ke, p.a_vec);
-        tile_load<T, BN, BK_>(rb, B, p.ldb, n0, p.N, ks, ke, p.b_vec);
-        tile_store<T, BM, AK>(ra, sA[0]);
-        tile_store<T, BN, BK_>(rb, sB[0]);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) {
-            const int k0 = ks + (kt + 1) * GA::BKE;
+    // number of k-tiles that lie fully inside [ks, ke) and can use unpredicated vector loads
+    const int nfast = (p.a_vec && p.b_vec && (AK || p.M >= 1) ) ? (ke - ks) / GA::BKE : 0;
+    FastLoader<T, BM, AK> la;
+    FastLoader<T, BN, BK_> lb;
+    la.init(A, p.lda, m0, p.M, ks);
+    lb.init(B, p.ldb, n0, p.N, ks);
+    auto fetch = [&](int kt) {
+        if (kt < nfast) { la.load(ra); lb.load(rb); }
+        else {
+            const int k0 = ks + kt * GA::BKE;
             tile_load<T, BM, AK>(ra, A, p.lda, m0, p.M, k0, ke, p.a_vec);
             tile_load<T, BN, BK_>(rb, B, p.ldb, n0, p.N, k0, ke, p.b_vec);
         }
+    };
+    if (nkt > 0) fetch(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        tile_store<T, BM, AK>(ra, sA);
+        tile_store<T, BN, BK_>(rb, sB);
+        __syncthreads();
+        if (kt + 1 < nkt) fetch(kt + 1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             typename Mma<T>::Frag fa[FM], fb[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) fa[i] = tile_frag<T, BM, AK>(sA[cur], wm * (BM / 2) + i * 16, kb);
+            for (int i = 0; i < FM; ++i) fa[i] = tile_frag<T, BM, AK>(sA, wm * (BM / 2) + i * 16, kb);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) fb[j] = tile_frag<T, BN, BK_>(sB[cur], wn * (BN / 2) + j * 16, kb);
+            for (int j = 0; j < FN; ++j) fb[j] = tile_frag<T, BN, BK_>(sB, wn * (BN / 2) + j * 16, kb);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
-        }
-        if (more) {
-            tile_store<T, BM, AK>(ra, sA[cur ^ 1]);
-            tile_store<T, BN, BK_>(rb, sB[cur ^ 1]);
         }
         __syncthreads();
     }
@@ -270,9 +304,9 @@ Plan choose_plan(const MvltGemm* p) {
         split = 1;
         const int bke = (p->dtype == MVLT_BF16) ? 64 : 32;
         const int nkt = ceil_div(p->K, bke);
-        if (tiles < 192 && nkt >= 8) {
-            split = (int)((512 + tiles - 1) / tiles);
-            if (split > nkt / 4) split = nkt / 4;
+        if (tiles < 512 && nkt >= 16) {
+            split = (int)((1024 + tiles - 1) / tiles);
+            if (split > nkt / 8) split = nkt / 8;
             if (split > 256) split = 256;
             if (split < 1) split = 1;
         }
