@@ -273,3 +273,50 @@ def test_bf16_gradients_match_f32_path(M, size):
     num = sum(float((g16[k] - g32[k]).pow(2).sum()) for k in g32)
     den = sum(float(g32[k].pow(2).sum()) for k in g32)
     assert (num / den) ** 0.5 < 3e-2, (num / den) ** 0.5
+
+
+# ------------------------------------------------------------------ decode (config #4 path): KV cache + greedy
+def _tiny_caption(M, specs, cd):
+    cfg = tiny_cfg(M, cls=M.MVLBertConfigForImageCaption)
+    cfg.max_length = 10
+    tok = type("Tok", (), {"mask_token_id": 103, "sep_token_id": 102})()
+    model = M.MVLBertForImageCaption(cfg, tokenizer=tok)
+    sd = load_formula(model, specs["tiny_caption"])
+    return M.set_compute_dtype(model.cuda().eval(), cd), sd
+
+
+def test_greedy_decode_matches_full_recompute_oracle(M, specs):
+    """greedy_search with the KV cache (2-token steps) == the oracle's full-sequence recompute
+    (the reference's own greedy loop does not run under the installed HF)."""
+    from oracle import mvlt_oracle as O
+    model, sd = _tiny_caption(M, specs, F32)
+    image, ids, _, _ = synth_batch(3, 24, seed=77, vocab=3000)
+    out_ids, scores = model(image.cuda(), None, 1, 'unilm')
+    scfg = O.SwinCfg(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), drop_path_rate=0.2)
+    bcfg = O.BertCfg(vocab_size=3000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024)
+    with torch.no_grad():
+        ref = O.greedy_decode_recompute(sd, scfg, bcfg, image, max_len=10)
+    assert out_ids.shape == ref.shape and torch.equal(out_ids.cpu(), ref), (out_ids.cpu(), ref)
+    assert scores.numel() == 3 * (out_ids.shape[1] if out_ids.shape[1] == 10 else out_ids.shape[1] - 1)
+
+
+@pytest.mark.parametrize("cd", [F32, BF16])
+def test_cached_step_api_equals_full_forward(M, specs, cd):
+    """MVLBert.forward(past_key_values=..., use_cache=True) (model.py:82-108): a 2-token cached step
+    reproduces the hidden state of the full seq2seq forward at the same position."""
+    model, _ = _tiny_caption(M, specs, cd)
+    mv = model.MVLBert
+    image, ids, _, _ = synth_batch(2, 6, seed=5, vocab=3000)
+    ids = ids.cuda()
+    with torch.no_grad():
+        feat = model.conv(image.cuda())
+        mask = torch.full((2, 1), 103, device="cuda")
+        out0, _ = mv(mask, None, feat, None, use_cache=True, seq2seq_mask=True)
+        pkv = tuple((k[:, :, :-1], v[:, :, :-1]) for k, v in out0.past_key_values)      # drop the MASK slot
+        assert pkv[0][0].shape == (2, 4, 51, 64)
+        for t in range(3):
+            new = torch.stack([ids[:, t], mask[:, 0]], 1)
+            out, _ = mv(new, None, feat, None, past_key_values=pkv, use_cache=True, seq2seq_mask=True)
+            full, _ = mv(torch.cat([ids[:, :t + 1], mask], 1), None, feat, None, seq2seq_mask=True)
+            assert rel_err(out.last_hidden_state[:, -1].float().cpu(), full[0][:, -1].float().cpu()) < (1e-4 if cd == F32 else 3e-2)
+            pkv = tuple((k[:, :, :-1], v[:, :, :-1]) for k, v in out.past_key_values)
