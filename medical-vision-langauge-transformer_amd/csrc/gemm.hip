@@ -11,6 +11,8 @@
 // The MFMA is issued as (B-fragment, A-fragment) so each lane owns 4
 // consecutive n of one output row -> 8/16-byte epilogue loads and stores.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -180,7 +182,7 @@ MVLT_DEV typename Mma<T>::Frag tile_frag(const T* lds, int row0, int kb) {
 }
 
 template <typename T, int BM, int BN, bool AK, bool BK_>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmDev p) {
+__global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     using GA = TileGeom<T, BM, AK>;
     using GB = TileGeom<T, BN, BK_>;
     using Vec = typename TypeInfo<T>::Vec;
@@ -188,7 +190,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev p) {
     __shared__ __attribute__((aligned(16))) T sA[GA::ELEMS];
     __shared__ __attribute__((aligned(16))) T sB[GB::ELEMS];
 
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
+    // L2), so give every XCD one contiguous chunk of the tile grid -> neighbouring tiles (same
+    // A rows / B columns) hit the same L2.  Bijective for any grid size; speed only.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, nwg = gx * gridDim.y;
+        const int orig = by * gx + bx;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        by = t / gx; bx = t - by * gx;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int ks = blockIdx.z * p.k_per_split;
     const int ke = min(p.K, ks + p.k_per_split);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -212,20 +225,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev p) {
     FastLoader<T, BN, BK_> lb;
     la.init(A, p.lda, m0, p.M, ks);
     lb.init(B, p.ldb, n0, p.N, ks);
-    auto fetch = [&](int kt) {
-        if (kt < nfast) { la.load(ra); lb.load(rb); }
-        else {
-            const int k0 = ks + kt * GA::BKE;
-            tile_load<T, BM, AK>(ra, A, p.lda, m0, p.M, k0, ke, p.a_vec);
-            tile_load<T, BN, BK_>(rb, B, p.ldb, n0, p.N, k0, ke, p.b_vec);
-        }
-    };
-    if (nkt > 0) fetch(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        tile_store<T, BM, AK>(ra, sA);
-        tile_store<T, BN, BK_>(rb, sB);
-        __syncthreads();
-        if (kt + 1 < nkt) fetch(kt + 1);
+    auto compute_tile = [&]() {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             typename Mma<T>::Frag fa[FM], fb[FN];
@@ -238,6 +238,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
         }
+    };
+    // ---- hot loop: full k-tiles only, no predication, nothing but loads / ds_write / ds_read / MFMA
+    if (nfast > 0) { la.load(ra); lb.load(rb); }
+    for (int kt = 0; kt < nfast; ++kt) {
+        tile_store<T, BM, AK>(ra, sA);
+        tile_store<T, BN, BK_>(rb, sB);
+        __syncthreads();
+        if (kt + 1 < nfast) { la.load(ra); lb.load(rb); }
+        compute_tile();
+        __syncthreads();
+    }
+    // ---- K-tail (at most one tile when the operands are vector-aligned), generic predicated loads
+    for (int kt = nfast; kt < nkt; ++kt) {
+        const int k0 = ks + kt * GA::BKE;
+        tile_load<T, BM, AK>(ra, A, p.lda, m0, p.M, k0, ke, p.a_vec);
+        tile_load<T, BN, BK_>(rb, B, p.ldb, n0, p.N, k0, ke, p.b_vec);
+        tile_store<T, BM, AK>(ra, sA);
+        tile_store<T, BN, BK_>(rb, sB);
+        __syncthreads();
+        compute_tile();
         __syncthreads();
     }
 
@@ -298,6 +318,11 @@ Plan choose_plan(const MvltGemm* p) {
     long tiles128 = (long)ceil_div(p->M, 128) * ceil_div(p->N, pl.bn);
     pl.bm = (tiles128 >= 384 || p->M > 64 * 1024) ? 128 : 64;
     if (pl.bn == 64) pl.bm = 64;
+    if (const char* ov = getenv("MVLT_TILE")) {          // experiments: MVLT_TILE=bm,bn
+        int a = 0, b = 0;
+        if (sscanf(ov, "%d,%d", &a, &b) == 2 && (a == 128 || a == 64) && (b == 128 || b == 96 || b == 64) &&
+            !(a == 128 && b == 64)) { pl.bm = a; pl.bn = b; }
+    }
     long tiles = (long)ceil_div(p->M, pl.bm) * ceil_div(p->N, pl.bn);
     int split = p->split_k;
     if (split == 0) {
