@@ -74,6 +74,8 @@ typedef struct MvltGemm {
     const int32_t* rowmap;
     float dropout_p; uint64_t seed; uint32_t tag;
     int split_k; void* workspace; size_t workspace_bytes;
+    float* a_colsum;                 /* optional (a_kmajor only): a_colsum[m] = sum_k A[k*lda+m], i.e. the bias
+                                        gradient colsum(dY) fused into the wgrad GEMM dW = dY^T X */
 } MvltGemm;
 int mvlt_gemm(const MvltGemm* p, void* stream);
 size_t mvlt_gemm_workspace_bytes(const MvltGemm* p);

@@ -104,7 +104,8 @@ class EncoderOutput(tuple):
 class _EncFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, token, image_feature, mod, text_idx, mask_ids, image_mask, seq2seq, save):
-        hidden, pooled, saved = mod._forward(image_feature, text_idx, mask_ids, image_mask, seq2seq, save)
+        with ops.pin_stream():
+            hidden, pooled, saved = mod._forward(image_feature, text_idx, mask_ids, image_mask, seq2seq, save)
         ctx.mod, ctx.saved = mod, saved
         ctx.set_materialize_grads(False)     # unused pooled output -> None, so the pooler gets no gradient
         if pooled is None:
@@ -114,7 +115,8 @@ class _EncFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dhidden, dpooled):
-        dimg = ctx.mod._backward(ctx.saved, dhidden, dpooled)
+        with ops.pin_stream():
+            dimg = ctx.mod._backward(ctx.saved, dhidden, dpooled)
         ctx.saved = None
         return None, dimg, None, None, None, None, None, None
 
@@ -239,8 +241,8 @@ class MVLBert(nn.Module):
             pd = self.pooler.dense
             dpre = ops.tanh_bwd(sv["pooled"], dpooled.contiguous())
             cls = sv["hidden"][:, 0]
-            ops.gemm(dpre, cls, a_kmajor=True, b_kmajor=True, out=g(pd.weight), out_f32=True)
-            ops.colsum(dpre, out=g(pd.bias))
+            ops.gemm(dpre, cls, a_kmajor=True, b_kmajor=True, out=g(pd.weight), out_f32=True,
+                     a_colsum=g(pd.bias))
             ops.gemm(dpre, ar.compute(pd.weight), b_kmajor=True, out=dx.view(B, Lq, H)[:, 0], accumulate=True)
             ar.mark(pd.weight, pd.bias)
         for i in range(len(self.encoder.layer) - 1, -1, -1):
@@ -251,21 +253,21 @@ class MVLBert(nn.Module):
             dy2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight), g(lo.LayerNorm.bias))
             dz2 = ops.rows_transform(dy2, dropout=(p_h, seed, 8 * i + 2)) if p_h > 0 else dy2
             dh = ops.gemm(dz2, ar.compute(lo.dense.weight), b_kmajor=True, mul_gelu_grad=h)
-            ops.gemm(dz2, a, a_kmajor=True, b_kmajor=True, out=g(lo.dense.weight), out_f32=True)
-            ops.colsum(dz2, out=g(lo.dense.bias))
+            ops.gemm(dz2, a, a_kmajor=True, b_kmajor=True, out=g(lo.dense.weight), out_f32=True,
+                     a_colsum=g(lo.dense.bias))
             dx1 = ops.gemm(dh, ar.compute(li.dense.weight), b_kmajor=True, residual=dy2)
-            ops.gemm(dh, x1, a_kmajor=True, b_kmajor=True, out=g(li.dense.weight), out_f32=True)
-            ops.colsum(dh, out=g(li.dense.bias))
+            ops.gemm(dh, x1, a_kmajor=True, b_kmajor=True, out=g(li.dense.weight), out_f32=True,
+                     a_colsum=g(li.dense.bias))
             dy1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight), g(so.LayerNorm.bias))
             dz1 = ops.rows_transform(dy1, dropout=(p_h, seed, 8 * i + 1)) if p_h > 0 else dy1
             dctx = ops.gemm(dz1, ar.compute(so.dense.weight), b_kmajor=True)
-            ops.gemm(dz1, ctx, a_kmajor=True, b_kmajor=True, out=g(so.dense.weight), out_f32=True)
-            ops.colsum(dz1, out=g(so.dense.bias))
+            ops.gemm(dz1, ctx, a_kmajor=True, b_kmajor=True, out=g(so.dense.weight), out_f32=True,
+                     a_colsum=g(so.dense.bias))
             dqkv = ops.attn_bwd(dctx, qkv, ctx, lse, sv["mode"], B, Lq, nH, H // nH, (H // nH) ** -0.5,
                                 dropout=(p_a, seed, 8 * i + 0), **sv["akw"])
             dx = ops.gemm(dqkv, ar.compute(sa.query.weight, 3 * H), b_kmajor=True, residual=dy1)
-            ops.gemm(dqkv, x, a_kmajor=True, b_kmajor=True, out=g(sa.query.weight, 3 * H), out_f32=True)
-            ops.colsum(dqkv, out=g(sa.query.bias, 3 * H))
+            ops.gemm(dqkv, x, a_kmajor=True, b_kmajor=True, out=g(sa.query.weight, 3 * H), out_f32=True,
+                     a_colsum=g(sa.query.bias, 3 * H))
             ar.mark(lo.LayerNorm.weight, lo.LayerNorm.bias, lo.dense.weight, lo.dense.bias, li.dense.weight,
                     li.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, so.dense.weight, so.dense.bias,
                     sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias)

@@ -26,6 +26,7 @@ struct GemmDev {
     uint32_t drop_thresh; float drop_scale; uint64_t seed; uint32_t tag;
     int split_k; int k_per_split; float* ws;
     int a_vec, b_vec, epi_vec;
+    float* a_colsum; float* ws_colsum;   // optional: column sums of a k-major A (bias gradient), fused
 };
 
 template <typename T>
@@ -225,6 +226,17 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     FastLoader<T, BN, BK_> lb;
     la.init(A, p.lda, m0, p.M, ks);
     lb.init(B, p.ldb, n0, p.N, ks);
+    // fused bias gradient: blocks of the first output-column tile also sum their A tile over k
+    float csum = 0.f;
+    const bool do_colsum = AK && p.a_colsum != nullptr && bx == 0 && threadIdx.x < BM;
+    auto colsum_tile = [&]() {
+        if (AK && do_colsum) {
+            float s0 = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < GA::BKE; ++k) s0 += to_f(sA[k * GA::LD + threadIdx.x]);
+            csum += s0;
+        }
+    };
     auto compute_tile = [&]() {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -246,6 +258,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
         tile_store<T, BN, BK_>(rb, sB);
         __syncthreads();
         if (kt + 1 < nfast) { la.load(ra); lb.load(rb); }
+        colsum_tile();
         compute_tile();
         __syncthreads();
     }
@@ -257,8 +270,16 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
         tile_store<T, BM, AK>(ra, sA);
         tile_store<T, BN, BK_>(rb, sB);
         __syncthreads();
+        colsum_tile();
         compute_tile();
         __syncthreads();
+    }
+    if (AK && do_colsum) {
+        const int m = m0 + threadIdx.x;
+        if (m < p.M) {
+            if (p.split_k > 1) p.ws_colsum[(long)blockIdx.z * p.M + m] = csum;
+            else p.a_colsum[m] = (p.epi & MVLT_EPI_ACCUM) ? p.a_colsum[m] + csum : csum;
+        }
     }
 
     // acc[i][j][r] <-> n = nb + 4*(lane>>4) + r, m = mb + (lane & 15)
@@ -294,6 +315,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDev p) {
             else for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += w[r];
         }
         epilogue4<T>(p, m, n, v);
+    }
+    if (p.a_colsum) {
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < p.M; m += gridDim.x * 256) {
+            float s0 = 0.f;
+            for (int z = 0; z < p.split_k; ++z) s0 += p.ws_colsum[(long)z * p.M + m];
+            p.a_colsum[m] = (p.epi & MVLT_EPI_ACCUM) ? p.a_colsum[m] + s0 : s0;
+        }
     }
 }
 
@@ -345,7 +373,7 @@ Plan choose_plan(const MvltGemm* p) {
 extern "C" size_t mvlt_gemm_workspace_bytes(const MvltGemm* p) {
     if (!p) return 0;
     Plan pl = choose_plan(p);
-    return pl.split > 1 ? (size_t)pl.split * p->M * p->N * sizeof(float) : 0;
+    return pl.split > 1 ? (size_t)pl.split * p->M * ((size_t)p->N + 1) * sizeof(float) : 0;
 }
 
 template <typename T>
@@ -369,11 +397,13 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     if (pl.split > 1) {
         // drop empty trailing splits
         d.split_k = ceil_div(p->K, kps);
-        size_t need = (size_t)d.split_k * p->M * p->N * sizeof(float);
+        size_t need = (size_t)d.split_k * p->M * ((size_t)p->N + 1) * sizeof(float);
         MVLT_CHECK(p->workspace && p->workspace_bytes >= need, MVLT_ERR_ARG);
         if (d.split_k == 1) d.k_per_split = ((p->K + bke - 1) / bke) * bke;
     }
     d.ws = reinterpret_cast<float*>(p->workspace);
+    d.a_colsum = p->a_colsum;
+    d.ws_colsum = d.ws ? d.ws + (size_t)d.split_k * p->M * p->N : nullptr;
     d.a_vec = (p->lda % E == 0) && aligned16(p->A);
     d.b_vec = (p->ldb % E == 0) && aligned16(p->B);
     const int epi = p->epilogue;
@@ -413,6 +443,7 @@ extern "C" int mvlt_gemm(const MvltGemm* p, void* stream) {
     if (e & MVLT_EPI_ROWMAP) MVLT_CHECK(p->rowmap, MVLT_ERR_ARG);
     if (e & MVLT_EPI_MUL_GELU_GRAD) MVLT_CHECK(p->aux, MVLT_ERR_ARG);
     if (e & MVLT_EPI_DROPOUT) MVLT_CHECK(p->dropout_p >= 0.f && p->dropout_p < 1.f, MVLT_ERR_ARG);
+    if (p->a_colsum) MVLT_CHECK(p->a_kmajor, MVLT_ERR_ARG);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p->dtype == MVLT_F32) return gemm_dispatch<float>(p, s);
     if (p->dtype == MVLT_BF16) return gemm_dispatch<bf16_t>(p, s);

@@ -188,14 +188,14 @@ class BertOnlyMLMHead(nn.Module):
         g = ar.grad_view
         dl = dlogits[:, :V]
         dt2 = ops.gemm(dl, ar.compute(pr.decoder.weight), b_kmajor=True)
-        ops.gemm(dl, t2, a_kmajor=True, b_kmajor=True, out=g(pr.decoder.weight), out_f32=True)
-        ops.colsum(dl, out=g(pr.decoder.bias))
+        ops.gemm(dl, t2, a_kmajor=True, b_kmajor=True, out=g(pr.decoder.weight), out_f32=True,
+                 a_colsum=g(pr.decoder.bias))
         ln = pr.transform.LayerNorm
         dt1 = ops.layernorm_bwd(dt2, t1, mean, rstd, ln.weight.data, g(ln.weight), g(ln.bias))
         dpre = ops.gelu_bwd(pre, dt1)
         dx = ops.gemm(dpre, ar.compute(pr.transform.dense.weight), b_kmajor=True)
-        ops.gemm(dpre, x, a_kmajor=True, b_kmajor=True, out=g(pr.transform.dense.weight), out_f32=True)
-        ops.colsum(dpre, out=g(pr.transform.dense.bias))
+        ops.gemm(dpre, x, a_kmajor=True, b_kmajor=True, out=g(pr.transform.dense.weight), out_f32=True,
+                 a_colsum=g(pr.transform.dense.bias))
         ar.mark(pr.decoder.weight, pr.decoder.bias, ln.weight, ln.bias, pr.transform.dense.weight, pr.transform.dense.bias)
         return dx
 
@@ -279,8 +279,8 @@ class _LinearCEFn(torch.autograd.Function):
         gs = dloss.reshape(1).to(torch.float32).contiguous()
         dl = ops.ce_bwd(logits, V, labels, lse, acc, grad_scale_dev=gs)[:, :V]
         dx = ops.gemm(dl, ar.compute(lin.weight), b_kmajor=True)
-        ops.gemm(dl, x, a_kmajor=True, b_kmajor=True, out=ar.grad_view(lin.weight), out_f32=True)
-        ops.colsum(dl, out=ar.grad_view(lin.bias))
+        ops.gemm(dl, x, a_kmajor=True, b_kmajor=True, out=ar.grad_view(lin.weight), out_f32=True,
+                 a_colsum=ar.grad_view(lin.bias))
         ar.mark(lin.weight, lin.bias)
         ctx.saved = None
         return None, dx, None, None, None
@@ -307,8 +307,8 @@ class _LinearFn(torch.autograd.Function):
         lin = ctx.lin
         dl = dlogits.to(xd.dtype).contiguous()
         dxd = ops.gemm(dl, ar.compute(lin.weight), b_kmajor=True)
-        ops.gemm(dl, xd, a_kmajor=True, b_kmajor=True, out=ar.grad_view(lin.weight), out_f32=True)
-        ops.colsum(dl, out=ar.grad_view(lin.bias))
+        ops.gemm(dl, xd, a_kmajor=True, b_kmajor=True, out=ar.grad_view(lin.weight), out_f32=True,
+                 a_colsum=ar.grad_view(lin.bias))
         ar.mark(lin.weight, lin.bias)
         dx = ops.rows_transform(dxd, dropout=(p_drop, seed, 4001)) if p_drop > 0 else dxd
         ctx.saved = None
@@ -376,9 +376,23 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
         itm_loss = None
         if self.config.MLM_task:
             B, T, H = text_out.shape
-            x = text_out.reshape(B * T, H).contiguous()
             labels = caption_label.reshape(-1).to(torch.int64).contiguous()
-            mlm_loss = _MlmLossFn.apply(_token(head, dev), x, head, labels, torch.is_grad_enabled())
+            cap = getattr(self.config, "mlm_max_labels_per_sample", None)
+            if cap is not None and cap * B < B * T:
+                # Only labelled positions contribute to F.cross_entropy(ignore_index=-100) (model.py:410),
+                # so the MLM head (768x30522 decoder, 312 MB of f32 logits in the reference) is evaluated on
+                # a fixed-capacity gather of them: a stable sort puts labelled rows first, the padding rows
+                # carry label -100 and are ignored.  No host sync; more than `cap` labels per sample on
+                # average would drop rows, which turns the loss into NaN instead of a silently wrong value.
+                valid = labels >= 0
+                order = torch.argsort((~valid).to(torch.int8), stable=True)[: cap * B]
+                x = text_out.reshape(B * T, H)[order]
+                sel_labels = labels[order].contiguous()
+                mlm_loss = _MlmLossFn.apply(_token(head, dev), x.contiguous(), head, sel_labels, torch.is_grad_enabled())
+                mlm_loss = torch.where(valid.sum() > cap * B, torch.full_like(mlm_loss, float("nan")), mlm_loss)
+            else:
+                x = text_out.reshape(B * T, H).contiguous()
+                mlm_loss = _MlmLossFn.apply(_token(head, dev), x, head, labels, torch.is_grad_enabled())
         if self.config.ITM_task:
             itm_loss = _LinearCEFn.apply(_token(self.ITM_mlp, dev), pooled, self.ITM_mlp,
                                          image_text_label.reshape(-1).to(torch.int64).contiguous(),

@@ -15,8 +15,25 @@ _ws = {}
 GEMM_TIMER = None   # bench.py: callable(flops) -> (start_event, end_event) bracketing every GEMM launch
 
 
+_stream_cache = [None, None]
+
+
 def _stream():
+    # torch.cuda.current_stream() costs ~5 us; engines pin it for the duration of a pass (pin_stream)
+    if _stream_cache[0] is not None:
+        return _stream_cache[0]
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class pin_stream:
+    """Context manager: resolve torch's current stream once for a whole forward/backward pass."""
+
+    def __enter__(self):
+        self.prev = _stream_cache[0]
+        _stream_cache[0] = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def __exit__(self, *a):
+        _stream_cache[0] = self.prev
 
 
 def _p(t):
@@ -48,7 +65,7 @@ def workspace(name, nbytes, device):
 # ----------------------------------------------------------------------------- GEMM
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=None, gelu=False,
          save_pre=None, dropout=None, rowscale=None, residual=None, rowmap=None, mul_gelu_grad=None,
-         accumulate=False, split_k=0, ldc=None):
+         accumulate=False, split_k=0, ldc=None, a_colsum=None):
     """C = epilogue(A @ B); see MvltGemm.  A: [M,K] (or [K,M] if a_kmajor);
     B: [N,K] torch-Linear layout (or [K,N] if b_kmajor)."""
     _need_cuda(A, B)
@@ -105,6 +122,9 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
         epi |= L.EPI_ACCUM
     p.epilogue = epi
     p.split_k = split_k
+    if a_colsum is not None:
+        assert a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M
+        p.a_colsum = _p(a_colsum)
     lib = L.lib()
     need = lib.mvlt_gemm_workspace_bytes(C.byref(p))
     if need:

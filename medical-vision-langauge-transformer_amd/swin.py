@@ -106,13 +106,15 @@ class PatchEmbed(nn.Module):
 class _SwinFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, token, img, mod, fuse_gelu, save):
-        out, saved = mod._forward(img, fuse_gelu, save)
+        with ops.pin_stream():
+            out, saved = mod._forward(img, fuse_gelu, save)
         ctx.mod, ctx.saved = mod, saved
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        ctx.mod._backward(ctx.saved, dout.contiguous())
+        with ops.pin_stream():
+            ctx.mod._backward(ctx.saved, dout.contiguous())
         ctx.saved = None
         return None, None, None, None, None
 
@@ -225,7 +227,10 @@ class SwinTransformer(nn.Module):
         nblk = sum(len(l.blocks) for l in self.layers)
         dp = None
         if train and any(b.drop_path_prob > 0 for _, b in self._blocks()):
-            probs = torch.tensor([b.drop_path_prob for _, b in self._blocks() for _ in (0, 1)], device=img.device)
+            probs = self.__dict__.get("_dp_probs")
+            if probs is None or probs.device != img.device:
+                probs = torch.tensor([b.drop_path_prob for _, b in self._blocks() for _ in (0, 1)], device=img.device)
+                self.__dict__["_dp_probs"] = probs          # cached: a per-step H2D copy would stall the host
             keep = (torch.rand(2 * nblk, B, device=img.device) >= probs[:, None]).float()
             dp = (keep / (1.0 - probs[:, None])).contiguous()
             self.last_droppath = dp
@@ -307,8 +312,8 @@ class SwinTransformer(nn.Module):
         cols, x0, mean, rstd = saved["pe"]
         pe = self.patch_embed
         dx0 = ops.layernorm_bwd(dx, x0, mean, rstd, pe.norm.weight.data, g(pe.norm.weight), g(pe.norm.bias))
-        ops.gemm(dx0, cols, a_kmajor=True, b_kmajor=True, out=g(pe.proj.weight), out_f32=True)
-        ops.colsum(dx0, out=g(pe.proj.bias))
+        ops.gemm(dx0, cols, a_kmajor=True, b_kmajor=True, out=g(pe.proj.weight), out_f32=True,
+                 a_colsum=g(pe.proj.bias))
         ar.mark(pe.norm.weight, pe.norm.bias, pe.proj.weight, pe.proj.bias)
 
     def _block_bwd(self, ar, sv, dx2, B):
@@ -322,26 +327,26 @@ class SwinTransformer(nn.Module):
         # ---- MLP branch
         dy2 = ops.rows_transform(dx2, rowscale=(s2, Lt)) if s2 is not None else dx2
         dh = ops.gemm(dy2, ar.compute(mlp.fc2.weight), b_kmajor=True, mul_gelu_grad=h)
-        ops.gemm(dy2, a, a_kmajor=True, b_kmajor=True, out=g(mlp.fc2.weight), out_f32=True)
-        ops.colsum(dy2, out=g(mlp.fc2.bias))
+        ops.gemm(dy2, a, a_kmajor=True, b_kmajor=True, out=g(mlp.fc2.weight), out_f32=True,
+                 a_colsum=g(mlp.fc2.bias))
         dxn2 = ops.gemm(dh, ar.compute(mlp.fc1.weight), b_kmajor=True)
-        ops.gemm(dh, xn2, a_kmajor=True, b_kmajor=True, out=g(mlp.fc1.weight), out_f32=True)
-        ops.colsum(dh, out=g(mlp.fc1.bias))
+        ops.gemm(dh, xn2, a_kmajor=True, b_kmajor=True, out=g(mlp.fc1.weight), out_f32=True,
+                 a_colsum=g(mlp.fc1.bias))
         dx1 = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, blk.norm2.weight.data, g(blk.norm2.weight),
                                 g(blk.norm2.bias), dres=dx2)
         # ---- attention branch (window order)
         dyw = ops.rows_transform(dx1, rowmap=w2n, rowscale=(s1, Lt) if s1 is not None else None)
         dao = ops.gemm(dyw, ar.compute(at.proj.weight), b_kmajor=True)
-        ops.gemm(dyw, ao, a_kmajor=True, b_kmajor=True, out=g(at.proj.weight), out_f32=True)
-        ops.colsum(dyw, out=g(at.proj.bias))
+        ops.gemm(dyw, ao, a_kmajor=True, b_kmajor=True, out=g(at.proj.weight), out_f32=True,
+                 a_colsum=g(at.proj.bias))
         dtab = g(at.relative_position_bias_table)
         dtab.zero_()
         dqkv = ops.attn_bwd(dao, qkv, ao, lse, L.ATTN_SWIN, B * nW, ws * ws, nH, C // nH, at.scale,
                             dbias_table=dtab, bias_table=at.relative_position_bias_table.data, nW=nW, win_res=H,
                             shift=blk.shift_size)
         dxn1w = ops.gemm(dqkv, ar.compute(at.qkv.weight), b_kmajor=True)
-        ops.gemm(dqkv, xn1w, a_kmajor=True, b_kmajor=True, out=g(at.qkv.weight), out_f32=True)
-        ops.colsum(dqkv, out=g(at.qkv.bias))
+        ops.gemm(dqkv, xn1w, a_kmajor=True, b_kmajor=True, out=g(at.qkv.weight), out_f32=True,
+                 a_colsum=g(at.qkv.bias))
         dx0 = ops.layernorm_bwd(dxn1w, x, mean1, rstd1, blk.norm1.weight.data, g(blk.norm1.weight),
                                 g(blk.norm1.bias), dy_rowmap=n2w, dres=dx1)
         ar.mark(mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, blk.norm1.weight, blk.norm1.bias,

@@ -21,3 +21,17 @@ for i in range(steps):
 torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
 print(f"B={B} ms/step={dt*1e3:.2f} pairs/s={B/dt:.1f} loss={l.item():.4f} mem={torch.cuda.max_memory_allocated()/2**30:.2f}GiB", flush=True)
+# host enqueue time: run steps without waiting for the GPU
+torch.cuda.synchronize()
+t0 = time.time()
+for i in range(steps):
+    l = step(batch)
+t_host = (time.time() - t0) / steps
+torch.cuda.synchronize()
+print(f"host enqueue ms/step={t_host*1e3:.2f}", flush=True)
+if os.environ.get("CPROF"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for i in range(3): l = step(batch)
+    pr.disable(); torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(18)

@@ -68,8 +68,10 @@ def test_gemm_splitk_wgrad_shape(ops, dt, split):
     dY = rnd((Mtok, Nout), dt, 3, 0.1)
     X = rnd((Mtok, Kin), dt, 4, 0.1)
     ref = dY.float().t() @ X.float()
-    out = ops.gemm(dY, X, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=split)
+    cs = torch.empty(Nout, device="cuda")
+    out = ops.gemm(dY, X, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=split, a_colsum=cs)
     assert out.dtype == torch.float32 and rel(out, ref) < (1e-5 if dt == torch.float32 else 2e-3)
+    assert rel(cs, dY.float().sum(0)) < 1e-5        # fused bias gradient (column sums of dY)
     out2 = ops.gemm(dY, X, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=split, out=out.clone(), accumulate=True)
     assert rel(out2, 2 * ref) < (1e-5 if dt == torch.float32 else 2e-3)
 
