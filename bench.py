@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--mlm-all-rows", action="store_true")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         cpu_baseline_worker()
@@ -133,6 +134,10 @@ def main():
     torch.manual_seed(1234)                         # same random-init replica on every rank
     cfg = M.MVLBertPretrainConfig()
     cfg.ITM_task = True                             # BASELINE config: Pretrain (MLM+ITM)
+    # the reference dataset masks at most 10 tokens per caption (run_pretrain_rgc_roco_medicat.py:188):
+    # the MLM head is evaluated on those rows only (loss and gradients identical to the all-rows head;
+    # --mlm-all-rows runs the reference-shaped head).  FLOP accounting stays reference-equivalent.
+    cfg.mlm_max_labels_per_sample = None if args.mlm_all_rows else 10
     model = M.MVLBertForPretraining(cfg).cuda().train()
     M.manual_seed(4321 + rank)                      # dropout stream differs per rank
     seed_coin_flip(5678)                            # seq2seq/bidir flip identical on all ranks

@@ -265,24 +265,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev p) {
     const T* dout = reinterpret_cast<const T*>(p.dout);
     const bool drop = p.drop_thresh != 0;
     if (SWIN) { for (int i = threadIdx.x; i < 176; i += 256) s.tblg[i] = 0.f; }
+    // Swin: every window maps (q,k) to the same lane/register, so dBias[relidx(q,k)] += dS[q,k] is summed
+    // in registers over all windows this workgroup walks and scattered to the LDS table once at the end.
+    f32x4 dbacc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) dbacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
         __syncthreads();
         stage_images<T, HD>(p, s, seq, h, true);
         stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, true);
-        // delta_q = sum_d dO[q,d] * O[q,d];  lse_q
-        for (int q = threadIdx.x; q < p.rows_alloc; q += 256) {
-            float dl = 0.f, ls = 0.f;
-            if (q < p.L) {
-                const T* o = outp + ((long)seq * p.L + q) * C + h * HD;
-                const T* d = dout + ((long)seq * p.L + q) * C + h * HD;
-                for (int i = 0; i < HD; i += 4) {
-                    const f32x4 a = load4f(o + i), b = load4f(d + i);
-                    dl += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
-                }
-                ls = p.lse[((long)seq * p.nH + h) * p.L + q];
-            }
-            s.delta[q] = dl; s.lse[q] = ls;
-        }
+        // lse_q (delta_q = rowsum(P .* dP) is produced by phase A in registers: no O / dO pre-pass)
+        for (int q = threadIdx.x; q < p.rows_alloc; q += 256)
+            s.lse[q] = q < p.L ? p.lse[((long)seq * p.nH + h) * p.L + q] : 0.f;
         __syncthreads();
         int wy = 0, wx = 0;
         if (SWIN) { const int w = seq % p.nW, nwx = p.res / 7; wy = w / nwx; wx = w % nwx; }
@@ -309,24 +303,37 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev p) {
                 }
             }
             const int q = 16 * tq + c15;
-            const float lse_q = s.lse[q], delta_q = s.delta[q];
+            const float lse_q = s.lse[q];
+            // pass 1: probabilities and (dropout-scaled) dP in place; delta_q = sum_k P*dP
+            float dl = 0.f;
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 16 * t + 4 * g + j;
-                    float ds = 0.f;
+                    float pr = 0.f, dpv = 0.f;
                     if (t < p.NT && k < p.L && q < p.L) {
                         const float lg = sc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx);
-                        const float pr = __expf(lg - lse_q);
-                        float dpv = dp[t][j];
+                        pr = __expf(lg - lse_q);
+                        dpv = dp[t][j];
                         if (drop) {
                             const uint32_t idx = (uint32_t)((((long)seq * p.nH + h) * p.L + q) * p.L + k);
                             dpv = rng_keep(p.seed, p.tag, idx, p.drop_thresh) ? dpv * p.drop_scale : 0.0f;
                         }
-                        ds = pr * (dpv - delta_q);
-                        if (SWIN) atomicAdd(&s.tblg[rel_index(q, k)], ds);
+                        dl += pr * dpv;
                     }
+                    sc[t][j] = pr; dp[t][j] = dpv;
+                }
+            dl += __shfl_xor(dl, 16, 64);
+            dl += __shfl_xor(dl, 32, 64);
+            if (g == 0) s.delta[q] = dl;
+            // pass 2: dS = P (dP - delta); bias gradient accumulates in registers across windows
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float ds = sc[t][j] * (dp[t][j] - dl);
+                    if (SWIN) dbacc[t][j] += ds;
                     sc[t][j] = ds * p.scale;
                 }
             f32x4 dq[TD];
@@ -347,6 +354,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev p) {
             }
         }
 
+        __syncthreads();      // delta of every query tile is in LDS
         // ---- phase B: queries on accumulator rows, one key tile per wave -> dK, dV
         for (int tk = wave; tk < p.NT; tk += 4) {
             f32x4 sc[KT], dp[KT];
@@ -416,6 +424,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev p) {
         }
     }
     if (SWIN && p.dbias) {
+        // Swin has NT == 4 == number of waves: wave w owns query tile w in every window
+        const int tqw = wave;
+        if (tqw < p.NT) {
+            const int q = 16 * tqw + c15;
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 16 * t + 4 * g + j;
+                    if (q < p.L && k < p.L) atomicAdd(&s.tblg[rel_index(q, k)], dbacc[t][j]);
+                }
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < 169; i += 256) atomicAdd(&p.dbias[i * p.nH + h], s.tblg[i]);
     }
@@ -427,7 +447,9 @@ int launch(const AttnDev& d, bool bwd, int dtype, hipStream_t s) {
     if (sh > 160 * 1024) return MVLT_ERR_UNSUPPORTED;
     int gx = d.nseq;
     if (SWIN) {   // several windows per workgroup: the LDS bias-gradient table is flushed once
-        const int target = 2048 / (d.nH > 0 ? d.nH : 1);
+        // backward: ~512 workgroups in total, each walking several windows of one head, so the LDS
+        // bias-gradient table is flushed with 169 global atomics per workgroup instead of per window
+        const int target = (bwd ? 512 : 2048) / (d.nH > 0 ? d.nH : 1);
         if (gx > target) gx = target < 1 ? 1 : target;
     }
     dim3 grid(gx, d.nH);

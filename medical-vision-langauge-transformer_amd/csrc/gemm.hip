@@ -357,8 +357,8 @@ Plan choose_plan(const MvltGemm* p) {
         split = 1;
         const int bke = (p->dtype == MVLT_BF16) ? 64 : 32;
         const int nkt = ceil_div(p->K, bke);
-        if (tiles < 512 && nkt >= 16) {
-            split = (int)((1024 + tiles - 1) / tiles);
+        if (tiles < 200 && nkt >= 16) {          // small outputs with a long reduction only (wgrads)
+            split = (int)((768 + tiles - 1) / tiles);
             if (split > nkt / 8) split = nkt / 8;
             if (split > 256) split = 256;
             if (split < 1) split = 1;

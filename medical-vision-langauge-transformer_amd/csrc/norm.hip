@@ -172,21 +172,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnDev p) {
     }
 }
 
-// partial rows -> dgamma/dbeta: block = 64 columns x 4 row groups (one wave each), coalesced 256-B row reads
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* part_g, const float* part_b, int nparts, int C,
-                                                              float* dgamma, float* dbeta, int accumulate) {
-    __shared__ float red[2][4][64];
+// partial rows -> dgamma/dbeta: block = 64 columns x 16 row groups (one wave each), coalesced 256-B row reads
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* part_g, const float* part_b, int nparts, int C,
+                                                               float* dgamma, float* dbeta, int accumulate) {
+    __shared__ float red[2][16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float g = 0.f, b = 0.f;
     if (c < C) {
-        for (int i = w; i < nparts; i += 4) { g += part_g[(long)i * C + c]; b += part_b[(long)i * C + c]; }
+        for (int i = w; i < nparts; i += 16) { g += part_g[(long)i * C + c]; b += part_b[(long)i * C + c]; }
     }
     red[0][w][lane] = g; red[1][w][lane] = b;
     __syncthreads();
     if (w == 0 && c < C) {
-        g = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-        b = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+        g = 0.f; b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { g += red[0][i][lane]; b += red[1][i][lane]; }
         if (accumulate) { g += dgamma[c]; b += dbeta[c]; }
         dgamma[c] = g; dbeta[c] = b;
     }
@@ -272,7 +273,7 @@ extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
     int lpr = p->C <= 64 ? 16 : (p->C <= 128 ? 32 : 64);
     int blocks = ceil_div(p->rows, 4 * (64 / lpr));
     if (blocks > LN_BWD_PARTS) blocks = LN_BWD_PARTS;
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(p->C, 64)), dim3(256), 0, s, d.part_g, d.part_b,
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(p->C, 64)), dim3(1024), 0, s, d.part_g, d.part_b,
                        blocks, p->C, p->dgamma, p->dbeta, p->accumulate);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;

@@ -7,6 +7,7 @@ from mvlt_amd.train import PretrainStep, synthetic_batch
 
 B = int(os.environ.get("B", 32)); steps = int(os.environ.get("STEPS", 5)); warm = int(os.environ.get("WARM", 3))
 cfg = M.MVLBertPretrainConfig(); cfg.ITM_task = True
+cfg.mlm_max_labels_per_sample = int(os.environ.get('MLM_CAP', 10)) or None   # dataset masks <=10 tokens/sample
 model = M.MVLBertForPretraining(cfg).cuda().train()
 M.manual_seed(1)
 step = PretrainStep(model)
