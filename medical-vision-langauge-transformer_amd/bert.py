@@ -253,21 +253,21 @@ class MVLBert(nn.Module):
             dy2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight), g(lo.LayerNorm.bias))
             dz2 = ops.rows_transform(dy2, dropout=(p_h, seed, 8 * i + 2)) if p_h > 0 else dy2
             dh = ops.gemm(dz2, ar.compute(lo.dense.weight), b_kmajor=True, mul_gelu_grad=h)
-            ops.gemm(dz2, a, a_kmajor=True, b_kmajor=True, out=g(lo.dense.weight), out_f32=True,
-                     a_colsum=g(lo.dense.bias))
             dx1 = ops.gemm(dh, ar.compute(li.dense.weight), b_kmajor=True, residual=dy2)
-            ops.gemm(dh, x1, a_kmajor=True, b_kmajor=True, out=g(li.dense.weight), out_f32=True,
-                     a_colsum=g(li.dense.bias))
             dy1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight), g(so.LayerNorm.bias))
             dz1 = ops.rows_transform(dy1, dropout=(p_h, seed, 8 * i + 1)) if p_h > 0 else dy1
             dctx = ops.gemm(dz1, ar.compute(so.dense.weight), b_kmajor=True)
-            ops.gemm(dz1, ctx, a_kmajor=True, b_kmajor=True, out=g(so.dense.weight), out_f32=True,
-                     a_colsum=g(so.dense.bias))
             dqkv = ops.attn_bwd(dctx, qkv, ctx, lse, sv["mode"], B, Lq, nH, H // nH, (H // nH) ** -0.5,
                                 dropout=(p_a, seed, 8 * i + 0), **sv["akw"])
-            dx = ops.gemm(dqkv, ar.compute(sa.query.weight, 3 * H), b_kmajor=True, residual=dy1)
-            ops.gemm(dqkv, x, a_kmajor=True, b_kmajor=True, out=g(sa.query.weight, 3 * H), out_f32=True,
-                     a_colsum=g(sa.query.bias, 3 * H))
+            dx_in = ops.gemm(dqkv, ar.compute(sa.query.weight, 3 * H), b_kmajor=True, residual=dy1)
+            # weight / bias gradients on the side stream (off the critical path)
+            with ops.on_side(dx.device, dz2, a, dh, x1, dz1, ctx, dqkv, x):
+                ops.gemm(dz2, a, a_kmajor=True, b_kmajor=True, out=g(lo.dense.weight), out_f32=True, a_colsum=g(lo.dense.bias))
+                ops.gemm(dh, x1, a_kmajor=True, b_kmajor=True, out=g(li.dense.weight), out_f32=True, a_colsum=g(li.dense.bias))
+                ops.gemm(dz1, ctx, a_kmajor=True, b_kmajor=True, out=g(so.dense.weight), out_f32=True, a_colsum=g(so.dense.bias))
+                ops.gemm(dqkv, x, a_kmajor=True, b_kmajor=True, out=g(sa.query.weight, 3 * H), out_f32=True,
+                         a_colsum=g(sa.query.bias, 3 * H))
+            dx = dx_in
             ar.mark(lo.LayerNorm.weight, lo.LayerNorm.bias, lo.dense.weight, lo.dense.bias, li.dense.weight,
                     li.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, so.dense.weight, so.dense.bias,
                     sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias)
@@ -276,5 +276,6 @@ class MVLBert(nn.Module):
         g(we).zero_(); g(pe).zero_(); g(te).zero_()
         dimg = ops.embed_bwd(dx.view(B, Lq, H), sv["text_idx"], sv["n_img"], we.data, pe.data, te.data,
                              cfg.cls_token_id, cfg.sep_token_id, g(we), g(pe), g(te))
+        ops.join_side(dx.device)
         ar.mark(we, pe, te)
         return dimg

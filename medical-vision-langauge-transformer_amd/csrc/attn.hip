@@ -72,13 +72,19 @@ template <int KT> MVLT_DEV bf16x8 frag_acc(const f32x4 (&a)[KT], int kb, bf16_t)
 }
 template <int KT> MVLT_DEV f32x4 frag_acc(const f32x4 (&a)[KT], int kb, float) { return a[kb]; }
 
+// v / 7 for 0 <= v < 64 without an integer division (7 * 37 = 259 ~ 2^8): exact on that range
+MVLT_DEV int div7(int v) { return (v * 37) >> 8; }
 MVLT_DEV int swin_region(int tok, int wy, int wx, int res, int shift) {
-    const int h = wy * 7 + tok / 7, w = wx * 7 + tok % 7;
+    const int ty = div7(tok), tx = tok - 7 * ty;
+    const int h = wy * 7 + ty, w = wx * 7 + tx;
     const int bh = h < res - 7 ? 0 : (h < res - shift ? 1 : 2);
     const int bw = w < res - 7 ? 0 : (w < res - shift ? 1 : 2);
     return bh * 3 + bw;
 }
-MVLT_DEV int rel_index(int q, int k) { return (q / 7 - k / 7 + 6) * 13 + (q % 7 - k % 7 + 6); }
+MVLT_DEV int rel_index(int q, int k) {
+    const int qy = div7(q), ky = div7(k);
+    return (qy - ky + 6) * 13 + ((q - 7 * qy) - (k - 7 * ky) + 6);
+}
 
 // LDS carve-up (all float-aligned): images Q,K,V,(dO) then small arrays
 template <typename T> struct Smem {
@@ -158,7 +164,7 @@ MVLT_DEV void stage_small(const AttnDev& p, float* kmask, float* tbl, float* tbl
 
 // ------------------------------------------------------------------ forward
 template <typename T, int HD, int KT, bool SWIN>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev p) {
+__global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const AttnDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using M = Mma<T>;
     constexpr int KBD = HD / M::KB;                     // k-blocks over the head dim
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev p) {
 
 // ------------------------------------------------------------------ backward
 template <typename T, int HD, int KT, bool SWIN>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using M = Mma<T>;
     constexpr int KBD = HD / M::KB;

@@ -90,12 +90,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnDev p) {
 }
 
 template <typename T, int LPR, int NV, bool MERGE>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnDev p) {
+__global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnDev p) {
     constexpr int RPW = 64 / LPR;
     extern __shared__ __attribute__((aligned(16))) float red[];   // [2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwave = blockDim.x >> 6;
     const int sl = lane % LPR;
-    for (int c = threadIdx.x; c < 2 * p.C; c += 256) red[c] = 0.f;
+    for (int c = threadIdx.x; c < 2 * p.C; c += blockDim.x) red[c] = 0.f;
     __syncthreads();
     const T* x = reinterpret_cast<const T*>(p.x);
     const T* dy = reinterpret_cast<const T*>(p.dy);
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnDev p) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) { ag[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[j] = ag[j]; }
     const float invC = 1.0f / p.C;
-    for (int r0 = (blockIdx.x * 4 + wave) * RPW; r0 < p.rows; r0 += gridDim.x * 4 * RPW) {
+    for (int r0 = (blockIdx.x * nwave + wave) * RPW; r0 < p.rows; r0 += gridDim.x * nwave * RPW) {
         const int r = r0 + lane / LPR;
         const bool rv = r < p.rows;
         const float mean = rv ? p.mean[r] : 0.f, rstd = rv ? p.rstd[r] : 0.f;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnDev p) {
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < p.C; c += 256) {
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
         p.part_g[(long)blockIdx.x * p.C + c] = red[c];
         p.part_b[(long)blockIdx.x * p.C + c] = red[p.C + c];
     }
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* part
 }
 
 constexpr int LN_BWD_PARTS = 256;
+constexpr int LN_BWD_WAVES = 16;     // 1024-thread blocks: 16 waves per CU hide the load latency, still 256 partial rows
 
 template <typename T, int LPR, int NV>
 void launch_fwd(const LnDev& d, bool merge, hipStream_t s) {
@@ -204,13 +206,13 @@ void launch_fwd(const LnDev& d, bool merge, hipStream_t s) {
 }
 template <typename T, int LPR, int NV>
 void launch_bwd(LnDev d, bool merge, hipStream_t s) {
-    const int rpb = 4 * (64 / LPR);
+    const int rpb = LN_BWD_WAVES * (64 / LPR);
     int blocks = ceil_div(d.rows, rpb);
     if (blocks > LN_BWD_PARTS) blocks = LN_BWD_PARTS;
     d.nparts = blocks;
     const size_t sh = 2 * (size_t)d.C * sizeof(float);
-    if (merge) hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, true>), dim3(blocks), dim3(256), sh, s, d);
-    else hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, false>), dim3(blocks), dim3(256), sh, s, d);
+    if (merge) hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, true>), dim3(blocks), dim3(64 * LN_BWD_WAVES), sh, s, d);
+    else hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, false>), dim3(blocks), dim3(64 * LN_BWD_WAVES), sh, s, d);
 }
 
 template <typename T, bool BWD>
@@ -271,7 +273,7 @@ extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
     if (rc != MVLT_OK) return rc;
     // the number of partial rows written == number of blocks launched above
     int lpr = p->C <= 64 ? 16 : (p->C <= 128 ? 32 : 64);
-    int blocks = ceil_div(p->rows, 4 * (64 / lpr));
+    int blocks = ceil_div(p->rows, LN_BWD_WAVES * (64 / lpr));
     if (blocks > LN_BWD_PARTS) blocks = LN_BWD_PARTS;
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(p->C, 64)), dim3(1024), 0, s, d.part_g, d.part_b,
                        blocks, p->C, p->dgamma, p->dbeta, p->accumulate);

@@ -25,15 +25,54 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_side = {}
+
+
+def side_stream(device):
+    """One extra HIP stream per device for work that is off the critical path (weight gradients)."""
+    st = _side.get(device.index)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side[device.index] = st
+    return st
+
+
+class on_side:
+    """Launch the enclosed kernels on the side stream once everything queued on the main stream so
+    far is done; tensors read there must be passed so the caching allocator keeps them alive."""
+
+    def __init__(self, device, *tensors):
+        self.dev, self.tensors = device, tensors
+
+    def __enter__(self):
+        side = side_stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(side)
+        self.prev = (_stream_cache[0], _stream_cache[1])
+        _stream_cache[0], _stream_cache[1] = C.c_void_p(side.cuda_stream), "side"
+
+    def __exit__(self, *a):
+        _stream_cache[0], _stream_cache[1] = self.prev
+
+
+def join_side(device):
+    """Main stream waits for the side stream (end of a backward pass / before communication)."""
+    st = _side.get(device.index)
+    if st is not None:
+        torch.cuda.current_stream().wait_stream(st)
+
+
 class pin_stream:
     """Context manager: resolve torch's current stream once for a whole forward/backward pass."""
 
     def __enter__(self):
-        self.prev = _stream_cache[0]
-        _stream_cache[0] = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.prev = (_stream_cache[0], _stream_cache[1])
+        _stream_cache[0], _stream_cache[1] = C.c_void_p(torch.cuda.current_stream().cuda_stream), None
 
     def __exit__(self, *a):
-        _stream_cache[0] = self.prev
+        _stream_cache[0], _stream_cache[1] = self.prev
 
 
 def _p(t):
@@ -54,10 +93,14 @@ def _need_cuda(*ts):
 
 
 def workspace(name, nbytes, device):
-    key = (name, device.index)
+    key = (name, device.index, _stream_cache[1])      # the side stream gets its own scratch buffers
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and _stream_cache[1] == "side":
+            buf.record_stream(side_stream(device))     # a queued side-stream kernel may still be using it
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if _stream_cache[1] == "side":
+            buf.record_stream(side_stream(device))
         _ws[key] = buf
     return buf
 

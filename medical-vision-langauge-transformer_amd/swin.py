@@ -314,6 +314,7 @@ class SwinTransformer(nn.Module):
         dx0 = ops.layernorm_bwd(dx, x0, mean, rstd, pe.norm.weight.data, g(pe.norm.weight), g(pe.norm.bias))
         ops.gemm(dx0, cols, a_kmajor=True, b_kmajor=True, out=g(pe.proj.weight), out_f32=True,
                  a_colsum=g(pe.proj.bias))
+        ops.join_side(dx0.device)                # all weight gradients are complete before anyone reads them
         ar.mark(pe.norm.weight, pe.norm.bias, pe.proj.weight, pe.proj.bias)
 
     def _block_bwd(self, ar, sv, dx2, B):
@@ -324,31 +325,28 @@ class SwinTransformer(nn.Module):
         nW = (H // ws) * (W // ws)
         w2n, n2w = batched_window_maps(B, H, W, ws, blk.shift_size, dx2.device)
         at, mlp = blk.attn, blk.mlp
-        # ---- MLP branch
+        # ---- critical path on the main stream: dgrads, LN backward, attention backward
         dy2 = ops.rows_transform(dx2, rowscale=(s2, Lt)) if s2 is not None else dx2
         dh = ops.gemm(dy2, ar.compute(mlp.fc2.weight), b_kmajor=True, mul_gelu_grad=h)
-        ops.gemm(dy2, a, a_kmajor=True, b_kmajor=True, out=g(mlp.fc2.weight), out_f32=True,
-                 a_colsum=g(mlp.fc2.bias))
         dxn2 = ops.gemm(dh, ar.compute(mlp.fc1.weight), b_kmajor=True)
-        ops.gemm(dh, xn2, a_kmajor=True, b_kmajor=True, out=g(mlp.fc1.weight), out_f32=True,
-                 a_colsum=g(mlp.fc1.bias))
         dx1 = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, blk.norm2.weight.data, g(blk.norm2.weight),
                                 g(blk.norm2.bias), dres=dx2)
-        # ---- attention branch (window order)
         dyw = ops.rows_transform(dx1, rowmap=w2n, rowscale=(s1, Lt) if s1 is not None else None)
         dao = ops.gemm(dyw, ar.compute(at.proj.weight), b_kmajor=True)
-        ops.gemm(dyw, ao, a_kmajor=True, b_kmajor=True, out=g(at.proj.weight), out_f32=True,
-                 a_colsum=g(at.proj.bias))
         dtab = g(at.relative_position_bias_table)
         dtab.zero_()
         dqkv = ops.attn_bwd(dao, qkv, ao, lse, L.ATTN_SWIN, B * nW, ws * ws, nH, C // nH, at.scale,
                             dbias_table=dtab, bias_table=at.relative_position_bias_table.data, nW=nW, win_res=H,
                             shift=blk.shift_size)
         dxn1w = ops.gemm(dqkv, ar.compute(at.qkv.weight), b_kmajor=True)
-        ops.gemm(dqkv, xn1w, a_kmajor=True, b_kmajor=True, out=g(at.qkv.weight), out_f32=True,
-                 a_colsum=g(at.qkv.bias))
         dx0 = ops.layernorm_bwd(dxn1w, x, mean1, rstd1, blk.norm1.weight.data, g(blk.norm1.weight),
                                 g(blk.norm1.bias), dy_rowmap=n2w, dres=dx1)
+        # ---- weight / bias gradients (only the optimizer consumes them): side stream, overlapping the next block
+        with ops.on_side(dx2.device, dy2, a, dh, xn2, dyw, ao, dqkv, xn1w):
+            ops.gemm(dy2, a, a_kmajor=True, b_kmajor=True, out=g(mlp.fc2.weight), out_f32=True, a_colsum=g(mlp.fc2.bias))
+            ops.gemm(dh, xn2, a_kmajor=True, b_kmajor=True, out=g(mlp.fc1.weight), out_f32=True, a_colsum=g(mlp.fc1.bias))
+            ops.gemm(dyw, ao, a_kmajor=True, b_kmajor=True, out=g(at.proj.weight), out_f32=True, a_colsum=g(at.proj.bias))
+            ops.gemm(dqkv, xn1w, a_kmajor=True, b_kmajor=True, out=g(at.qkv.weight), out_f32=True, a_colsum=g(at.qkv.bias))
         ar.mark(mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, blk.norm1.weight, blk.norm1.bias,
                 blk.norm2.weight, blk.norm2.bias, at.qkv.weight, at.qkv.bias, at.proj.weight, at.proj.bias,
                 at.relative_position_bias_table)
