@@ -38,9 +38,10 @@ MVLT_DEV uint32_t mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16; return h;
 }
 MVLT_DEV uint32_t rng_u32(uint64_t seed, uint32_t tag, uint32_t idx) {
-    uint32_t a = mix32((uint32_t)seed ^ (tag * 0x9E3779B9U));
-    uint32_t b = mix32((uint32_t)(seed >> 32) + idx * 0x85EBCA6BU + a);
-    return mix32(a ^ b ^ idx);
+    // key depends only on (seed, tag): wave-uniform, hoisted out of element loops by the compiler;
+    // per element: one multiply-add + one 32-bit finaliser
+    const uint32_t key = mix32((uint32_t)seed ^ (tag * 0x9E3779B9U)) ^ (uint32_t)(seed >> 32);
+    return mix32(idx * 0x9E3779B1U + key);
 }
 // keep with probability (1-p); thresh = p * 2^32
 MVLT_DEV bool rng_keep(uint64_t seed, uint32_t tag, uint32_t idx, uint32_t thresh) {

@@ -302,19 +302,29 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     }
 }
 
+// slabs -> output: 64 output quads per block, the slabs are shared out over 4 waves and combined in LDS
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDev p) {
+    __shared__ f32x4 red[4][64];
     const int nq = (p.N + 3) / 4;
     const long total = (long)p.M * nq;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int m = (int)(idx / nq), n = (int)(idx % nq) * 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+        const long idx = base + lane;
+        const bool ok = idx < total;
+        const int m = ok ? (int)(idx / nq) : 0, n = ok ? (int)(idx % nq) * 4 : 0;
         f32x4 v{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.split_k; ++s) {
-            const float* w = p.ws + ((long)s * p.M + m) * p.N + n;
-            if ((p.N & 3) == 0) { f32x4 t = load4f(w); v += t; }
-            else for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += w[r];
+        if (ok) {
+            for (int s = w; s < p.split_k; s += 4) {
+                const float* ws = p.ws + ((long)s * p.M + m) * p.N + n;
+                if ((p.N & 3) == 0) { f32x4 t = load4f(ws); v += t; }
+                else for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += ws[r];
+            }
         }
-        epilogue4<T>(p, m, n, v);
+        red[w][lane] = v;
+        __syncthreads();
+        if (w == 0 && ok) epilogue4<T>(p, m, n, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+        __syncthreads();
     }
     if (p.a_colsum) {
         for (int m = blockIdx.x * 256 + threadIdx.x; m < p.M; m += gridDim.x * 256) {
@@ -360,7 +370,7 @@ Plan choose_plan(const MvltGemm* p) {
         if (tiles < 200 && nkt >= 16) {          // small outputs with a long reduction only (wgrads)
             split = (int)((768 + tiles - 1) / tiles);
             if (split > nkt / 8) split = nkt / 8;
-            if (split > 256) split = 256;
+            if (split > 96) split = 96;
             if (split < 1) split = 1;
         }
     }
@@ -422,8 +432,8 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     MVLT_LAUNCH_CHECK();
     if (d.split_k > 1) {
         long total = (long)p->M * ((p->N + 3) / 4);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
+        int blocks = (int)((total + 63) / 64);
+        if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, s, d);
         MVLT_LAUNCH_CHECK();
     }

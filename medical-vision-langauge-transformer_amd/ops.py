@@ -174,10 +174,12 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
         ws = workspace("gemm", need, A.device)
         p.workspace, p.workspace_bytes = _p(ws), ws.numel()
     if GEMM_TIMER is not None:
+        # bench.py: bracket the launch with HIP events on the stream it is launched on
+        st = side_stream(A.device) if _stream_cache[1] == "side" else torch.cuda.current_stream()
         ev0, ev1 = GEMM_TIMER(2.0 * M * N * K)
-        ev0.record()
+        ev0.record(st)
         L.check(lib.mvlt_gemm(C.byref(p), _stream()), "mvlt_gemm")
-        ev1.record()
+        ev1.record(st)
         return out
     L.check(lib.mvlt_gemm(C.byref(p), _stream()), "mvlt_gemm")
     return out
