@@ -79,6 +79,8 @@ typedef struct MvltGemm {
 } MvltGemm;
 int mvlt_gemm(const MvltGemm* p, void* stream);
 size_t mvlt_gemm_workspace_bytes(const MvltGemm* p);
+/* introspection: tile (= kernel instantiation gemm_kernel<dtype,bm,bn,a_kmajor,b_kmajor>) and split-K chosen for p */
+int mvlt_gemm_plan(const MvltGemm* p, int* bm, int* bn, int* split_k);
 
 /* column sums: out[n] = sum_m x[m*ld + n]  (bias gradients), f32 out.
  * workspace: f32 [mvlt_colsum_workspace_rows(M)][N]. */
@@ -120,6 +122,11 @@ typedef struct MvltLayerNormBwd {
     int merge_H, merge_W;
     float* dgamma; float* dbeta; int accumulate;
     float* workspace;
+    /* optional second output, the gradient entering the residual BRANCH that produced x's summand:
+     * dz[dz_rowmap ? dz_rowmap[r] : r] = dropout_mask(dx[r]; p, seed, tag, idx r*C+c) * dz_rowscale[r / rows_per_scale]
+     * (Swin: window-order scatter + DropPath scale; BERT: hidden-dropout backward) */
+    void* dz; const int32_t* dz_rowmap; const float* dz_rowscale; int dz_rows_per_scale;
+    float dz_dropout_p; uint64_t seed; uint32_t tag;
 } MvltLayerNormBwd;
 int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream);
 int mvlt_layernorm_bwd_workspace_rows(void);

@@ -47,7 +47,9 @@ class MvltLayerNormBwd(C.Structure):
                 ("dres", vp), ("dx", vp),
                 ("merge_H", i32), ("merge_W", i32),
                 ("dgamma", vp), ("dbeta", vp), ("accumulate", i32),
-                ("workspace", vp)]
+                ("workspace", vp),
+                ("dz", vp), ("dz_rowmap", vp), ("dz_rowscale", vp), ("dz_rows_per_scale", i32),
+                ("dz_dropout_p", f32), ("seed", u64), ("tag", u32)]
 
 
 class MvltAttn(C.Structure):
@@ -81,6 +83,7 @@ SYMBOLS = {
     "mvlt_arch": (C.c_char_p, []),
     "mvlt_gemm": (i32, [C.POINTER(MvltGemm), vp]),
     "mvlt_gemm_workspace_bytes": (sz, [C.POINTER(MvltGemm)]),
+    "mvlt_gemm_plan": (i32, [C.POINTER(MvltGemm), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "mvlt_colsum": (i32, [i32, vp, i64, i32, i32, vp, i32, vp, vp]),
     "mvlt_colsum_workspace_rows": (i32, [i32]),
     "mvlt_layernorm_fwd": (i32, [C.POINTER(MvltLayerNorm), vp]),

@@ -250,12 +250,18 @@ class MVLBert(nn.Module):
             sa, so = layer.attention.self, layer.attention.output
             (x, qkv, ctx, lse, y1, m1, r1, x1, h, a, y2, m2, r2) = sv["layers"][i]
             lo, li = layer.output, layer.intermediate
-            dy2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight), g(lo.LayerNorm.bias))
-            dz2 = ops.rows_transform(dy2, dropout=(p_h, seed, 8 * i + 2)) if p_h > 0 else dy2
+            if p_h > 0:
+                dy2, dz2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight),
+                                             g(lo.LayerNorm.bias), branch=dict(dropout=(p_h, seed, 8 * i + 2)))
+            else:
+                dy2 = dz2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight), g(lo.LayerNorm.bias))
             dh = ops.gemm(dz2, ar.compute(lo.dense.weight), b_kmajor=True, mul_gelu_grad=h)
             dx1 = ops.gemm(dh, ar.compute(li.dense.weight), b_kmajor=True, residual=dy2)
-            dy1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight), g(so.LayerNorm.bias))
-            dz1 = ops.rows_transform(dy1, dropout=(p_h, seed, 8 * i + 1)) if p_h > 0 else dy1
+            if p_h > 0:
+                dy1, dz1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight),
+                                             g(so.LayerNorm.bias), branch=dict(dropout=(p_h, seed, 8 * i + 1)))
+            else:
+                dy1 = dz1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight), g(so.LayerNorm.bias))
             dctx = ops.gemm(dz1, ar.compute(so.dense.weight), b_kmajor=True)
             dqkv = ops.attn_bwd(dctx, qkv, ctx, lse, sv["mode"], B, Lq, nH, H // nH, (H // nH) ** -0.5,
                                 dropout=(p_a, seed, 8 * i + 0), **sv["akw"])

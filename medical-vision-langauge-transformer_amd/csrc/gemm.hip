@@ -386,6 +386,13 @@ extern "C" size_t mvlt_gemm_workspace_bytes(const MvltGemm* p) {
     return pl.split > 1 ? (size_t)pl.split * p->M * ((size_t)p->N + 1) * sizeof(float) : 0;
 }
 
+extern "C" int mvlt_gemm_plan(const MvltGemm* p, int* bm, int* bn, int* split_k) {
+    if (!p || !bm || !bn || !split_k) return MVLT_ERR_ARG;
+    Plan pl = choose_plan(p);
+    *bm = pl.bm; *bn = pl.bn; *split_k = pl.split;
+    return MVLT_OK;
+}
+
 template <typename T>
 static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     Plan pl = choose_plan(p);

@@ -16,6 +16,8 @@ struct LnDev {
     // backward
     const void* dy; const void* dres; void* dx;
     float* part_g; float* part_b; int nparts;
+    // optional second output: dz[zmap ? zmap[r] : r] = dropmask(dx[r]) * zscale[r / zrps]
+    void* dz; const int* zmap; const float* zscale; int zrps; uint32_t zthresh; float zdscale; uint64_t seed; uint32_t tag;
 };
 
 template <int LPR> MVLT_DEV float group_sum(float v) {
@@ -151,6 +153,18 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnDev p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] += a[e]; }
                     store4f(dx + off, o);
+                    if (!MERGE && p.dz) {           // branch gradient for the residual branch that consumed this tensor
+                        if (p.zthresh) {
+                            const uint32_t base = (uint32_t)r * (uint32_t)p.C + c;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = rng_keep(p.seed, p.tag, base + e, p.zthresh) ? o[e] * p.zdscale : 0.f;
+                        }
+                        if (p.zscale) { const float zs = p.zscale[r / p.zrps];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] *= zs; }
+                        const int zr = p.zmap ? p.zmap[r] : r;
+                        store4f(reinterpret_cast<T*>(p.dz) + (long)zr * p.C + c, o);
+                    }
                 }
             }
         }
@@ -259,12 +273,16 @@ extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
     MVLT_CHECK(p->rows > 0 && p->C > 0 && p->C % 4 == 0, MVLT_ERR_ARG);
     if (p->gelu) MVLT_CHECK(p->y_pre, MVLT_ERR_ARG);
     const bool merge = p->merge_H != 0;
-    if (merge) MVLT_CHECK(p->merge_H % 2 == 0 && p->merge_W % 2 == 0 && p->C % 16 == 0 && !p->dres, MVLT_ERR_ARG);
+    if (merge) MVLT_CHECK(p->merge_H % 2 == 0 && p->merge_W % 2 == 0 && p->C % 16 == 0 && !p->dres && !p->dz, MVLT_ERR_ARG);
+    MVLT_CHECK(p->dz_dropout_p >= 0.f && p->dz_dropout_p < 1.f, MVLT_ERR_ARG);
     LnDev d{};
     d.rows = p->rows; d.C = p->C; d.x = p->x; d.gamma = p->gamma; d.mean = const_cast<float*>(p->mean);
     d.rstd = const_cast<float*>(p->rstd); d.rowmap = p->dy_rowmap; d.mH = p->merge_H; d.mW = p->merge_W;
     d.gelu = p->gelu; d.y_pre = const_cast<void*>(p->y_pre); d.dy = p->dy; d.dres = p->dres; d.dx = p->dx;
     d.part_g = p->workspace; d.part_b = p->workspace + (size_t)LN_BWD_PARTS * p->C;
+    d.dz = p->dz; d.zmap = p->dz_rowmap; d.zscale = p->dz_rowscale; d.zrps = p->dz_rows_per_scale > 0 ? p->dz_rows_per_scale : 1;
+    d.zthresh = (uint32_t)((double)p->dz_dropout_p * 4294967296.0); d.zdscale = 1.0f / (1.0f - p->dz_dropout_p);
+    d.seed = p->seed; d.tag = p->tag;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (p->dtype == MVLT_F32) rc = dispatch<float, true>(d, merge, s);

@@ -175,12 +175,15 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
         p.workspace, p.workspace_bytes = _p(ws), ws.numel()
     if GEMM_TIMER is not None:
         # bench.py: bracket the launch with HIP events on the stream it is launched on
-        st = side_stream(A.device) if _stream_cache[1] == "side" else torch.cuda.current_stream()
-        ev0, ev1 = GEMM_TIMER(2.0 * M * N * K)
-        ev0.record(st)
-        L.check(lib.mvlt_gemm(C.byref(p), _stream()), "mvlt_gemm")
-        ev1.record(st)
-        return out
+        bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
+        lib.mvlt_gemm_plan(C.byref(p), C.byref(bm), C.byref(bn), C.byref(sp))
+        evs = GEMM_TIMER(2.0 * M * N * K, (p.dtype, bm.value, bn.value, int(a_kmajor), int(b_kmajor)))
+        if evs is not None:
+            st = side_stream(A.device) if _stream_cache[1] == "side" else torch.cuda.current_stream()
+            evs[0].record(st)
+            L.check(lib.mvlt_gemm(C.byref(p), _stream()), "mvlt_gemm")
+            evs[1].record(st)
+            return out
     L.check(lib.mvlt_gemm(C.byref(p), _stream()), "mvlt_gemm")
     return out
 
@@ -236,7 +239,8 @@ def layernorm_fwd(x, gamma, beta, eps, *, rows=None, C_=None, out=None, out_rowm
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_pre=None, dres=None, merge=None,
-                  accumulate=False, dx=None):
+                  accumulate=False, dx=None, branch=None):
+    """branch=dict(rowmap=, rowscale=(t, rps), dropout=(p, seed, tag)) also returns the branch gradient dz."""
     _need_cuda(dy, x)
     Cn = gamma.numel()
     nrows = mean.numel()
@@ -257,8 +261,18 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_
     if merge is not None:
         p.merge_H, p.merge_W = merge
     p.dgamma, p.dbeta, p.accumulate, p.workspace = _p(dgamma), _p(dbeta), int(accumulate), _p(ws)
+    dz = None
+    if branch is not None:
+        dz = torch.empty((nrows, Cn), dtype=x.dtype, device=x.device)
+        p.dz = _p(dz)
+        if branch.get("rowmap") is not None:
+            p.dz_rowmap = _p(branch["rowmap"])
+        if branch.get("rowscale") is not None:
+            p.dz_rowscale, p.dz_rows_per_scale = _p(branch["rowscale"][0]), int(branch["rowscale"][1])
+        if branch.get("dropout") is not None and branch["dropout"][0] > 0:
+            p.dz_dropout_p, p.seed, p.tag = float(branch["dropout"][0]), int(branch["dropout"][1]), int(branch["dropout"][2])
     L.check(lib.mvlt_layernorm_bwd(C.byref(p), _stream()), "mvlt_layernorm_bwd")
-    return dx
+    return dx if branch is None else (dx, dz)
 
 
 # ----------------------------------------------------------------------------- attention

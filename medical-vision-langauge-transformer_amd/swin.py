@@ -329,9 +329,9 @@ class SwinTransformer(nn.Module):
         dy2 = ops.rows_transform(dx2, rowscale=(s2, Lt)) if s2 is not None else dx2
         dh = ops.gemm(dy2, ar.compute(mlp.fc2.weight), b_kmajor=True, mul_gelu_grad=h)
         dxn2 = ops.gemm(dh, ar.compute(mlp.fc1.weight), b_kmajor=True)
-        dx1 = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, blk.norm2.weight.data, g(blk.norm2.weight),
-                                g(blk.norm2.bias), dres=dx2)
-        dyw = ops.rows_transform(dx1, rowmap=w2n, rowscale=(s1, Lt) if s1 is not None else None)
+        dx1, dyw = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, blk.norm2.weight.data, g(blk.norm2.weight),
+                                     g(blk.norm2.bias), dres=dx2,
+                                     branch=dict(rowmap=n2w, rowscale=(s1, Lt) if s1 is not None else None))
         dao = ops.gemm(dyw, ar.compute(at.proj.weight), b_kmajor=True)
         dtab = g(at.relative_position_bias_table)
         dtab.zero_()
