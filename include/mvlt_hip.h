@@ -76,6 +76,8 @@ typedef struct MvltGemm {
     int split_k; void* workspace; size_t workspace_bytes;
     float* a_colsum;                 /* optional (a_kmajor only): a_colsum[m] = sum_k A[k*lda+m], i.e. the bias
                                         gradient colsum(dY) fused into the wgrad GEMM dW = dY^T X */
+    void* event_after_main;          /* optional hipEvent_t recorded on `stream` right after the main GEMM kernel
+                                        (before the split-K reduce): lets a benchmark time that kernel alone */
 } MvltGemm;
 int mvlt_gemm(const MvltGemm* p, void* stream);
 size_t mvlt_gemm_workspace_bytes(const MvltGemm* p);

@@ -29,7 +29,7 @@ class MvltGemm(C.Structure):
                 ("bias", vp), ("pre", vp), ("residual", vp), ("ldr", i64), ("aux", vp),
                 ("rowscale", vp), ("rows_per_scale", i32), ("rowmap", vp),
                 ("dropout_p", f32), ("seed", u64), ("tag", u32),
-                ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("a_colsum", vp)]
+                ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("a_colsum", vp), ("event_after_main", vp)]
 
 
 class MvltLayerNorm(C.Structure):

@@ -81,6 +81,7 @@ class Arena:
         self._ptr0 = self.params[0].data_ptr()
         self.shadow_fresh = False
         self._flat_version = -1
+        self._views: Dict[tuple, torch.Tensor] = {}
         self.has_grad: Dict[int, bool] = {id(p): False for p in self.params}
         self.steps: Dict[int, int] = {id(p): 0 for p in self.params}
         self.exp_avg: Optional[torch.Tensor] = None
@@ -103,7 +104,15 @@ class Arena:
 
     def compute(self, p: nn.Parameter, rows: Optional[int] = None) -> torch.Tensor:
         """2-D compute-dtype view of a weight ([out, in]); ``rows`` > p.shape[0]
-        spans the adjacent parameters of a fused group (QKV)."""
+        spans the adjacent parameters of a fused group (QKV).  Views are cached:
+        creating ~900 slice/view tensors per step is measurable host time."""
+        key = ("c", id(p), rows)
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = self._compute(p, rows)
+        return v
+
+    def _compute(self, p: nn.Parameter, rows: Optional[int] = None) -> torch.Tensor:
         o = self.offset[id(p)]
         cols = p.numel() // p.shape[0]
         r = p.shape[0] if rows is None else rows
@@ -111,10 +120,21 @@ class Arena:
         return src[o:o + r * cols].view(r, cols)
 
     def master_span(self, p: nn.Parameter, n: int) -> torch.Tensor:
-        o = self.offset[id(p)]
-        return self.flat[o:o + n]
+        key = ("m", id(p), n)
+        v = self._views.get(key)
+        if v is None:
+            o = self.offset[id(p)]
+            v = self._views[key] = self.flat[o:o + n]
+        return v
 
     def grad_view(self, p: nn.Parameter, rows: Optional[int] = None) -> torch.Tensor:
+        key = ("g", id(p), rows)
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = self._grad_view(p, rows)
+        return v
+
+    def _grad_view(self, p: nn.Parameter, rows: Optional[int] = None) -> torch.Tensor:
         o = self.offset[id(p)]
         if p.dim() == 1:
             n = p.numel() if rows is None else rows

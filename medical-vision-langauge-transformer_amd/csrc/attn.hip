@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
 
 // ------------------------------------------------------------------ backward
 template <typename T, int HD, int KT, bool SWIN>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnDev p) {
+__global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const AttnDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using M = Mma<T>;
     constexpr int KBD = HD / M::KB;

@@ -437,6 +437,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     else if (pl.bm == 64 && pl.bn == 96) launch_layout<T, 64, 96>(d, ak, bk, grid, s);
     else launch_layout<T, 64, 64>(d, ak, bk, grid, s);
     MVLT_LAUNCH_CHECK();
+    if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
     if (d.split_k > 1) {
         long total = (long)p->M * ((p->N + 3) / 4);
         int blocks = (int)((total + 63) / 64);

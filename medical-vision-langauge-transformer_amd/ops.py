@@ -180,9 +180,12 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
         evs = GEMM_TIMER(2.0 * M * N * K, (p.dtype, bm.value, bn.value, int(a_kmajor), int(b_kmajor)))
         if evs is not None:
             st = side_stream(A.device) if _stream_cache[1] == "side" else torch.cuda.current_stream()
+            if not getattr(evs[1], "_mvlt_created", False):
+                evs[1].record(st)                       # creates the underlying hipEvent_t; re-recorded by the library
+                evs[1]._mvlt_created = True
+            p.event_after_main = C.c_void_p(evs[1].cuda_event)
             evs[0].record(st)
             L.check(lib.mvlt_gemm(C.byref(p), _stream()), "mvlt_gemm")
-            evs[1].record(st)
             return out
     L.check(lib.mvlt_gemm(C.byref(p), _stream()), "mvlt_gemm")
     return out

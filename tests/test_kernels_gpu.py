@@ -376,3 +376,37 @@ def test_cached_attention_and_argmax(ops, dt):
     assert rel(kc[:, :, past:past + 2], k) < 1e-6 and rel(vc[:, :, past:past + 2], v) < 1e-6
     logits = rnd((5, 3008), dt, 103)
     assert torch.equal(ops.argmax(logits, 3000), logits[:, :3000].float().argmax(-1))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_layernorm_bwd_branch_output(ops, dt):
+    """Second output of LN backward: dz[map[r]] = dropmask(dx[r]) * rowscale[r // rps]
+    (Swin window scatter + DropPath, BERT hidden-dropout backward)."""
+    rows, C = 300, 192
+    x, dy = rnd((rows, C), dt, 120, 2.0), rnd((rows, C), dt, 121)
+    g = (1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(122))).cuda()
+    b = torch.zeros(C, device="cuda")
+    _, mean, rstd, _ = ops.layernorm_fwd(x, g, b, 1e-5)
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ref_dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dgam, dbet)
+    perm = torch.randperm(rows, generator=torch.Generator().manual_seed(4)).int().cuda()
+    rs = torch.tensor([0.0, 1.5, 2.0], device="cuda")
+    dx, dz = ops.layernorm_bwd(dy, x, mean, rstd, g, dgam, dbet, branch=dict(rowmap=perm, rowscale=(rs, 100)))
+    assert torch.equal(dx, ref_dx)
+    exp = torch.empty_like(ref_dx, dtype=torch.float32)
+    exp[perm.long()] = ref_dx.float() * rs[torch.arange(rows, device="cuda") // 100][:, None]
+    assert rel(dz, exp) < tol(dt)
+    dx, dz = ops.layernorm_bwd(dy, x, mean, rstd, g, dgam, dbet, branch=dict(dropout=(0.2, 9, 3)))
+    keep = ops.dropout_mask(rows * C, 0.2, 9, 3, x.device).view(rows, C).float()
+    assert rel(dz, ref_dx.float() * keep / 0.8) < tol(dt)
+
+
+def test_gemm_plan_introspection(ops):
+    import ctypes as C
+    from mvlt_amd import _lib as L
+    p = L.MvltGemm()
+    p.dtype, p.M, p.N, p.K = L.BF16, 3072, 768, 4192          # BERT FFN-in weight gradient
+    p.a_kmajor = p.b_kmajor = 1
+    bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
+    assert L.lib().mvlt_gemm_plan(C.byref(p), C.byref(bm), C.byref(bn), C.byref(sp)) == 0
+    assert (bm.value, bn.value) in ((64, 128), (128, 128)) and sp.value >= 1
