@@ -128,8 +128,10 @@ def main():
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     import torch.distributed as dist
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MVLT_FORCE_DDP") == "1"     # FORCE: exercise RCCL + reducer on 1 rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     import mvlt_amd as M
@@ -147,7 +149,7 @@ def main():
     model = M.MVLBertForPretraining(cfg).cuda().train()
     M.manual_seed(4321 + rank)                      # dropout stream differs per rank
     seed_coin_flip(5678)                            # seq2seq/bidir flip identical on all ranks
-    reducer = GradReducer(model) if world > 1 else None
+    reducer = GradReducer(model) if use_dist else None
     step = PretrainStep(model, reducer=reducer, world_size=world)
     batch = synthetic_batch(PER_GPU_BATCH, SEQ, "cuda", 1234 + rank)
 
@@ -156,19 +158,19 @@ def main():
     timer = KernelTimer(DOMINANT)
     ops.GEMM_TIMER = timer
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(batch)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.GEMM_TIMER = None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -197,7 +199,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
