@@ -129,9 +129,15 @@ typedef struct MvltLayerNormBwd {
      * (Swin: window-order scatter + DropPath scale; BERT: hidden-dropout backward) */
     void* dz; const int32_t* dz_rowmap; const float* dz_rowscale; int dz_rows_per_scale;
     float dz_dropout_p; uint64_t seed; uint32_t tag;
+    int defer_param_reduce;          /* 1: leave the partial rows in `workspace`; reduce them later, batched */
 } MvltLayerNormBwd;
 int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream);
 int mvlt_layernorm_bwd_workspace_rows(void);
+/* deferred parameter-gradient reduction: one launch per 24 LayerNorms instead of one per LayerNorm.
+ * items is a HOST array; workspace = the buffer given to mvlt_layernorm_bwd, nparts = mvlt_layernorm_bwd_nparts(rows, C). */
+typedef struct MvltLnReduceItem { const float* workspace; int nparts, C; float* dgamma; float* dbeta; } MvltLnReduceItem;
+int mvlt_layernorm_bwd_nparts(int rows, int C);
+int mvlt_layernorm_param_reduce_batch(const MvltLnReduceItem* items, int n, void* stream);
 
 /* ------------------------------------------------------------------ attention
  * One (sequence, head) problem per workgroup; Q,K,V come from a fused

@@ -49,7 +49,11 @@ class MvltLayerNormBwd(C.Structure):
                 ("dgamma", vp), ("dbeta", vp), ("accumulate", i32),
                 ("workspace", vp),
                 ("dz", vp), ("dz_rowmap", vp), ("dz_rowscale", vp), ("dz_rows_per_scale", i32),
-                ("dz_dropout_p", f32), ("seed", u64), ("tag", u32)]
+                ("dz_dropout_p", f32), ("seed", u64), ("tag", u32), ("defer_param_reduce", i32)]
+
+
+class MvltLnReduceItem(C.Structure):
+    _fields_ = [("workspace", vp), ("nparts", i32), ("C", i32), ("dgamma", vp), ("dbeta", vp)]
 
 
 class MvltAttn(C.Structure):
@@ -89,6 +93,8 @@ SYMBOLS = {
     "mvlt_layernorm_fwd": (i32, [C.POINTER(MvltLayerNorm), vp]),
     "mvlt_layernorm_bwd": (i32, [C.POINTER(MvltLayerNormBwd), vp]),
     "mvlt_layernorm_bwd_workspace_rows": (i32, []),
+    "mvlt_layernorm_bwd_nparts": (i32, [i32, i32]),
+    "mvlt_layernorm_param_reduce_batch": (i32, [C.POINTER(MvltLnReduceItem), i32, vp]),
     "mvlt_attn_fwd": (i32, [C.POINTER(MvltAttn), vp]),
     "mvlt_attn_bwd": (i32, [C.POINTER(MvltAttn), vp]),
     "mvlt_im2col_patch": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),

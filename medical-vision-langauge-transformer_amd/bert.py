@@ -229,6 +229,7 @@ class MVLBert(nn.Module):
     def _backward(self, sv, dhidden, dpooled):
         ar: Arena = sv["ar"]
         backward_begin(ar)
+        lnq = ops.LnReduceQueue()
         g = ar.grad_view
         cfg = self.config
         B, Lq, H = sv["B"], sv["Lq"], cfg.hidden_size
@@ -252,16 +253,16 @@ class MVLBert(nn.Module):
             lo, li = layer.output, layer.intermediate
             if p_h > 0:
                 dy2, dz2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight),
-                                             g(lo.LayerNorm.bias), branch=dict(dropout=(p_h, seed, 8 * i + 2)))
+                                             g(lo.LayerNorm.bias), branch=dict(dropout=(p_h, seed, 8 * i + 2)), defer=lnq)
             else:
-                dy2 = dz2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight), g(lo.LayerNorm.bias))
+                dy2 = dz2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight), g(lo.LayerNorm.bias), defer=lnq)
             dh = ops.gemm(dz2, ar.compute(lo.dense.weight), b_kmajor=True, mul_gelu_grad=h)
             dx1 = ops.gemm(dh, ar.compute(li.dense.weight), b_kmajor=True, residual=dy2)
             if p_h > 0:
                 dy1, dz1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight),
-                                             g(so.LayerNorm.bias), branch=dict(dropout=(p_h, seed, 8 * i + 1)))
+                                             g(so.LayerNorm.bias), branch=dict(dropout=(p_h, seed, 8 * i + 1)), defer=lnq)
             else:
-                dy1 = dz1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight), g(so.LayerNorm.bias))
+                dy1 = dz1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight), g(so.LayerNorm.bias), defer=lnq)
             dctx = ops.gemm(dz1, ar.compute(so.dense.weight), b_kmajor=True)
             dqkv = ops.attn_bwd(dctx, qkv, ctx, lse, sv["mode"], B, Lq, nH, H // nH, (H // nH) ** -0.5,
                                 dropout=(p_a, seed, 8 * i + 0), **sv["akw"])
@@ -277,6 +278,7 @@ class MVLBert(nn.Module):
             ar.mark(lo.LayerNorm.weight, lo.LayerNorm.bias, lo.dense.weight, lo.dense.bias, li.dense.weight,
                     li.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, so.dense.weight, so.dense.bias,
                     sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias)
+        lnq.flush()
         # ---- embeddings: dense f32 table gradients, like nn.Embedding in the reference
         we, pe, te = self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight
         g(we).zero_(); g(pe).zero_(); g(te).zero_()

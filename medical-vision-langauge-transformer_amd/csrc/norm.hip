@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 namespace {
+constexpr int LN_PARTS_STRIDE = 256;   // == LN_BWD_PARTS: row stride between the dgamma and dbeta partial blocks
 
 struct LnDev {
     int rows, C; float eps;
@@ -209,6 +210,30 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* part
     }
 }
 
+struct LnReduceBatch { MvltLnReduceItem it[24]; int n; };
+// one launch reduces the partial rows of up to 24 LayerNorms: blockIdx.y = item, blockIdx.x = 64-column group
+__global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnReduceBatch b) {
+    __shared__ float red[2][16][64];
+    const MvltLnReduceItem it = b.it[blockIdx.y];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= it.C) return;
+    float g = 0.f, bb = 0.f;
+    if (c < it.C) {
+        const float* pg = it.workspace;
+        const float* pb = it.workspace + (long)LN_PARTS_STRIDE * it.C;
+        for (int i = w; i < it.nparts; i += 16) { g += pg[(long)i * it.C + c]; bb += pb[(long)i * it.C + c]; }
+    }
+    red[0][w][lane] = g; red[1][w][lane] = bb;
+    __syncthreads();
+    if (w == 0 && c < it.C) {
+        g = 0.f; bb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { g += red[0][i][lane]; bb += red[1][i][lane]; }
+        it.dgamma[c] = g; it.dbeta[c] = bb;
+    }
+}
+
 constexpr int LN_BWD_PARTS = 256;
 constexpr int LN_BWD_WAVES = 16;
 static int ln_env(const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; }
@@ -305,8 +330,33 @@ extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
     int lpr = p->C <= 64 ? 16 : (p->C <= 128 ? 32 : 64);
     int blocks = ceil_div(p->rows, ln_bwd_waves(p->rows, 64 / lpr) * (64 / lpr));
     if (blocks > ln_bwd_parts()) blocks = ln_bwd_parts();
+    if (p->defer_param_reduce) return MVLT_OK;       // caller batches it with mvlt_layernorm_param_reduce_batch
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(p->C, 64)), dim3(1024), 0, s, d.part_g, d.part_b,
                        blocks, p->C, p->dgamma, p->dbeta, p->accumulate);
     MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_layernorm_bwd_nparts(int rows, int C) {
+    int lpr = C <= 64 ? 16 : (C <= 128 ? 32 : 64);
+    int blocks = ceil_div(rows, ln_bwd_waves(rows, 64 / lpr) * (64 / lpr));
+    return blocks > ln_bwd_parts() ? ln_bwd_parts() : blocks;
+}
+
+extern "C" int mvlt_layernorm_param_reduce_batch(const MvltLnReduceItem* items, int n, void* stream) {
+    MVLT_CHECK(items && n > 0, MVLT_ERR_ARG);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int i0 = 0; i0 < n; i0 += 24) {
+        LnReduceBatch b;
+        b.n = n - i0 < 24 ? n - i0 : 24;
+        int maxC = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.it[i] = items[i0 + i];
+            MVLT_CHECK(b.it[i].workspace && b.it[i].dgamma && b.it[i].dbeta && b.it[i].nparts > 0 && b.it[i].C > 0, MVLT_ERR_ARG);
+            if (b.it[i].C > maxC) maxC = b.it[i].C;
+        }
+        hipLaunchKernelGGL(ln_param_reduce_batch_kernel, dim3(ceil_div(maxC, 64), b.n), dim3(1024), 0, s, b);
+        MVLT_LAUNCH_CHECK();
+    }
     return MVLT_OK;
 }

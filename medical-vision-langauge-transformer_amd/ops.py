@@ -242,15 +242,20 @@ def layernorm_fwd(x, gamma, beta, eps, *, rows=None, C_=None, out=None, out_rowm
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_pre=None, dres=None, merge=None,
-                  accumulate=False, dx=None, branch=None):
-    """branch=dict(rowmap=, rowscale=(t, rps), dropout=(p, seed, tag)) also returns the branch gradient dz."""
+                  accumulate=False, dx=None, branch=None, defer=None):
+    """branch=dict(rowmap=, rowscale=(t, rps), dropout=(p, seed, tag)) also returns the branch gradient dz.
+    defer=LnReduceQueue: the dgamma/dbeta partial rows are reduced later in one batched launch."""
     _need_cuda(dy, x)
     Cn = gamma.numel()
     nrows = mean.numel()
     if dx is None:
         dx = torch.empty_like(x)
     lib = L.lib()
-    ws = workspace("ln_bwd", 2 * lib.mvlt_layernorm_bwd_workspace_rows() * Cn * 4, x.device)
+    if defer is not None:
+        ws = defer.take(2 * lib.mvlt_layernorm_bwd_workspace_rows() * Cn, x.device)
+        defer.items.append((ws, lib.mvlt_layernorm_bwd_nparts(nrows, Cn), Cn, dgamma, dbeta))
+    else:
+        ws = workspace("ln_bwd", 2 * lib.mvlt_layernorm_bwd_workspace_rows() * Cn * 4, x.device)
     p = L.MvltLayerNormBwd()
     p.dtype, p.rows, p.C = _dt(x), nrows, Cn
     p.dy, p.x, p.mean, p.rstd, p.gamma = _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma)
@@ -264,6 +269,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_
     if merge is not None:
         p.merge_H, p.merge_W = merge
     p.dgamma, p.dbeta, p.accumulate, p.workspace = _p(dgamma), _p(dbeta), int(accumulate), _p(ws)
+    p.defer_param_reduce = int(defer is not None)
     dz = None
     if branch is not None:
         dz = torch.empty((nrows, Cn), dtype=x.dtype, device=x.device)
@@ -276,6 +282,37 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_
             p.dz_dropout_p, p.seed, p.tag = float(branch["dropout"][0]), int(branch["dropout"][1]), int(branch["dropout"][2])
     L.check(lib.mvlt_layernorm_bwd(C.byref(p), _stream()), "mvlt_layernorm_bwd")
     return dx if branch is None else (dx, dz)
+
+
+class LnReduceQueue:
+    """Partial dgamma/dbeta rows of every LayerNorm of one backward pass live in one pool and are
+    reduced by ceil(n/24) launches at the end (instead of one launch per LayerNorm)."""
+    _pool = {}
+
+    def __init__(self):
+        self.items, self.off = [], 0
+
+    def take(self, nfloats, device):
+        pool = LnReduceQueue._pool.get(device.index)
+        need = self.off + nfloats
+        if pool is None or pool.numel() < need:
+            newp = torch.empty(max(need, 48 << 20), dtype=torch.float32, device=device)
+            if pool is not None:            # keep earlier slices valid: they are still referenced by self.items
+                self._keep = getattr(self, "_keep", []) + [pool]
+                self.off = 0
+            LnReduceQueue._pool[device.index] = pool = newp
+        ws = pool[self.off:self.off + nfloats]
+        self.off += nfloats
+        return ws
+
+    def flush(self):
+        if not self.items:
+            return
+        arr = (L.MvltLnReduceItem * len(self.items))()
+        for i, (ws, nparts, Cn, dg, db) in enumerate(self.items):
+            arr[i].workspace, arr[i].nparts, arr[i].C, arr[i].dgamma, arr[i].dbeta = ws.data_ptr(), nparts, Cn, dg.data_ptr(), db.data_ptr()
+        L.check(L.lib().mvlt_layernorm_param_reduce_batch(arr, len(self.items), _stream()), "mvlt_layernorm_param_reduce_batch")
+        self.items, self.off = [], 0
 
 
 # ----------------------------------------------------------------------------- attention

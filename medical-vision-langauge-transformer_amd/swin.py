@@ -287,12 +287,13 @@ class SwinTransformer(nn.Module):
     def _backward(self, saved, dout):
         ar: Arena = saved["arena"]
         backward_begin(ar)
+        lnq = self.__dict__["_lnq"] = ops.LnReduceQueue()
         B = saved["B"]
         g = ar.grad_view
         x, mean, rstd, ypre = saved["final"]
         dy = dout.reshape(-1, self.num_features)
         dx = ops.layernorm_bwd(dy, x, mean, rstd, self.norm.weight.data, g(self.norm.weight), g(self.norm.bias),
-                               y_pre=ypre)
+                               y_pre=ypre, defer=lnq)
         ar.mark(self.norm.weight, self.norm.bias)
         bi = len(saved["blocks"])
         for li in range(len(self.layers) - 1, -1, -1):
@@ -304,14 +305,15 @@ class SwinTransformer(nn.Module):
                 dxm = ops.gemm(dx, ar.compute(ds.reduction.weight), b_kmajor=True)
                 ops.gemm(dx, xm, a_kmajor=True, b_kmajor=True, out=g(ds.reduction.weight), out_f32=True)
                 dx = ops.layernorm_bwd(dxm, xin, mean, rstd, ds.norm.weight.data, g(ds.norm.weight), g(ds.norm.bias),
-                                       merge=(H, W))
+                                       merge=(H, W), defer=lnq)
                 ar.mark(ds.reduction.weight, ds.norm.weight, ds.norm.bias)
             for _ in layer.blocks:
                 bi -= 1
                 dx = self._block_bwd(ar, saved["blocks"][bi], dx, B)
         cols, x0, mean, rstd = saved["pe"]
         pe = self.patch_embed
-        dx0 = ops.layernorm_bwd(dx, x0, mean, rstd, pe.norm.weight.data, g(pe.norm.weight), g(pe.norm.bias))
+        dx0 = ops.layernorm_bwd(dx, x0, mean, rstd, pe.norm.weight.data, g(pe.norm.weight), g(pe.norm.bias), defer=lnq)
+        lnq.flush()
         ops.gemm(dx0, cols, a_kmajor=True, b_kmajor=True, out=g(pe.proj.weight), out_f32=True,
                  a_colsum=g(pe.proj.bias))
         ops.join_side(dx0.device)                # all weight gradients are complete before anyone reads them
@@ -331,7 +333,8 @@ class SwinTransformer(nn.Module):
         dxn2 = ops.gemm(dh, ar.compute(mlp.fc1.weight), b_kmajor=True)
         dx1, dyw = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, blk.norm2.weight.data, g(blk.norm2.weight),
                                      g(blk.norm2.bias), dres=dx2,
-                                     branch=dict(rowmap=n2w, rowscale=(s1, Lt) if s1 is not None else None))
+                                     branch=dict(rowmap=n2w, rowscale=(s1, Lt) if s1 is not None else None),
+                                     defer=self.__dict__["_lnq"])
         dao = ops.gemm(dyw, ar.compute(at.proj.weight), b_kmajor=True)
         dtab = g(at.relative_position_bias_table)
         dtab.zero_()
@@ -340,7 +343,7 @@ class SwinTransformer(nn.Module):
                             shift=blk.shift_size)
         dxn1w = ops.gemm(dqkv, ar.compute(at.qkv.weight), b_kmajor=True)
         dx0 = ops.layernorm_bwd(dxn1w, x, mean1, rstd1, blk.norm1.weight.data, g(blk.norm1.weight),
-                                g(blk.norm1.bias), dy_rowmap=n2w, dres=dx1)
+                                g(blk.norm1.bias), dy_rowmap=n2w, dres=dx1, defer=self.__dict__["_lnq"])
         # ---- weight / bias gradients (only the optimizer consumes them): side stream, overlapping the next block
         with ops.on_side(dx2.device, dy2, a, dh, xn2, dyw, ao, dqkv, xn1w):
             ops.gemm(dy2, a, a_kmajor=True, b_kmajor=True, out=g(mlp.fc2.weight), out_f32=True, a_colsum=g(mlp.fc2.bias))
