@@ -100,8 +100,6 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnDev p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwave = blockDim.x >> 6;
     const int sl = lane % LPR;
-    for (int c = threadIdx.x; c < 2 * p.C; c += blockDim.x) red[c] = 0.f;
-    __syncthreads();
     const T* x = reinterpret_cast<const T*>(p.x);
     const T* dy = reinterpret_cast<const T*>(p.dy);
     const T* ypre = reinterpret_cast<const T*>(p.y_pre);
@@ -171,21 +169,28 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnDev p) {
             }
         }
     }
+    // block-level reduction without atomics: lanes of different row groups (LPR < 64) fold by
+    // xor-shuffle, every wave stores its partial row to LDS [wave][2][C], then a conflict-free
+    // column sum over the waves.
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int c = 4 * (sl + LPR * j);
-        if (c < p.C) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(&red[c + e], ag[j][e]);
-                atomicAdd(&red[p.C + c + e], ab[j][e]);
-            }
+        for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ag[j][e] += __shfl_xor(ag[j][e], o, 64); ab[j][e] += __shfl_xor(ab[j][e], o, 64); }
+        }
+        const int c = 4 * (sl + LPR * j);
+        if (c < p.C && lane < LPR) {
+            *reinterpret_cast<f32x4*>(&red[(wave * 2 + 0) * p.C + c]) = ag[j];
+            *reinterpret_cast<f32x4*>(&red[(wave * 2 + 1) * p.C + c]) = ab[j];
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-        p.part_g[(long)blockIdx.x * p.C + c] = red[c];
-        p.part_b[(long)blockIdx.x * p.C + c] = red[p.C + c];
+    for (int c = threadIdx.x; c < 2 * p.C; c += blockDim.x) {
+        const int which = c >= p.C, cc = which ? c - p.C : c;
+        float sum = 0.f;
+        for (int w = 0; w < nwave; ++w) sum += red[(w * 2 + which) * p.C + cc];
+        (which ? p.part_b : p.part_g)[(long)blockIdx.x * p.C + cc] = sum;
     }
 }
 
@@ -237,13 +242,12 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnRed
 constexpr int LN_BWD_PARTS = 256;
 constexpr int LN_BWD_WAVES = 16;
 static int ln_env(const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; }
-// waves per block: every wave ends with 8*NV LDS atomics, so few-row launches use 4 waves and
-// many-row launches 16 (measured: 4192x768 25 us vs 45 us; 100352x96 33 us vs 58 us)
-static int ln_bwd_waves(long rows = 1 << 30, int rpw = 1) {
+static int ln_bwd_waves(int C) {
     static int forced = ln_env("MVLT_LN_WAVES", 0);
     if (forced) return forced;
-    const long per_wave4 = rows / ((long)LN_BWD_PARTS * rpw * 4);
-    return per_wave4 < 8 ? 4 : (per_wave4 < 16 ? 8 : 16);
+    int nw = 16;                                   // per-wave partial rows: nw * 2 * C floats of LDS, keep <= 64 KB
+    while (nw > 1 && (size_t)nw * 2 * C * sizeof(float) > 64 * 1024) nw >>= 1;
+    return nw;
 }
 static int ln_bwd_parts() { static int w = ln_env("MVLT_LN_PARTS", LN_BWD_PARTS); return w < LN_BWD_PARTS ? w : LN_BWD_PARTS; }     // 1024-thread blocks: 16 waves per CU hide the load latency, still 256 partial rows
 
@@ -256,12 +260,12 @@ void launch_fwd(const LnDev& d, bool merge, hipStream_t s) {
 }
 template <typename T, int LPR, int NV>
 void launch_bwd(LnDev d, bool merge, hipStream_t s) {
-    const int nw = ln_bwd_waves(d.rows, 64 / LPR);
+    const int nw = ln_bwd_waves(d.C);
     const int rpb = nw * (64 / LPR);
     int blocks = ceil_div(d.rows, rpb);
     if (blocks > ln_bwd_parts()) blocks = ln_bwd_parts();
     d.nparts = blocks;
-    const size_t sh = 2 * (size_t)d.C * sizeof(float);
+    const size_t sh = 2 * (size_t)nw * d.C * sizeof(float);
     if (merge) hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, true>), dim3(blocks), dim3(64 * nw), sh, s, d);
     else hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, false>), dim3(blocks), dim3(64 * nw), sh, s, d);
 }
@@ -328,7 +332,7 @@ extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
     if (rc != MVLT_OK) return rc;
     // the number of partial rows written == number of blocks launched above
     int lpr = p->C <= 64 ? 16 : (p->C <= 128 ? 32 : 64);
-    int blocks = ceil_div(p->rows, ln_bwd_waves(p->rows, 64 / lpr) * (64 / lpr));
+    int blocks = ceil_div(p->rows, ln_bwd_waves(p->C) * (64 / lpr));
     if (blocks > ln_bwd_parts()) blocks = ln_bwd_parts();
     if (p->defer_param_reduce) return MVLT_OK;       // caller batches it with mvlt_layernorm_param_reduce_batch
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(p->C, 64)), dim3(1024), 0, s, d.part_g, d.part_b,
@@ -339,7 +343,7 @@ extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
 
 extern "C" int mvlt_layernorm_bwd_nparts(int rows, int C) {
     int lpr = C <= 64 ? 16 : (C <= 128 ? 32 : 64);
-    int blocks = ceil_div(rows, ln_bwd_waves(rows, 64 / lpr) * (64 / lpr));
+    int blocks = ceil_div(rows, ln_bwd_waves(C) * (64 / lpr));
     return blocks > ln_bwd_parts() ? ln_bwd_parts() : blocks;
 }
 
