@@ -137,7 +137,9 @@ MVLT_DEV float logit_bias(const AttnDev& p, const float* kmask, const float* tbl
     if (k >= p.L) return NEG_BIG;
     if (SWIN) {
         float b = tbl[rel_index(min(q, 48), k)];
-        if (p.shift > 0 && swin_region(min(q, 48), wy, wx, p.res, p.shift) != swin_region(k, wy, wx, p.res, p.shift))
+        // wy < 0 flags an interior window: after the cyclic shift only windows of the last window
+        // row / column straddle an image border, every other window's mask is all zeros
+        if (wy >= 0 && swin_region(min(q, 48), wy, wx, p.res, p.shift) != swin_region(k, wy, wx, p.res, p.shift))
             b += -100.0f;
         return b;
     }
@@ -182,7 +184,11 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
         stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, false);
         __syncthreads();
         int wy = 0, wx = 0;
-        if (SWIN) { const int w = seq % p.nW, nwx = p.res / 7; wy = w / nwx; wx = w % nwx; }
+        if (SWIN) {
+            const int w = seq % p.nW, nwx = p.res / 7;
+            wy = w / nwx; wx = w % nwx;
+            if (p.shift == 0 || (wy != nwx - 1 && wx != nwx - 1)) wy = -1;     // no mask for this window
+        }
         for (int tq = wave; tq < p.NT; tq += 4) {
             f32x4 acc[KT];
 #pragma unroll
@@ -285,7 +291,11 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
             s.lse[q] = q < p.L ? p.lse[((long)seq * p.nH + h) * p.L + q] : 0.f;
         __syncthreads();
         int wy = 0, wx = 0;
-        if (SWIN) { const int w = seq % p.nW, nwx = p.res / 7; wy = w / nwx; wx = w % nwx; }
+        if (SWIN) {
+            const int w = seq % p.nW, nwx = p.res / 7;
+            wy = w / nwx; wx = w % nwx;
+            if (p.shift == 0 || (wy != nwx - 1 && wx != nwx - 1)) wy = -1;     // no mask for this window
+        }
 
         // ---- phase A: keys on accumulator rows, one query tile per wave -> dQ, dBias
         for (int tq = wave; tq < p.NT; tq += 4) {
