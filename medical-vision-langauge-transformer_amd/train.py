@@ -37,8 +37,22 @@ class PretrainStep:
         self.opt = FusedAdamW(model, lr=lr if lr is not None else model.config.lr, betas=(0.9, 0.999), eps=1e-6,
                               weight_decay=1e-4, grad_scale=1.0 / world_size)
         self.reducer = reducer
+        import os
+        self.hp_stream = torch.cuda.Stream(priority=-1) if os.environ.get("MVLT_HP_STREAM", "0") == "1" else None
 
     def __call__(self, batch):
+        if self.hp_stream is None:
+            return self._step(batch)
+        # critical path (forward, dgrad chain, optimizer) on a high-priority HIP stream; the weight
+        # gradients run on the default-priority side stream and fill the gaps
+        cur = torch.cuda.current_stream()
+        self.hp_stream.wait_stream(cur)
+        with torch.cuda.stream(self.hp_stream):
+            loss = self._step(batch)
+        cur.wait_stream(self.hp_stream)
+        return loss
+
+    def _step(self, batch):
         loss = self.model(*batch)
         loss.backward()
         self.opt.step()
