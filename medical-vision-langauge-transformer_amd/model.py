@@ -435,8 +435,52 @@ class MVLBertForRetrieval(MVLBertPretrainedModel):
         self.final_mlp = nn.Sequential(BertPredictionHeadTransform(config), nn.Linear(config.hidden_size, 2))
 
     def forward(self, image, caption, image_text_label=None, image_mask=None):
-        raise NotImplementedError("retrieval head is outside the MI355X hot-path scope (SURVEY.md section 2); "
-                                  "it reuses Conv_layer + MVLBert, which are drop-ins")
+        """model.py:444-476: logits = Linear(LN(GELU(dense(pooled)))); softmax prob when no label is given.
+        (The retrieval *drivers* are out of scope; the head reuses the hot path.)"""
+        Arena.of(self, compute_dtype_of(self))
+        image_feature = self.conv(image)
+        _, pooled = self.MVLBert(text_idx=caption, text_mask=None, image_feature=image_feature, image_mask=image_mask)
+        tr, lin = self.final_mlp[0], self.final_mlp[1]
+        logits = _TransformLinearFn.apply(_token(lin, pooled.device), pooled, tr, lin, torch.is_grad_enabled())
+        if image_text_label is None:
+            with torch.no_grad():
+                return ops.softmax_rows(logits.contiguous(), logits.shape[1])
+        return logits
+
+
+class _TransformLinearFn(torch.autograd.Function):
+    """BertPredictionHeadTransform (dense + GELU + LayerNorm) followed by a small Linear, f32 logits."""
+
+    @staticmethod
+    def forward(ctx, token, x, tr, lin, save):
+        ar = Arena.of(lin, x.dtype)
+        ar.refresh_shadow()
+        x = x.contiguous()
+        pre = torch.empty_like(x)
+        t1 = ops.gemm(x, ar.compute(tr.dense.weight), bias=tr.dense.bias.data, gelu=True, save_pre=pre)
+        t2, mean, rstd, _ = ops.layernorm_fwd(t1, tr.LayerNorm.weight.data, tr.LayerNorm.bias.data, tr.LayerNorm.eps,
+                                              save_stats=save)
+        V = lin.out_features
+        logits = ops.gemm(t2, ar.compute(lin.weight), bias=lin.bias.data, ldc=(V + 3) // 4 * 4)
+        ctx.mods, ctx.saved = (tr, lin), (ar, V, x, pre, t1, t2, mean, rstd) if save else None
+        return ops.cast(logits, torch.float32)[:, :V] if logits.dtype != torch.float32 else logits[:, :V]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ar, V, x, pre, t1, t2, mean, rstd = ctx.saved
+        tr, lin = ctx.mods
+        backward_begin(ar)
+        g = ar.grad_view
+        dl = dlogits.to(x.dtype).contiguous()
+        dt2 = ops.gemm(dl, ar.compute(lin.weight), b_kmajor=True)
+        ops.gemm(dl, t2, a_kmajor=True, b_kmajor=True, out=g(lin.weight), out_f32=True, a_colsum=g(lin.bias))
+        dt1 = ops.layernorm_bwd(dt2, t1, mean, rstd, tr.LayerNorm.weight.data, g(tr.LayerNorm.weight), g(tr.LayerNorm.bias))
+        dpre = ops.gelu_bwd(pre, dt1)
+        dx = ops.gemm(dpre, ar.compute(tr.dense.weight), b_kmajor=True)
+        ops.gemm(dpre, x, a_kmajor=True, b_kmajor=True, out=g(tr.dense.weight), out_f32=True, a_colsum=g(tr.dense.bias))
+        ar.mark(lin.weight, lin.bias, tr.LayerNorm.weight, tr.LayerNorm.bias, tr.dense.weight, tr.dense.bias)
+        ctx.saved = None
+        return None, dx, None, None, None
 
 
 class MVLBertForImageCaption(MVLBertPretrainedModel):

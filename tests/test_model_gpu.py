@@ -320,3 +320,44 @@ def test_cached_step_api_equals_full_forward(M, specs, cd):
             full, _ = mv(torch.cat([ids[:, :t + 1], mask], 1), None, feat, None, seq2seq_mask=True)
             assert rel_err(out.last_hidden_state[:, -1].float().cpu(), full[0][:, -1].float().cpu()) < (1e-4 if cd == F32 else 3e-2)
             pkv = tuple((k[:, :, :-1], v[:, :, :-1]) for k, v in out.past_key_values)
+
+
+# ------------------------------------------------------------------ breadth: Swin-B widths (config #5 stress), retrieval head
+def test_swin_b_widths_forward_backward_vs_oracle(M):
+    """Swin-B (embed 128, heads 4/8/16/32: C = 128..1024) through the same kernels, f32, vs the oracle."""
+    from oracle import mvlt_oracle as O
+    torch.manual_seed(3)
+    sw = M.SwinTransformer(embed_dim=128, depths=[2, 2, 2, 2], num_heads=[4, 8, 16, 32], drop_path_rate=0.0)
+    sd = {k: v.detach().clone() for k, v in sw.state_dict().items()}
+    sw = M.set_compute_dtype(sw.cuda().eval(), F32)
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(12))
+    out = sw(img.cuda())
+    assert out.shape == (2, 49, 1024)
+    w = torch.randn(2, 49, 1024, generator=torch.Generator().manual_seed(13))
+    (out.float() * w.cuda()).sum().backward()
+    osd = {k: (v.requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    cfg = O.SwinCfg(embed_dim=128, depths=(2, 2, 2, 2), num_heads=(4, 8, 16, 32), drop_path_rate=0.0)
+    ref = O.swin_forward(img, osd, "", cfg)
+    assert rel_err(out.float().cpu(), ref) < 2e-4
+    (ref * w).sum().backward()
+    for k in ("patch_embed.proj.weight", "layers.0.blocks.1.attn.relative_position_bias_table",
+              "layers.2.blocks.0.mlp.fc1.weight", "layers.3.blocks.1.attn.qkv.weight", "layers.1.downsample.reduction.weight"):
+        assert rel_err(dict(sw.named_parameters())[k].grad.cpu(), osd[k].grad) < 5e-3, k
+
+
+def test_retrieval_head_forward(M, specs):
+    from oracle import mvlt_oracle as O
+    cfg = tiny_cfg(M, cls=M.MVLBertRetrieval)
+    torch.manual_seed(4)
+    model = M.MVLBertForRetrieval(cfg)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = M.set_compute_dtype(model.cuda().eval(), F32)
+    image, ids, _, _ = synth_batch(3, 24, seed=41, vocab=3000)
+    with torch.no_grad():
+        prob = model(image.cuda(), ids.cuda())
+        scfg = O.SwinCfg(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), drop_path_rate=0.2)
+        bcfg = O.BertCfg(vocab_size=3000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024)
+        o = O.mvlbert_forward(sd, bcfg, ids, O.conv_layer(image, sd, scfg), False)
+        h = O._ln(torch.nn.functional.gelu(O._lin(o["pooled"], sd, "final_mlp.0.dense")), sd, "final_mlp.0.LayerNorm", 1e-12)
+        ref = O._lin(h, sd, "final_mlp.1").softmax(-1)
+    assert prob.shape == (3, 2) and rel_err(prob.cpu(), ref) < 2e-4
