@@ -183,7 +183,10 @@ def main():
             roofline = {"bound": "mfma", "kernel": "gemm_kernel<bf16,64,128,kmajor,kmajor> (weight-gradient GEMMs dW = dY^T X, "
                                                    "side stream, overlapped with the dgrad chain)",
                         "achieved": round(kr["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(kr["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "frac": round(kr["tflops"] / PEAK_BF16_TFLOPS, 4),
+                        # HBM bytes per launch of this kernel from rocprofv3 PMC passes of the same step
+                        # (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_dominant_kernel_traffic.md), not measured live
+                        "traffic": 9.71e7,
                         "launches": kr["launches"], "avg_launch_us": round(kr["avg_us"], 2)}
         out = {"metric": "image-text pairs/sec pretrain step (Swin-S+BERT, 224px, seq80)", "value": round(value, 2),
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
