@@ -29,7 +29,7 @@ struct AttnDev {
     const float* bias_table; int nW, res, shift;
     const int64_t* text_ids; int T; const uint8_t* image_mask; int obj_end;
     uint32_t drop_thresh; float drop_scale; uint64_t seed; uint32_t tag;
-    const void* dout; void* dqkv; float* dbias;
+    const void* dout; void* dqkv; float* dbias; float* delta_ws;
     int ld;          // LDS row stride (elements)
     int rows_alloc;  // LDS rows per image
 };
@@ -457,6 +457,203 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
     }
 }
 
+
+// ------------------------------------------------------------------ backward, split in two launches (MVLBert)
+// PHASE 0 (dQ + delta): K,V staged in full, Q,dO only the 4 query tiles of this workgroup.
+// PHASE 1 (dK, dV)    : Q,dO staged in full, K,V only the 4 key tiles of this workgroup.
+// 66 KB of LDS and half the live registers of the fused kernel -> 2 workgroups per CU, 3x the
+// workgroups (grid.z = ceil(NT/4)); delta_q = rowsum(P .* dP) goes from phase 0 to phase 1 through
+// `delta_ws` in global memory (separate launches: ordinary stream order, no in-kernel hand-off).
+template <typename T, int HD>
+MVLT_DEV void stage_one(const AttnDev& p, T* img, int which, int row0, int nrows, int seq, int h) {
+    constexpr int E = TypeInfo<T>::E;
+    constexpr int CPR = HD / E;
+    using Vec = typename TypeInfo<T>::Vec;
+    const int C = p.nH * HD;
+    const T* qkv = reinterpret_cast<const T*>(p.qkv);
+    const T* dout = reinterpret_cast<const T*>(p.dout);
+    for (int idx = threadIdx.x; idx < nrows * CPR; idx += 256) {
+        const int r = idx / CPR, ch = idx % CPR, tok = row0 + r;
+        Vec v = zero_vec<T>();
+        if (tok < p.L) {
+            if (which < 3) v = *reinterpret_cast<const Vec*>(qkv + ((long)seq * p.L + tok) * 3 * C + which * C + h * HD + ch * E);
+            else v = *reinterpret_cast<const Vec*>(dout + ((long)seq * p.L + tok) * C + h * HD + ch * E);
+        }
+        *reinterpret_cast<Vec*>(img + r * p.ld + ch * E) = v;
+    }
+}
+static size_t smem_bytes_split(int dtype, int rows_alloc, int ld) {
+    const size_t es = dtype == MVLT_BF16 ? 2 : 4;
+    return (size_t)(2 * rows_alloc + 2 * 64) * ld * es + 3 * (size_t)rows_alloc * sizeof(float);
+}
+
+template <typename T, int HD, int KT, int PHASE>
+__global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using M = Mma<T>;
+    constexpr int KBD = HD / M::KB;
+    constexpr int TPB = Tok<T>::TPB;
+    constexpr int KBT = (KT + TPB - 1) / TPB;
+    constexpr int TD = HD / 16;
+    const size_t full = (size_t)p.rows_alloc * p.ld * sizeof(T), part = (size_t)64 * p.ld * sizeof(T);
+    T* F1 = reinterpret_cast<T*>(smem_raw);                 // phase 0: K   phase 1: Q
+    T* F2 = reinterpret_cast<T*>(smem_raw + full);          // phase 0: V   phase 1: dO
+    T* P1 = reinterpret_cast<T*>(smem_raw + 2 * full);      // phase 0: Q   phase 1: K   (4 tiles)
+    T* P2 = reinterpret_cast<T*>(smem_raw + 2 * full + part);   // phase 0: dO  phase 1: V
+    float* kmask = reinterpret_cast<float*>(smem_raw + 2 * full + 2 * part);
+    float* lse_s = kmask + p.rows_alloc;
+    float* delta_s = lse_s + p.rows_alloc;
+    const int seq = blockIdx.x, h = blockIdx.y, zt0 = blockIdx.z * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c15 = lane & 15;
+    const int C = p.nH * HD;
+    T* dqkv = reinterpret_cast<T*>(p.dqkv);
+    const bool drop = p.drop_thresh != 0;
+    const long rowbase = ((long)seq * p.nH + h) * p.L;
+    if (PHASE == 0) {
+        stage_one<T, HD>(p, F1, 1, 0, p.rows_alloc, seq, h);
+        stage_one<T, HD>(p, F2, 2, 0, p.rows_alloc, seq, h);
+        stage_one<T, HD>(p, P1, 0, 16 * zt0, 64, seq, h);
+        stage_one<T, HD>(p, P2, 3, 16 * zt0, 64, seq, h);
+    } else {
+        stage_one<T, HD>(p, F1, 0, 0, p.rows_alloc, seq, h);
+        stage_one<T, HD>(p, F2, 3, 0, p.rows_alloc, seq, h);
+        stage_one<T, HD>(p, P1, 1, 16 * zt0, 64, seq, h);
+        stage_one<T, HD>(p, P2, 2, 16 * zt0, 64, seq, h);
+    }
+    stage_small<false>(p, kmask, nullptr, nullptr, seq, h, true);
+    for (int q = threadIdx.x; q < p.rows_alloc; q += 256) {
+        lse_s[q] = q < p.L ? p.lse[rowbase + q] : 0.f;
+        if (PHASE == 1) delta_s[q] = q < p.L ? p.delta_ws[rowbase + q] : 0.f;
+    }
+    __syncthreads();
+    const int tile = zt0 + wave;
+    if (tile >= p.NT) return;
+    f32x4 sc[KT], dp[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = sc[t]; }
+    typename M::Frag f1[KBD], f2[KBD];
+#pragma unroll
+    for (int kb = 0; kb < KBD; ++kb) {
+        f1[kb] = frag_rowmajor<T>(P1, p.ld, 16 * wave, kb * M::KB);
+        f2[kb] = frag_rowmajor<T>(P2, p.ld, 16 * wave, kb * M::KB);
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        if (t < p.NT) {
+#pragma unroll
+            for (int kb = 0; kb < KBD; ++kb) {
+                M::mma(sc[t], frag_rowmajor<T>(F1, p.ld, 16 * t, kb * M::KB), f1[kb]);
+                M::mma(dp[t], frag_rowmajor<T>(F2, p.ld, 16 * t, kb * M::KB), f2[kb]);
+            }
+        }
+    }
+    if (PHASE == 0) {
+        const int q = 16 * tile + c15;
+        const float lse_q = lse_s[q];
+        float dl = 0.f;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * t + 4 * g + j;
+                float pr = 0.f, dpv = 0.f;
+                if (t < p.NT && k < p.L && q < p.L) {
+                    const float lg = sc[t][j] * p.scale + logit_bias<false>(p, kmask, nullptr, q, k, 0, 0);
+                    pr = __expf(lg - lse_q);
+                    dpv = dp[t][j];
+                    if (drop) dpv = rng_keep(p.seed, p.tag, (uint32_t)((rowbase + q) * p.L + k), p.drop_thresh) ? dpv * p.drop_scale : 0.0f;
+                    dl += pr * dpv;
+                }
+                sc[t][j] = pr; dp[t][j] = dpv;
+            }
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        if (g == 0 && q < p.L) p.delta_ws[rowbase + q] = dl;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[t][j] = sc[t][j] * (dp[t][j] - dl) * p.scale;
+        f32x4 dq[TD];
+#pragma unroll
+        for (int td = 0; td < TD; ++td) dq[td] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KBT; ++kb) {
+            if (kb * TPB < p.NT) {
+                const typename M::Frag fs = frag_acc<KT>(sc, kb, T());
+#pragma unroll
+                for (int td = 0; td < TD; ++td) M::mma(dq[td], frag_tok(F1, p.ld, 16 * td, kb), fs);
+            }
+        }
+        if (q < p.L) {
+#pragma unroll
+            for (int td = 0; td < TD; ++td)
+                store4f(dqkv + ((long)seq * p.L + q) * 3 * C + h * HD + 16 * td + 4 * g, dq[td]);
+        }
+    } else {
+        const int k = 16 * tile + c15;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = 16 * t + 4 * g + j;
+                float pd = 0.f, ds = 0.f;
+                if (t < p.NT && k < p.L && q < p.L) {
+                    const float lg = sc[t][j] * p.scale + logit_bias<false>(p, kmask, nullptr, q, k, 0, 0);
+                    const float pr = __expf(lg - lse_s[q]);
+                    float dpv = dp[t][j];
+                    pd = pr;
+                    if (drop) {
+                        const bool keep = rng_keep(p.seed, p.tag, (uint32_t)((rowbase + q) * p.L + k), p.drop_thresh);
+                        dpv = keep ? dpv * p.drop_scale : 0.0f;
+                        pd = keep ? pr * p.drop_scale : 0.0f;
+                    }
+                    ds = pr * (dpv - delta_s[q]) * p.scale;
+                }
+                sc[t][j] = ds; dp[t][j] = pd;
+            }
+        f32x4 dk[TD], dv[TD];
+#pragma unroll
+        for (int td = 0; td < TD; ++td) { dk[td] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[td] = dk[td]; }
+#pragma unroll
+        for (int kb = 0; kb < KBT; ++kb) {
+            if (kb * TPB < p.NT) {
+                const typename M::Frag fs = frag_acc<KT>(sc, kb, T());
+                const typename M::Frag fp = frag_acc<KT>(dp, kb, T());
+#pragma unroll
+                for (int td = 0; td < TD; ++td) {
+                    M::mma(dk[td], frag_tok(F1, p.ld, 16 * td, kb), fs);
+                    M::mma(dv[td], frag_tok(F2, p.ld, 16 * td, kb), fp);
+                }
+            }
+        }
+        if (k < p.L) {
+#pragma unroll
+            for (int td = 0; td < TD; ++td) {
+                T* base = dqkv + ((long)seq * p.L + k) * 3 * C + h * HD + 16 * td + 4 * g;
+                store4f(base + C, dk[td]);
+                store4f(base + 2 * C, dv[td]);
+            }
+        }
+    }
+}
+
+template <typename T, int HD, int KT>
+int launch_split(const AttnDev& d, int dtype, hipStream_t s) {
+    const size_t sh = smem_bytes_split(dtype, d.rows_alloc, d.ld);
+    if (sh > 160 * 1024) return MVLT_ERR_UNSUPPORTED;
+    dim3 grid(d.nseq, d.nH, ceil_div(d.NT, 4));
+    auto k0 = attn_bwd_split_kernel<T, HD, KT, 0>;
+    auto k1 = attn_bwd_split_kernel<T, HD, KT, 1>;
+    if (sh > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    }
+    hipLaunchKernelGGL(k0, grid, dim3(256), sh, s, d);
+    hipLaunchKernelGGL(k1, grid, dim3(256), sh, s, d);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
 template <typename T, int HD, int KT, bool SWIN>
 int launch(const AttnDev& d, bool bwd, int dtype, hipStream_t s) {
     const size_t sh = smem_bytes(dtype, d.rows_alloc, d.ld, bwd);
@@ -493,6 +690,11 @@ int dispatch(AttnDev d, bool bwd, int dtype, hipStream_t s) {
         return launch<T, 32, 4, true>(d, bwd, dtype, s);
     }
     if (d.hd != 64) return MVLT_ERR_UNSUPPORTED;
+    if (bwd && d.delta_ws) {           // two-launch backward (dQ+delta, then dK/dV): 2 workgroups per CU
+        if (d.NT <= 5) return launch_split<T, 64, 5>(d, dtype, s);
+        if (d.NT <= 9) return launch_split<T, 64, 9>(d, dtype, s);
+        return MVLT_ERR_UNSUPPORTED;
+    }
     if (d.NT <= 5) return launch<T, 64, 5, false>(d, bwd, dtype, s);
     if (d.NT <= 9) return launch<T, 64, 9, false>(d, bwd, dtype, s);
     if (d.NT <= 13 && !bwd) return launch<T, 64, 13, false>(d, bwd, dtype, s);
@@ -520,7 +722,7 @@ int run(const MvltAttn* p, bool bwd, void* stream) {
     d.drop_thresh = (uint32_t)th;
     d.drop_scale = 1.0f / (1.0f - p->dropout_p);
     d.seed = p->seed; d.tag = p->tag;
-    d.dout = p->dout; d.dqkv = p->dqkv; d.dbias = p->dbias_table;
+    d.dout = p->dout; d.dqkv = p->dqkv; d.dbias = p->dbias_table; d.delta_ws = p->delta_ws;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p->dtype == MVLT_F32) return dispatch<float>(d, bwd, MVLT_F32, s);
     if (p->dtype == MVLT_BF16) return dispatch<bf16_t>(d, bwd, MVLT_BF16, s);

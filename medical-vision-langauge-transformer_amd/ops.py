@@ -352,6 +352,9 @@ def attn_bwd(dout, qkv, out, lse, mode, nseq, Lq, nH, hd, scale, dbias_table=Non
     dqkv = torch.empty_like(qkv)
     p = _attn_struct(qkv, out, lse, mode, nseq, Lq, nH, hd, scale, **kw)
     p.dout, p.dqkv = _p(dout), _p(dqkv)
+    if mode != L.ATTN_SWIN:
+        delta = torch.empty_like(lse)          # delta_q hand-over between the two backward launches
+        p.delta_ws = _p(delta)
     if dbias_table is not None:
         assert dbias_table.dtype == torch.float32
         p.dbias_table = _p(dbias_table)
