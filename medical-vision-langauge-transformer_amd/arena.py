@@ -82,7 +82,10 @@ class Arena:
         self.shadow_fresh = False
         self._flat_version = -1
         self._views: Dict[tuple, torch.Tensor] = {}
-        self.has_grad: Dict[int, bool] = {id(p): False for p in self.params}
+        self.has_grad = _EpochFlags(self.params)       # has_grad[id(p)] -> bool, reset in O(1) per backward pass
+        self._marked: List[nn.Parameter] = []
+        self._published: Optional[frozenset] = None
+        self._ranges_cache: Dict[frozenset, list] = {}
         self.steps: Dict[int, int] = {id(p): 0 for p in self.params}
         self.exp_avg: Optional[torch.Tensor] = None
         self.exp_avg_sq: Optional[torch.Tensor] = None
@@ -149,7 +152,8 @@ class Arena:
         far is final: that watermark drives the DDP bucket launches."""
         lo = None
         for p in ps:
-            self.has_grad[id(p)] = True
+            self.has_grad.set(id(p))
+            self._marked.append(p)
             o = self.offset[id(p)]
             lo = o if lo is None or o < lo else lo
         cb = self.__dict__.get("_on_watermark")
@@ -161,8 +165,8 @@ class Arena:
 
     # ------------------------------------------------------------------ per-step state
     def begin_backward(self) -> None:
-        for k in self.has_grad:
-            self.has_grad[k] = False
+        self.has_grad.clear()
+        self._marked = []
         self._watermark = self.total
         cb = self.__dict__.get("_on_backward_begin")
         if cb is not None:
@@ -171,14 +175,23 @@ class Arena:
     def publish_grads(self) -> None:
         """Expose gradients the torch way: p.grad is a view for parameters that
         received a gradient this step and None for the others (so a stock
-        torch optimizer skips them exactly as it does for the reference)."""
-        for p in self.params:
-            if self.has_grad[id(p)]:
-                if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offset[id(p)]:
-                    o, n = self.offset[id(p)], p.numel()
-                    p.grad = self.grad[o:o + n].view(p.shape)
-            elif p.grad is not None:
+        torch optimizer skips them exactly as it does for the reference).
+        Only parameters whose status changed since the previous step are touched."""
+        cur = frozenset(id(p) for p in self._marked)
+        if cur == self._published:
+            return
+        prev = self._published or frozenset()
+        byid = self.__dict__.get("_byid")
+        if byid is None:
+            byid = self._byid = {id(p): p for p in self.params}
+        for pid in cur ^ prev:
+            p = byid[pid]
+            if pid in cur:
+                o, n = self.offset[pid], p.numel()
+                p.grad = self.grad[o:o + n].view(p.shape)
+            else:
                 p.grad = None
+        self._published = cur
 
     def refresh_shadow(self) -> None:
         """bf16 compute copy <- f32 master (one pass, 6 B/param) whenever the
@@ -197,18 +210,40 @@ class Arena:
     def active_ranges(self) -> List[Tuple[int, int, int]]:
         """Maximal contiguous [start, end) element ranges of parameters that
         have a gradient and share the same optimizer step count."""
-        out: List[Tuple[int, int, int]] = []
+        out: List[List[int]] = []
         cur = None
         for p in self.params:
-            if not self.has_grad[id(p)]:
+            pid = id(p)
+            if not self.has_grad[pid]:
                 cur = None
                 continue
-            o = self.offset[id(p)]
+            o = self.offset[pid]
             e = o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-            st = self.steps[id(p)]
+            st = self.steps[pid]
             if cur is not None and cur[1] == o and cur[2] == st:
                 cur[1] = e
             else:
                 cur = [o, e, st]
                 out.append(cur)
         return [(a, b, c) for a, b, c in out]
+
+    def bump_steps(self) -> None:
+        for p in self._marked:
+            self.steps[id(p)] += 1
+
+
+class _EpochFlags:
+    """dict-like bool flags keyed by id(param) with an O(1) clear()."""
+
+    def __init__(self, params):
+        self.epoch = 1
+        self.stamp = {id(p): 0 for p in params}
+
+    def __getitem__(self, pid):
+        return self.stamp[pid] == self.epoch
+
+    def set(self, pid):
+        self.stamp[pid] = self.epoch
+
+    def clear(self):
+        self.epoch += 1

@@ -47,9 +47,9 @@ class on_side:
     def __enter__(self):
         side = side_stream(self.dev)
         side.wait_stream(torch.cuda.current_stream())
-        for t in self.tensors:
-            if t is not None:
-                t.record_stream(side)
+        # keep the operands alive until the side stream has been joined (cheaper than record_stream per
+        # tensor, and also correct under hipGraph capture where the allocator cannot see stream use)
+        _side_keepalive.append(self.tensors)
         self.prev = (_stream_cache[0], _stream_cache[1])
         _stream_cache[0], _stream_cache[1] = C.c_void_p(side.cuda_stream), "side"
 
@@ -57,11 +57,17 @@ class on_side:
         _stream_cache[0], _stream_cache[1] = self.prev
 
 
+_side_keepalive = []
+
+
 def join_side(device):
-    """Main stream waits for the side stream (end of a backward pass / before communication)."""
+    """Main stream waits for the side stream (end of a backward pass / before communication).
+    The operands kept alive for the side stream are released to the main-stream allocator only now:
+    anything that reuses their memory is ordered after this join."""
     st = _side.get(device.index)
     if st is not None:
         torch.cuda.current_stream().wait_stream(st)
+    _side_keepalive.clear()
 
 
 class pin_stream:
@@ -224,8 +230,8 @@ def layernorm_fwd(x, gamma, beta, eps, *, rows=None, C_=None, out=None, out_rowm
     p.x, p.gamma, p.beta, p.y = _p(x), _p(gamma), _p(beta), _p(y)
     mean = rstd = ypre = None
     if save_stats:
-        mean = torch.empty(nrows, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(nrows, dtype=torch.float32, device=x.device)
+        stats = torch.empty((2, nrows), dtype=torch.float32, device=x.device)
+        mean, rstd = stats[0], stats[1]
         p.mean, p.rstd = _p(mean), _p(rstd)
     if gelu:
         p.gelu = 1

@@ -42,7 +42,5 @@ class FusedAdamW:
             ops.adamw(ar.flat[lo:hi], ar.grad[lo:hi], ar.exp_avg[lo:hi], ar.exp_avg_sq[lo:hi],
                       ar.shadow[lo:hi] if ar.shadow is not None else None,
                       self.lr, b1, b2, self.eps, self.weight_decay, st + 1, self.grad_scale)
-        for p in ar.params:
-            if ar.has_grad[id(p)]:
-                ar.steps[id(p)] += 1
+        ar.bump_steps()
         ar.note_params_written_by_kernel()
