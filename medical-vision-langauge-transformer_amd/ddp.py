@@ -97,6 +97,7 @@ class GradReducer:
     def _launch(self, arena: Arena, lo: int, hi: int) -> None:
         if arena.flat.is_cuda:
             from . import ops
+            ops.LnReduceQueue.flush_all()         # LayerNorm gamma/beta gradients are reduced in deferred batches
             ops.join_side(arena.flat.device)      # weight gradients are produced on the side stream
         for a, b in plan_ranges(arena, lo, hi, self.done):
             self.handles.append(dist.all_reduce(arena.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))

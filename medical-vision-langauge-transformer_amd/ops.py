@@ -260,6 +260,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_
     if defer is not None:
         ws = defer.take(2 * lib.mvlt_layernorm_bwd_workspace_rows() * Cn, x.device)
         defer.items.append((ws, lib.mvlt_layernorm_bwd_nparts(nrows, Cn), Cn, dgamma, dbeta))
+        if defer not in LnReduceQueue._active:
+            LnReduceQueue._active.append(defer)
     else:
         ws = workspace("ln_bwd", 2 * lib.mvlt_layernorm_bwd_workspace_rows() * Cn * 4, x.device)
     p = L.MvltLayerNormBwd()
@@ -294,9 +296,16 @@ class LnReduceQueue:
     """Partial dgamma/dbeta rows of every LayerNorm of one backward pass live in one pool and are
     reduced by ceil(n/24) launches at the end (instead of one launch per LayerNorm)."""
     _pool = {}
+    _active = []          # queues with pending items (flushed early by the DDP bucket launcher)
 
     def __init__(self):
         self.items, self.off = [], 0
+
+    @staticmethod
+    def flush_all():
+        """Write every pending dgamma/dbeta now: a gradient bucket is about to be communicated."""
+        for q in list(LnReduceQueue._active):
+            q.flush()
 
     def take(self, nfloats, device):
         pool = LnReduceQueue._pool.get(device.index)
@@ -312,6 +321,8 @@ class LnReduceQueue:
         return ws
 
     def flush(self):
+        if self in LnReduceQueue._active:
+            LnReduceQueue._active.remove(self)
         if not self.items:
             return
         arr = (L.MvltLnReduceItem * len(self.items))()

@@ -361,3 +361,44 @@ def test_retrieval_head_forward(M, specs):
         h = O._ln(torch.nn.functional.gelu(O._lin(o["pooled"], sd, "final_mlp.0.dense")), sd, "final_mlp.0.LayerNorm", 1e-12)
         ref = O._lin(h, sd, "final_mlp.1").softmax(-1)
     assert prob.shape == (3, 2) and rel_err(prob.cpu(), ref) < 2e-4
+
+
+# ------------------------------------------------------------------ DDP bucket launches see final gradients
+def test_ddp_buckets_carry_final_gradients(M, specs, monkeypatch):
+    """Every gradient element must be written before the bucket that carries it is communicated
+    (weight gradients come from the side stream, LayerNorm gamma/beta from a deferred batched reduce).
+    A fake 2-rank SUM (x2, in place, on the bucket slice at launch time) stands in for RCCL: with
+    small buckets launched in the middle of the backward pass all gradients must come out exactly 2x."""
+    from mvlt_amd import ddp
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        t.mul_(2.0)
+        return _Done()
+
+    monkeypatch.setattr(ddp.dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setattr(ddp.dist, "broadcast", lambda *a, **k: None)
+    monkeypatch.setattr(ddp.dist, "get_world_size", lambda *a, **k: 2)
+    grads = []
+    for use_ddp in (False, True):
+        cfg = tiny_cfg(M, ITM_task=True)
+        cfg.ITM_task = True
+        model = M.MVLBertForPretraining(cfg)
+        load_formula(model, specs["tiny_pretrain"])
+        model = M.set_compute_dtype(model.cuda().eval(), F32)
+        red = ddp.GradReducer(model, bucket_bytes=64 << 10) if use_ddp else None
+        image, ids, labels, itm = synth_batch(3, 24, seed=41, vocab=3000)
+        monkeypatch.setattr(random, "random", lambda: 0.9)
+        for _ in range(2):       # second pass: stale values of the first one must not leak through
+            loss = model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda())
+            loss.backward()
+        torch.cuda.synchronize()
+        if red is not None:
+            assert len(red.launched) > 8          # buckets really were launched during the backward pass
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 150
+    bad = [k for k in grads[0] if not torch.allclose(grads[1][k], 2.0 * grads[0][k], rtol=1e-4, atol=1e-9)]
+    assert not bad, bad[:10]
