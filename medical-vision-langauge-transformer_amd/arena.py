@@ -67,6 +67,7 @@ class Arena:
             self.numel[id(p)] = p.numel()
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
+        self._starts: List[int] = [self.offset[id(p)] for p in self.params]      # ascending (bisect)
         self.device = dev
         self.compute_dtype = compute_dtype
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -226,6 +227,16 @@ class Arena:
                 cur = [o, e, st]
                 out.append(cur)
         return [(a, b, c) for a, b, c in out]
+
+    def params_between(self, lo: int, hi: int):
+        """Parameters that lie entirely inside the element range [lo, hi), in arena order."""
+        import bisect
+        i = bisect.bisect_left(self._starts, lo)
+        while i < len(self.params) and self._starts[i] < hi:
+            p = self.params[i]
+            if self._starts[i] + (p.numel() + ALIGN - 1) // ALIGN * ALIGN <= hi:
+                yield p
+            i += 1
 
     def bump_steps(self) -> None:
         for p in self._marked:

@@ -44,10 +44,10 @@ def plan_ranges(arena: Arena, lo: int, hi: int, done: set) -> List[Tuple[int, in
     received a gradient this step and have not been reduced yet (``done`` is
     updated)."""
     out: List[List[int]] = []
-    for p in arena.params:
+    for p in arena.params_between(lo, hi):
         o = arena.offset[id(p)]
         e = o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-        if o < lo or e > hi or not arena.has_grad[id(p)] or id(p) in done:
+        if not arena.has_grad[id(p)] or id(p) in done:
             continue
         done.add(id(p))
         if out and out[-1][1] == o:
@@ -69,6 +69,7 @@ class GradReducer:
         self.launched: List[Tuple[int, int]] = []
         self.done: set = set()
         self.pending_hi = 0
+        self.on_bucket = None      # optional consumer (ranges, handles) of a launched bucket: optim.FusedAdamW overlap
         self.attach()
 
     def attach(self) -> Arena:
@@ -99,9 +100,12 @@ class GradReducer:
             from . import ops
             ops.LnReduceQueue.flush_all()         # LayerNorm gamma/beta gradients are reduced in deferred batches
             ops.join_side(arena.flat.device)      # weight gradients are produced on the side stream
-        for a, b in plan_ranges(arena, lo, hi, self.done):
-            self.handles.append(dist.all_reduce(arena.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-            self.launched.append((a, b))
+        ranges = plan_ranges(arena, lo, hi, self.done)
+        hs = [dist.all_reduce(arena.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for a, b in ranges]
+        self.handles += hs
+        self.launched += ranges
+        if self.on_bucket is not None and ranges:
+            self.on_bucket(arena, ranges, hs)
 
     def _finish(self, arena: Arena) -> None:
         # everything not yet communicated, including parameters whose gradient

@@ -135,7 +135,11 @@ class Conv_layer(nn.Module):
     def forward(self, v):
         swin = self.conv[0]
         if torch.is_tensor(v) and v.dim() == 5:       # IU-Xray image pairs (model.py:240-253)
-            return torch.cat((swin(v[:, 0], fuse_gelu=True), swin(v[:, 1], fuse_gelu=True)), dim=1)
+            # both views go through the (shared-weight) Swin as ONE batch of n*B images: one backward pass
+            # produces the summed weight gradient, and the kernels see twice the rows
+            B, n = v.shape[0], v.shape[1]
+            f = swin(v.transpose(0, 1).reshape(n * B, *v.shape[2:]), fuse_gelu=True)       # [n*B, 49, C]
+            return f.view(n, B, f.shape[1], f.shape[2]).transpose(0, 1).reshape(B, n * f.shape[1], f.shape[2])
         return swin(v, fuse_gelu=True)
 
 

@@ -58,6 +58,29 @@ class on_side:
 
 
 _side_keepalive = []
+_opt = {}
+
+
+def opt_stream(device):
+    """Third HIP stream: AdamW of finished gradient buckets runs here while the backward pass continues."""
+    st = _opt.get(device.index)
+    if st is None:
+        st = _opt[device.index] = torch.cuda.Stream(device=device)
+    return st
+
+
+class on_stream:
+    """Context manager: launch the enclosed ops on ``stream`` (ordering is the caller's business)."""
+
+    def __init__(self, stream, tag):
+        self.stream, self.tag = stream, tag
+
+    def __enter__(self):
+        self.prev = (_stream_cache[0], _stream_cache[1])
+        _stream_cache[0], _stream_cache[1] = C.c_void_p(self.stream.cuda_stream), self.tag
+
+    def __exit__(self, *a):
+        _stream_cache[0], _stream_cache[1] = self.prev
 
 
 def join_side(device):

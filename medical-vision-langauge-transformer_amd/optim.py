@@ -7,11 +7,19 @@ pass refreshes the bf16 compute copy.  Parameters without a gradient are
 skipped entirely -- no weight decay, no moment update, own step counter --
 exactly like torch.optim.AdamW treats ``p.grad is None`` (idle MLM head,
 unused ``head`` / ``resnet_fc`` / ``embedding_LayerNorm``).
+
+``overlap_with_backward``: AdamW is HBM-bound (30 B/parameter) while the
+backward pass is MFMA-bound, so the update of a finished slice of the arena
+(everything above the backward watermark; under DDP: a bucket whose
+all-reduce has been issued) is queued on a third HIP stream while the
+backward pass continues below it.  ``step()`` then only handles what is left
+and joins the stream.  Same arithmetic, same result; only for loops that call
+``backward(); step()`` once each per batch (mvlt_amd.train.PretrainStep).
 """
 import torch
 
 from . import ops
-from .arena import Arena
+from .arena import ALIGN, Arena
 from .runtime import compute_dtype_of
 
 
@@ -21,6 +29,9 @@ class FusedAdamW:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.grad_scale = grad_scale           # 1/world_size under DDP (gradients are summed, not averaged)
         self._arena = None
+        self._overlap = None                   # dict(reducer=, chunk=) when enabled
+        self._stepped = set()                  # id(param) already updated during the current backward pass
+        self._pending_hi = 0
 
     def _state(self) -> Arena:
         ar = Arena.of(self.model, compute_dtype_of(self.model))
@@ -28,19 +39,99 @@ class FusedAdamW:
             ar.exp_avg = torch.zeros_like(ar.flat)
             ar.exp_avg_sq = torch.zeros_like(ar.flat)
             self._arena = ar
+            if self._overlap is not None:
+                self._hook(ar)
         return ar
 
     def zero_grad(self, set_to_none=True):
         """Gradients are overwritten (not accumulated) by every backward pass and
         parameters without a gradient are tracked per step, so nothing to clear."""
 
-    @torch.no_grad()
-    def step(self):
-        ar = self._state()
+    # ------------------------------------------------------------------ update of a set of element ranges
+    def _apply(self, ar: Arena, params) -> None:
+        """AdamW over ``params`` (arena order): one launch per contiguous run with equal step count."""
         b1, b2 = self.betas
-        for lo, hi, st in ar.active_ranges():
+        run = None
+        runs = []
+        for p in params:
+            pid = id(p)
+            o = ar.offset[pid]
+            e = o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            st = ar.steps[pid]
+            if run is not None and run[1] == o and run[2] == st:
+                run[1] = e
+            else:
+                run = [o, e, st]
+                runs.append(run)
+        for lo, hi, st in runs:
             ops.adamw(ar.flat[lo:hi], ar.grad[lo:hi], ar.exp_avg[lo:hi], ar.exp_avg_sq[lo:hi],
                       ar.shadow[lo:hi] if ar.shadow is not None else None,
                       self.lr, b1, b2, self.eps, self.weight_decay, st + 1, self.grad_scale)
+
+    # ------------------------------------------------------------------ overlap with the backward pass
+    def overlap_with_backward(self, reducer=None, chunk_bytes: int = 64 << 20) -> "FusedAdamW":
+        self._overlap = dict(reducer=reducer, chunk=chunk_bytes // 4)
+        self._hook(self._state())
+        return self
+
+    def _hook(self, ar: Arena) -> None:
+        red = self._overlap["reducer"]
+        if red is not None:
+            red.on_bucket = self._on_bucket
+            prev_begin = red._begin
+
+            def begin(arena, prev_begin=prev_begin):
+                prev_begin(arena)
+                self._begin(arena)
+            ar._on_backward_begin = begin
+        else:
+            ar._on_backward_begin = self._begin
+            ar._on_watermark = self._on_watermark
+
+    def _begin(self, ar: Arena) -> None:
+        self._stepped = set()
+        self._pending_hi = ar.total
+
+    def _on_watermark(self, ar: Arena, lo: int) -> None:
+        # single GPU: everything at or above the watermark has its final gradient queued
+        if self._pending_hi - lo < self._overlap["chunk"]:
+            return
+        hi, self._pending_hi = self._pending_hi, lo
+        params = [p for p in ar.params_between(lo, hi) if ar.has_grad[id(p)] and id(p) not in self._stepped]
+        if not params:
+            return
+        ops.LnReduceQueue.flush_all()                       # deferred LayerNorm gamma/beta gradients
+        st = ops.opt_stream(ar.device)
+        st.wait_stream(torch.cuda.current_stream())         # dgrad chain + flushed reductions
+        st.wait_stream(ops.side_stream(ar.device))          # weight gradients
+        with ops.on_stream(st, "opt"):
+            self._apply(ar, params)
+        self._stepped.update(id(p) for p in params)
+
+    def _on_bucket(self, ar: Arena, ranges, handles) -> None:
+        # DDP: the bucket's all-reduce has been issued; the update waits for it on the optimizer stream
+        params = [p for a, b in ranges for p in ar.params_between(a, b)
+                  if ar.has_grad[id(p)] and id(p) not in self._stepped]
+        if not params or not ar.flat.is_cuda:
+            return
+        st = ops.opt_stream(ar.device)
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            for h in handles:
+                h.wait()
+        with ops.on_stream(st, "opt"):
+            self._apply(ar, params)
+        self._stepped.update(id(p) for p in params)
+
+    # ------------------------------------------------------------------ the torch.optim-style entry point
+    @torch.no_grad()
+    def step(self):
+        ar = self._state()
+        if self._overlap is None:
+            self._apply(ar, [p for p in ar.params if ar.has_grad[id(p)]])
+        else:
+            self._apply(ar, [p for p in ar.params if ar.has_grad[id(p)] and id(p) not in self._stepped])
+            torch.cuda.current_stream().wait_stream(ops.opt_stream(ar.device))
+            self._stepped = set()
         ar.bump_steps()
         ar.note_params_written_by_kernel()

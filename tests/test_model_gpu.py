@@ -402,3 +402,77 @@ def test_ddp_buckets_carry_final_gradients(M, specs, monkeypatch):
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 150
     bad = [k for k in grads[0] if not torch.allclose(grads[1][k], 2.0 * grads[0][k], rtol=1e-4, atol=1e-9)]
     assert not bad, bad[:10]
+
+
+def test_image_pair_input_gradients_are_summed_over_both_views(M, specs):
+    """5-D input (IU-Xray pairs, model.py:240-253): the two views share the Swin weights, so the weight
+    gradient is the sum of the two single-view gradients."""
+    cfg = tiny_cfg(M)
+    conv = M.Conv_layer(cfg)
+    sd = {k[len("conv."):]: v for k, v in formula_sd(specs["tiny_pretrain"]).items() if k.startswith("conv.")}
+    conv.load_state_dict(sd, strict=False)
+    conv = M.set_compute_dtype(conv.cuda().eval(), F32)
+    g = torch.Generator().manual_seed(5)
+    pair = torch.randn(2, 2, 3, 224, 224, generator=g).cuda()
+    w = torch.randn(2, 98, 256, generator=g).cuda()
+    out = conv(pair)
+    assert out.shape == (2, 98, 256)
+    (out.float() * w).sum().backward()
+    both = {k: p.grad.clone() for k, p in conv.named_parameters() if p.grad is not None}
+    single = []
+    for i in range(2):
+        o = conv(pair[:, i].contiguous())
+        assert torch.allclose(o, out[:, 49 * i:49 * (i + 1)], rtol=1e-4, atol=1e-5)
+        (o.float() * w[:, 49 * i:49 * (i + 1)]).sum().backward()
+        single.append({k: p.grad.clone() for k, p in conv.named_parameters() if p.grad is not None})
+    assert len(both) > 100 and both.keys() == single[0].keys()
+    bad = [k for k in both if rel_err(both[k], single[0][k] + single[1][k]) > 2e-3]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("ddp_sim", [False, True])
+def test_optimizer_overlapped_with_backward_equals_plain_step(M, specs, monkeypatch, ddp_sim):
+    """AdamW slices queued during the backward pass (third stream) == AdamW after it, with and without
+    a (simulated 2-rank) gradient exchange in between."""
+    from mvlt_amd import ddp
+    from mvlt_amd.train import PretrainStep
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        t.mul_(2.0)
+        return _Done()
+
+    monkeypatch.setattr(ddp.dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setattr(ddp.dist, "broadcast", lambda *a, **k: None)
+    monkeypatch.setattr(ddp.dist, "get_world_size", lambda *a, **k: 2)
+    monkeypatch.setattr(random, "random", lambda: 0.9)
+    image, ids, labels, itm = (t.cuda() for t in synth_batch(3, 24, seed=41, vocab=3000))
+    deltas, losses = [], []
+    for overlap in (False, True):
+        cfg = tiny_cfg(M, ITM_task=True)
+        cfg.ITM_task = True
+        model = M.MVLBertForPretraining(cfg)
+        load_formula(model, specs["tiny_pretrain"])
+        model = M.set_compute_dtype(model.cuda().train(), F32)
+        M.manual_seed(7)              # counter RNG of the dropout sites
+        torch.manual_seed(3)          # DropPath keep masks come from torch's generator (like timm's DropPath)
+        init = {k: p.detach().clone() for k, p in model.named_parameters()}
+        red = ddp.GradReducer(model, bucket_bytes=64 << 10) if ddp_sim else None
+        step = PretrainStep(model, lr=1e-4, reducer=red, world_size=2 if ddp_sim else 1, overlap_optimizer=overlap)
+        if overlap and not ddp_sim:
+            step.opt._overlap["chunk"] = (64 << 10) // 4       # many slices even on the tiny model
+        losses.append([step((image, ids, labels, itm)).item() for _ in range(2)])
+        torch.cuda.synchronize()
+        deltas.append({k: (p.detach() - init[k]) for k, p in model.named_parameters()})
+    # float atomics (rel-pos bias / embedding gradients) make runs differ in the last bits, and Adam's first
+    # steps are sign-like, so compare the parameter UPDATES in norm: a slice that was skipped, stepped twice
+    # or stepped on a stale gradient shows up as an O(1) relative error of its update
+    assert all(abs(a - b) < 1e-5 * abs(a) for a, b in zip(*losses)), losses
+    # key.bias: its gradient is identically zero in exact arithmetic (softmax is shift invariant) -> pure noise
+    moved = [k for k in deltas[0] if deltas[0][k].abs().max() > 0 and not k.endswith("key.bias")]
+    assert len(moved) > 150 and all(deltas[1][k].abs().max() > 0 for k in moved)
+    bad = [(k, rel_err(deltas[1][k], deltas[0][k])) for k in moved if rel_err(deltas[1][k], deltas[0][k]) > 5e-2]
+    assert not bad, bad[:10]
