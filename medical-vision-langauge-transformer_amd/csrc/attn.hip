@@ -106,29 +106,37 @@ static size_t smem_bytes(int dtype, int rows_alloc, int ld, bool bwd) {
     return (size_t)(bwd ? 4 : 3) * rows_alloc * ld * es + (3 * (size_t)rows_alloc + 352) * sizeof(float);
 }
 
-template <typename T, int HD>
-MVLT_DEV void stage_images(const AttnDev& p, const Smem<T>& s, int seq, int h, bool bwd) {
-    constexpr int E = TypeInfo<T>::E;
-    constexpr int CPR = HD / E;                         // 16-byte chunks per row
+// Register-batched staging of one [rows x HD] head slice: all 16-byte global loads of a slice are issued
+// back to back (compile-time trip count, no load->ds_write dependency between iterations), the LDS writes
+// happen later -- for the window kernels one sequence ahead, so the next window's loads are in flight
+// while the current one is multiplied.
+template <typename T, int HD, int ROWS>
+struct Stager {
+    static constexpr int E = TypeInfo<T>::E;
+    static constexpr int CPR = HD / E;                  // 16-byte chunks per row
+    static constexpr int IT = (ROWS * CPR + 255) / 256;
     using Vec = typename TypeInfo<T>::Vec;
-    const int C = p.nH * HD;
-    const T* qkv = reinterpret_cast<const T*>(p.qkv);
-    const T* dout = reinterpret_cast<const T*>(p.dout);
-    const int nimg = bwd ? 4 : 3;
-    const int total = nimg * p.rows_alloc * CPR;
-    for (int idx = threadIdx.x; idx < total; idx += 256) {
-        const int which = idx / (p.rows_alloc * CPR);
-        const int rem = idx % (p.rows_alloc * CPR);
-        const int tok = rem / CPR, ch = rem % CPR;
-        Vec v = zero_vec<T>();
-        if (tok < p.L) {
-            if (which < 3) v = *reinterpret_cast<const Vec*>(qkv + ((long)seq * p.L + tok) * 3 * C + which * C + h * HD + ch * E);
-            else v = *reinterpret_cast<const Vec*>(dout + ((long)seq * p.L + tok) * C + h * HD + ch * E);
+    Vec r[IT];
+    // src -> (token 0 of the sequence, first column of this head); stride = elements per token
+    MVLT_DEV void load(const T* src, long stride, int row0, int nrows, int L) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int rr = idx / CPR, ch = idx % CPR, tok = row0 + rr;
+            Vec v = zero_vec<T>();
+            if (rr < nrows && tok < L) v = *reinterpret_cast<const Vec*>(src + (long)tok * stride + ch * E);
+            r[i] = v;
         }
-        T* img = which == 0 ? s.q : which == 1 ? s.k : which == 2 ? s.v : s.d;
-        *reinterpret_cast<Vec*>(img + tok * p.ld + ch * E) = v;
     }
-}
+    MVLT_DEV void store(T* img, int ld, int nrows) const {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int rr = idx / CPR, ch = idx % CPR;
+            if (rr < nrows) *reinterpret_cast<Vec*>(img + rr * ld + ch * E) = r[i];
+        }
+    }
+};
 
 // additive logit term for (query q, key k); also folds key padding
 template <bool SWIN>
@@ -178,11 +186,24 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c15 = lane & 15;
     const int C = p.nH * HD;
     T* out = reinterpret_cast<T*>(p.out);
+    const T* qkv_g = reinterpret_cast<const T*>(p.qkv);
+    Stager<T, HD, KT * 16> gq, gk, gv;
+    auto issue = [&](int sq) {
+        const T* base = qkv_g + (long)sq * p.L * 3 * C + h * HD;
+        gq.load(base, 3 * C, 0, p.rows_alloc, p.L);
+        gk.load(base + C, 3 * C, 0, p.rows_alloc, p.L);
+        gv.load(base + 2 * C, 3 * C, 0, p.rows_alloc, p.L);
+    };
+    if (SWIN && (int)blockIdx.x < p.nseq) issue(blockIdx.x);
     for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
+        if (!SWIN) issue(seq);
         __syncthreads();
-        stage_images<T, HD>(p, s, seq, h, false);
+        gq.store(s.q, p.ld, p.rows_alloc);
+        gk.store(s.k, p.ld, p.rows_alloc);
+        gv.store(s.v, p.ld, p.rows_alloc);
         stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, false);
         __syncthreads();
+        if (SWIN && seq + (int)gridDim.x < p.nseq) issue(seq + gridDim.x);      // next window in flight
         int wy = 0, wx = 0;
         if (SWIN) {
             const int w = seq % p.nW, nwx = p.res / 7;
@@ -282,14 +303,29 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
     f32x4 dbacc[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) dbacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* qkv_g = reinterpret_cast<const T*>(p.qkv);
+    Stager<T, HD, KT * 16> gq, gk, gv, gd;
+    auto issue = [&](int sq) {
+        const T* base = qkv_g + (long)sq * p.L * 3 * C + h * HD;
+        gq.load(base, 3 * C, 0, p.rows_alloc, p.L);
+        gk.load(base + C, 3 * C, 0, p.rows_alloc, p.L);
+        gv.load(base + 2 * C, 3 * C, 0, p.rows_alloc, p.L);
+        gd.load(dout + (long)sq * p.L * C + h * HD, C, 0, p.rows_alloc, p.L);
+    };
+    if (SWIN && (int)blockIdx.x < p.nseq) issue(blockIdx.x);
     for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
+        if (!SWIN) issue(seq);
         __syncthreads();
-        stage_images<T, HD>(p, s, seq, h, true);
+        gq.store(s.q, p.ld, p.rows_alloc);
+        gk.store(s.k, p.ld, p.rows_alloc);
+        gv.store(s.v, p.ld, p.rows_alloc);
+        gd.store(s.d, p.ld, p.rows_alloc);
         stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, true);
         // lse_q (delta_q = rowsum(P .* dP) is produced by phase A in registers: no O / dO pre-pass)
         for (int q = threadIdx.x; q < p.rows_alloc; q += 256)
             s.lse[q] = q < p.L ? p.lse[((long)seq * p.nH + h) * p.L + q] : 0.f;
         __syncthreads();
+        if (SWIN && seq + (int)gridDim.x < p.nseq) issue(seq + gridDim.x);      // next window in flight
         int wy = 0, wx = 0;
         if (SWIN) {
             const int w = seq % p.nW, nwx = p.res / 7;
@@ -464,24 +500,6 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
 // 66 KB of LDS and half the live registers of the fused kernel -> 2 workgroups per CU, 3x the
 // workgroups (grid.z = ceil(NT/4)); delta_q = rowsum(P .* dP) goes from phase 0 to phase 1 through
 // `delta_ws` in global memory (separate launches: ordinary stream order, no in-kernel hand-off).
-template <typename T, int HD>
-MVLT_DEV void stage_one(const AttnDev& p, T* img, int which, int row0, int nrows, int seq, int h) {
-    constexpr int E = TypeInfo<T>::E;
-    constexpr int CPR = HD / E;
-    using Vec = typename TypeInfo<T>::Vec;
-    const int C = p.nH * HD;
-    const T* qkv = reinterpret_cast<const T*>(p.qkv);
-    const T* dout = reinterpret_cast<const T*>(p.dout);
-    for (int idx = threadIdx.x; idx < nrows * CPR; idx += 256) {
-        const int r = idx / CPR, ch = idx % CPR, tok = row0 + r;
-        Vec v = zero_vec<T>();
-        if (tok < p.L) {
-            if (which < 3) v = *reinterpret_cast<const Vec*>(qkv + ((long)seq * p.L + tok) * 3 * C + which * C + h * HD + ch * E);
-            else v = *reinterpret_cast<const Vec*>(dout + ((long)seq * p.L + tok) * C + h * HD + ch * E);
-        }
-        *reinterpret_cast<Vec*>(img + r * p.ld + ch * E) = v;
-    }
-}
 static size_t smem_bytes_split(int dtype, int rows_alloc, int ld) {
     const size_t es = dtype == MVLT_BF16 ? 2 : 4;
     return (size_t)(2 * rows_alloc + 2 * 64) * ld * es + 3 * (size_t)rows_alloc * sizeof(float);
@@ -509,16 +527,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
     T* dqkv = reinterpret_cast<T*>(p.dqkv);
     const bool drop = p.drop_thresh != 0;
     const long rowbase = ((long)seq * p.nH + h) * p.L;
-    if (PHASE == 0) {
-        stage_one<T, HD>(p, F1, 1, 0, p.rows_alloc, seq, h);
-        stage_one<T, HD>(p, F2, 2, 0, p.rows_alloc, seq, h);
-        stage_one<T, HD>(p, P1, 0, 16 * zt0, 64, seq, h);
-        stage_one<T, HD>(p, P2, 3, 16 * zt0, 64, seq, h);
-    } else {
-        stage_one<T, HD>(p, F1, 0, 0, p.rows_alloc, seq, h);
-        stage_one<T, HD>(p, F2, 3, 0, p.rows_alloc, seq, h);
-        stage_one<T, HD>(p, P1, 1, 16 * zt0, 64, seq, h);
-        stage_one<T, HD>(p, P2, 2, 16 * zt0, 64, seq, h);
+    {
+        // PHASE 0: F1,F2 = K,V   P1,P2 = Q,dO     PHASE 1: F1,F2 = Q,dO   P1,P2 = K,V
+        const int C3 = 3 * p.nH * HD, C1 = p.nH * HD;
+        const T* qb = reinterpret_cast<const T*>(p.qkv) + (long)seq * p.L * C3 + h * HD;
+        const T* db = reinterpret_cast<const T*>(p.dout) + (long)seq * p.L * C1 + h * HD;
+        Stager<T, HD, KT * 16> f1, f2;
+        Stager<T, HD, 64> p1, p2;
+        if (PHASE == 0) {
+            f1.load(qb + C1, C3, 0, p.rows_alloc, p.L);
+            f2.load(qb + 2 * C1, C3, 0, p.rows_alloc, p.L);
+            p1.load(qb, C3, 16 * zt0, 64, p.L);
+            p2.load(db, C1, 16 * zt0, 64, p.L);
+        } else {
+            f1.load(qb, C3, 0, p.rows_alloc, p.L);
+            f2.load(db, C1, 0, p.rows_alloc, p.L);
+            p1.load(qb + C1, C3, 16 * zt0, 64, p.L);
+            p2.load(qb + 2 * C1, C3, 16 * zt0, 64, p.L);
+        }
+        f1.store(F1, p.ld, p.rows_alloc);
+        f2.store(F2, p.ld, p.rows_alloc);
+        p1.store(P1, p.ld, 64);
+        p2.store(P2, p.ld, 64);
     }
     stage_small<false>(p, kmask, nullptr, nullptr, seq, h, true);
     for (int q = threadIdx.x; q < p.rows_alloc; q += 256) {
