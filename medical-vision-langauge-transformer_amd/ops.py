@@ -12,7 +12,7 @@ from . import _lib as L
 
 _DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
 _ws = {}
-GEMM_TIMER = None   # bench.py: callable(flops) -> (start_event, end_event) bracketing every GEMM launch
+GEMM_TIMER = None   # bench.py: callable(flops, key) -> (start_event, end_event) or None; .layout = (a_kmajor, b_kmajor) it watches
 
 
 _stream_cache = [None, None]
@@ -202,7 +202,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
     if need:
         ws = workspace("gemm", need, A.device)
         p.workspace, p.workspace_bytes = _p(ws), ws.numel()
-    if GEMM_TIMER is not None:
+    if GEMM_TIMER is not None and GEMM_TIMER.layout == (int(a_kmajor), int(b_kmajor)):
         # bench.py: bracket the launch with HIP events on the stream it is launched on
         bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
         lib.mvlt_gemm_plan(C.byref(p), C.byref(bm), C.byref(bn), C.byref(sp))
