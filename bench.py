@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--mlm-all-rows", action="store_true")
+    ap.add_argument("--dense-rows", action="store_true",
+                    help="materialise the zero-padded caption tails like the reference (default: packed rows)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         cpu_baseline_worker()
@@ -158,7 +160,12 @@ def main():
     seed_coin_flip(5678)                            # seq2seq/bidir flip identical on all ranks
     reducer = GradReducer(model) if use_dist else None
     step = PretrainStep(model, reducer=reducer, world_size=world)
-    batch = synthetic_batch(PER_GPU_BATCH, SEQ, "cuda", 1234 + rank)
+    # captions are zero-padded to seq80 (lengths U{16..79}).  The padded tail of a caption is a
+    # masked key (bidir) / above the causal diagonal (seq2seq) and carries no label, so nothing that reaches
+    # the loss reads it: by default the BERT tower runs on packed rows, given the tokeniser's lengths on the
+    # host (same loss and gradients, tests/test_model_gpu.py::test_packed_rows_*).  --dense-rows computes the
+    # padded positions too, as the reference does.  FLOP accounting stays reference-equivalent either way.
+    batch = synthetic_batch(PER_GPU_BATCH, SEQ, "cuda", 1234 + rank, with_lengths=not args.dense_rows)
 
     for _ in range(args.warmup):
         step(batch)
@@ -203,6 +210,8 @@ def main():
                "config": {"workload": "Pretrain (MLM+ITM) Swin-S + BERT-base, batch=32/GPU, 224x224, seq80, bf16 "
                                       "storage + f32 accumulate/master, fwd+bwd+allreduce+AdamW, random-init weights",
                           "global_batch": PER_GPU_BATCH * world, "seq_len": SEQ, "parallelism": f"dp{world}",
+                          "mlm_head_rows": "all" if args.mlm_all_rows else "labelled (<=10/sample)",
+                          "bert_rows": "dense (padded)" if args.dense_rows else "packed (caption padding skipped)",
                           "loss": round(float(loss.item()), 4)},
                "step_tflops_per_gpu": round(value / world * GFLOP_PER_PAIR / 1e3, 2),
                "step_mfma_frac": round(value / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS, 4),

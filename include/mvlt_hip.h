@@ -167,6 +167,11 @@ typedef struct MvltAttn {
     float dropout_p; uint64_t seed; uint32_t tag;
     /* backward only */
     const void* dout; void* dqkv; float* dbias_table; float* delta_ws;
+    /* packed rows (optional, MVLBert modes): sequence s occupies rows [row_start[s], row_start[s]+seq_len[s])
+     * of qkv/out/dout/dqkv, seq_len[s] <= L; trailing zero-padded caption positions are simply absent
+     * (they are masked keys in BIDIR mode and lie above the causal diagonal in SEQ2SEQ mode, so no kept
+     * row ever reads them).  lse / delta_ws keep the [nseq,nH,L] layout.  NULL = dense [nseq*L] rows. */
+    const int32_t* row_start; const int32_t* seq_len;
 } MvltAttn;
 int mvlt_attn_fwd(const MvltAttn* p, void* stream);
 int mvlt_attn_bwd(const MvltAttn* p, void* stream);   /* delta_ws: f32 [nseq,nH,L] */
@@ -188,6 +193,8 @@ typedef struct MvltEmbed {
     void* out;                          /* [B, L, H] */
     /* backward */
     const void* dout; void* dimage; float* dword; float* dpos; float* dtype_emb;
+    /* packed rows (optional): sequence b is written to / read from rows row_start[b] + pos, pos < seq_len[b] */
+    const int32_t* row_start; const int32_t* seq_len;
 } MvltEmbed;
 int mvlt_embed_fwd(const MvltEmbed* p, void* stream);
 int mvlt_embed_bwd(const MvltEmbed* p, void* stream);  /* dword/dpos/dtype_emb are ACCUMULATED (zero them first) */

@@ -63,7 +63,8 @@ class MvltAttn(C.Structure):
                 ("bias_table", vp), ("nW", i32), ("win_res", i32), ("shift", i32),
                 ("text_ids", vp), ("T", i32), ("image_mask", vp), ("obj_end", i32),
                 ("dropout_p", f32), ("seed", u64), ("tag", u32),
-                ("dout", vp), ("dqkv", vp), ("dbias_table", vp), ("delta_ws", vp)]
+                ("dout", vp), ("dqkv", vp), ("dbias_table", vp), ("delta_ws", vp),
+                ("row_start", vp), ("seq_len", vp)]
 
 
 class MvltEmbed(C.Structure):
@@ -72,7 +73,8 @@ class MvltEmbed(C.Structure):
                 ("word_emb", vp), ("pos_emb", vp), ("type_emb", vp),
                 ("cls_id", i32), ("sep_id", i32), ("pos_offset", i32), ("type_override", i32),
                 ("out", vp),
-                ("dout", vp), ("dimage", vp), ("dword", vp), ("dpos", vp), ("dtype_emb", vp)]
+                ("dout", vp), ("dimage", vp), ("dword", vp), ("dpos", vp), ("dtype_emb", vp),
+                ("row_start", vp), ("seq_len", vp)]
 
 
 class MvltAttnCached(C.Structure):

@@ -103,9 +103,9 @@ class EncoderOutput(tuple):
 
 class _EncFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, token, image_feature, mod, text_idx, mask_ids, image_mask, seq2seq, save):
+    def forward(ctx, token, image_feature, mod, text_idx, mask_ids, image_mask, seq2seq, save, pack=None):
         with ops.pin_stream():
-            hidden, pooled, saved = mod._forward(image_feature, text_idx, mask_ids, image_mask, seq2seq, save)
+            hidden, pooled, saved = mod._forward(image_feature, text_idx, mask_ids, image_mask, seq2seq, save, pack)
         ctx.mod, ctx.saved = mod, saved
         ctx.set_materialize_grads(False)     # unused pooled output -> None, so the pooler gets no gradient
         if pooled is None:
@@ -118,7 +118,7 @@ class _EncFn(torch.autograd.Function):
         with ops.pin_stream():
             dimg = ctx.mod._backward(ctx.saved, dhidden, dpooled)
         ctx.saved = None
-        return None, dimg, None, None, None, None, None, None
+        return None, dimg, None, None, None, None, None, None, None
 
 
 class MVLBert(nn.Module):
@@ -176,8 +176,39 @@ class MVLBert(nn.Module):
             return (hidden[:, obj_end + 1:text_end], hidden[:, 1:obj_end], pooler_output, hidden[:, obj_end])
         return EncoderOutput(hidden), pooler_output
 
+    # ------------------------------------------------------------------ packed rows (pre-training fast path)
+    def forward_packed(self, text_idx, image_feature, text_lengths, seq2seq_mask=False):
+        """Same encoder on PACKED rows: sample b keeps positions [0, n_img + 2 + text_lengths[b]) and its
+        trailing zero-padded caption positions are not materialised at all.  Those positions are masked keys
+        in the bidirectional mode (model.py:125-128) and lie above the causal diagonal in the seq2seq mode
+        (model.py:118-123), so every kept row is computed from exactly the same operands as in the dense
+        layout; the dropped rows are the ones the reference computes and never reads (padding carries no
+        label).  ``text_lengths``: host int tensor/list [B] (tokeniser output; no device sync is needed).
+        Returns (hidden [R, H], pooled [B, H], row_start int64 [B], seq_len int32 [B]) -- the last two on the
+        device; seq_len counts [CLS] + image tokens + [SEP] + kept caption positions."""
+        cd = compute_dtype_of(self)
+        B, n_img, _ = image_feature.shape
+        T = text_idx.shape[1]
+        dev = image_feature.device
+        lens = torch.as_tensor(text_lengths, dtype=torch.int32).reshape(-1).clamp(0, T) + (n_img + 2)
+        if lens.numel() != B:
+            raise ValueError("text_lengths must have one entry per sample")
+        starts = torch.cumsum(lens, 0, dtype=torch.int32) - lens
+        R = int(lens.sum())
+        both = torch.stack((starts, lens)).pin_memory().to(dev, non_blocking=True)      # no sync: pinned, async
+        pack = (both[0], both[1], R, both[0].to(torch.int64))
+        tok = self.__dict__.get("_mvlt_token")
+        if tok is None or tok.device != dev:
+            tok = torch.zeros(1, device=dev, requires_grad=True)
+            self.__dict__["_mvlt_token"] = tok
+        text_idx = text_idx.contiguous()
+        feat = image_feature if image_feature.dtype == cd else image_feature.to(cd)
+        hidden, pooled = _EncFn.apply(tok, feat.contiguous(), self, text_idx, text_idx, None, bool(seq2seq_mask),
+                                      torch.is_grad_enabled(), pack)
+        return hidden, (pooled if self.pooler is not None else None), pack[3], pack[1]
+
     # ------------------------------------------------------------------ engine
-    def _forward(self, feat, text_idx, mask_ids, image_mask, seq2seq, save):
+    def _forward(self, feat, text_idx, mask_ids, image_mask, seq2seq, save, pack=None):
         cfg = self.config
         cd = feat.dtype
         ar = Arena.of(self, cd)
@@ -191,10 +222,14 @@ class MVLBert(nn.Module):
         p_a = cfg.attention_probs_dropout_prob if train else 0.0
         seed = next_seed() if (p_h > 0 or p_a > 0) else 0
         self.last_seed = seed
+        # pack = (row_start, seq_len, R): activations are [R, H] with the trailing zero-padded caption positions
+        # of every sample left out (forward_packed); otherwise dense [B*Lq, H]
+        rows = B * Lq if pack is None else pack[2]
         x = ops.embed_fwd(text_idx, feat, self.word_embeddings.weight.data, self.position_embeddings.weight.data,
-                          self.token_type_embeddings.weight.data, cfg.cls_token_id, cfg.sep_token_id).view(B * Lq, H)
+                          self.token_type_embeddings.weight.data, cfg.cls_token_id, cfg.sep_token_id,
+                          pack=pack).view(rows, H)
         mode = L.ATTN_SEQ2SEQ if seq2seq else L.ATTN_BIDIR
-        akw = dict(text_ids=mask_ids, image_mask=image_mask, obj_end=n_img + 1)
+        akw = dict(text_ids=mask_ids, image_mask=image_mask, obj_end=n_img + 1, pack=pack)
         layers = []
         for i, layer in enumerate(self.encoder.layer):
             sa, so = layer.attention.self, layer.attention.output
@@ -205,7 +240,7 @@ class MVLBert(nn.Module):
                           residual=x)
             x1, m1, r1, _ = ops.layernorm_fwd(y1, so.LayerNorm.weight.data, so.LayerNorm.bias.data, so.LayerNorm.eps,
                                               save_stats=save)
-            h = torch.empty((B * Lq, cfg.intermediate_size), dtype=cd, device=x.device)
+            h = torch.empty((rows, cfg.intermediate_size), dtype=cd, device=x.device)
             a = ops.gemm(x1, ar.compute(layer.intermediate.dense.weight), bias=layer.intermediate.dense.bias.data,
                          gelu=True, save_pre=h)
             y2 = ops.gemm(a, ar.compute(layer.output.dense.weight), bias=layer.output.dense.bias.data,
@@ -215,15 +250,16 @@ class MVLBert(nn.Module):
             if save:
                 layers.append((x, qkv, ctx, lse, y1, m1, r1, x1, h, a, y2, m2, r2))
             x = x2
-        hidden = x.view(B, Lq, H)
-        pooled = None
+        hidden = x.view(B, Lq, H) if pack is None else x
+        pooled = cls = None
         if self.pooler is not None:          # tanh(Linear(h[:,0]))  (modeling_bert.py:451-463)
-            pooled = ops.tanh_fwd(ops.gemm(hidden[:, 0], ar.compute(self.pooler.dense.weight),
+            cls = hidden[:, 0] if pack is None else x.index_select(0, pack[3])
+            pooled = ops.tanh_fwd(ops.gemm(cls, ar.compute(self.pooler.dense.weight),
                                            bias=self.pooler.dense.bias.data))
         saved = None
         if save:
             saved = dict(ar=ar, layers=layers, B=B, Lq=Lq, n_img=n_img, text_idx=text_idx, akw=akw, mode=mode,
-                         seed=seed, p_h=p_h, p_a=p_a, hidden=hidden, pooled=pooled)
+                         seed=seed, p_h=p_h, p_a=p_a, cls=cls, pooled=pooled, pack=pack, rows=rows)
         return hidden, pooled, saved
 
     def _backward(self, sv, dhidden, dpooled):
@@ -235,16 +271,19 @@ class MVLBert(nn.Module):
         B, Lq, H = sv["B"], sv["Lq"], cfg.hidden_size
         nH = cfg.num_attention_heads
         seed, p_h, p_a = sv["seed"], sv["p_h"], sv["p_a"]
-        dx = dhidden.contiguous().view(B * Lq, H)
+        pack, rows = sv["pack"], sv["rows"]
+        dx = dhidden.contiguous().view(rows, H)
         if dx.data_ptr() == dhidden.data_ptr() and self.pooler is not None and sv["pooled"] is not None:
             dx = dx.clone()                      # we accumulate the pooler gradient into it
         if self.pooler is not None and sv["pooled"] is not None and dpooled is not None:
             pd = self.pooler.dense
             dpre = ops.tanh_bwd(sv["pooled"], dpooled.contiguous())
-            cls = sv["hidden"][:, 0]
-            ops.gemm(dpre, cls, a_kmajor=True, b_kmajor=True, out=g(pd.weight), out_f32=True,
+            ops.gemm(dpre, sv["cls"], a_kmajor=True, b_kmajor=True, out=g(pd.weight), out_f32=True,
                      a_colsum=g(pd.bias))
-            ops.gemm(dpre, ar.compute(pd.weight), b_kmajor=True, out=dx.view(B, Lq, H)[:, 0], accumulate=True)
+            if pack is None:
+                ops.gemm(dpre, ar.compute(pd.weight), b_kmajor=True, out=dx.view(B, Lq, H)[:, 0], accumulate=True)
+            else:
+                dx.index_add_(0, pack[3], ops.gemm(dpre, ar.compute(pd.weight), b_kmajor=True))
             ar.mark(pd.weight, pd.bias)
         for i in range(len(self.encoder.layer) - 1, -1, -1):
             layer = self.encoder.layer[i]
@@ -282,8 +321,8 @@ class MVLBert(nn.Module):
         # ---- embeddings: dense f32 table gradients, like nn.Embedding in the reference
         we, pe, te = self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight
         g(we).zero_(); g(pe).zero_(); g(te).zero_()
-        dimg = ops.embed_bwd(dx.view(B, Lq, H), sv["text_idx"], sv["n_img"], we.data, pe.data, te.data,
-                             cfg.cls_token_id, cfg.sep_token_id, g(we), g(pe), g(te))
+        dimg = ops.embed_bwd(dx.view(B, Lq, H) if pack is None else dx, sv["text_idx"], sv["n_img"], we.data, pe.data,
+                             te.data, cfg.cls_token_id, cfg.sep_token_id, g(we), g(pe), g(te), pack=pack, B=B)
         ops.join_side(dx.device)
         ar.mark(we, pe, te)
         return dimg

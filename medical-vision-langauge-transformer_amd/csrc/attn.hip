@@ -30,11 +30,16 @@ struct AttnDev {
     const int64_t* text_ids; int T; const uint8_t* image_mask; int obj_end;
     uint32_t drop_thresh; float drop_scale; uint64_t seed; uint32_t tag;
     const void* dout; void* dqkv; float* dbias; float* delta_ws;
+    const int* row_start; const int* seq_len;   // packed rows (MVLBert modes), or null
     int ld;          // LDS row stride (elements)
     int rows_alloc;  // LDS rows per image
 };
 
 constexpr float NEG_BIG = -1.0e30f;
+
+// first activation row / length of sequence `seq` (dense [nseq*L] rows unless a packed layout is given)
+MVLT_DEV long seq_row0(const AttnDev& p, int seq) { return p.row_start ? (long)p.row_start[seq] : (long)seq * p.L; }
+MVLT_DEV int seq_length(const AttnDev& p, int seq) { return p.seq_len ? p.seq_len[seq] : p.L; }
 
 template <typename T> struct Tok;   // token tiles per MFMA k-block
 template <> struct Tok<bf16_t> { static constexpr int TPB = 2; };
@@ -141,8 +146,8 @@ struct Stager {
 // additive logit term for (query q, key k); also folds key padding
 template <bool SWIN>
 MVLT_DEV float logit_bias(const AttnDev& p, const float* kmask, const float* tbl, int q, int k,
-                          int wy, int wx) {
-    if (k >= p.L) return NEG_BIG;
+                          int wy, int wx, int Ls) {
+    if (k >= Ls) return NEG_BIG;
     if (SWIN) {
         float b = tbl[rel_index(min(q, 48), k)];
         // wy < 0 flags an interior window: after the cyclic shift only windows of the last window
@@ -189,13 +194,18 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
     const T* qkv_g = reinterpret_cast<const T*>(p.qkv);
     Stager<T, HD, KT * 16> gq, gk, gv;
     auto issue = [&](int sq) {
-        const T* base = qkv_g + (long)sq * p.L * 3 * C + h * HD;
-        gq.load(base, 3 * C, 0, p.rows_alloc, p.L);
-        gk.load(base + C, 3 * C, 0, p.rows_alloc, p.L);
-        gv.load(base + 2 * C, 3 * C, 0, p.rows_alloc, p.L);
+        const long r0 = seq_row0(p, sq);
+        const int ln = seq_length(p, sq);
+        const T* base = qkv_g + r0 * 3 * C + h * HD;
+        gq.load(base, 3 * C, 0, p.rows_alloc, ln);
+        gk.load(base + C, 3 * C, 0, p.rows_alloc, ln);
+        gv.load(base + 2 * C, 3 * C, 0, p.rows_alloc, ln);
     };
     if (SWIN && (int)blockIdx.x < p.nseq) issue(blockIdx.x);
     for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
+        const long rs = seq_row0(p, seq);
+        const int Ls = seq_length(p, seq);
+        const int nt = p.seq_len ? (Ls + 15) >> 4 : p.NT;
         if (!SWIN) issue(seq);
         __syncthreads();
         gq.store(s.q, p.ld, p.rows_alloc);
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
             wy = w / nwx; wx = w % nwx;
             if (p.shift == 0 || (wy != nwx - 1 && wx != nwx - 1)) wy = -1;     // no mask for this window
         }
-        for (int tq = wave; tq < p.NT; tq += 4) {
+        for (int tq = wave; tq < nt; tq += 4) {
             f32x4 acc[KT];
 #pragma unroll
             for (int t = 0; t < KT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
             for (int kb = 0; kb < KBD; ++kb) fq[kb] = frag_rowmajor<T>(s.q, p.ld, 16 * tq, kb * M::KB);
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                if (t < p.NT) {
+                if (t < nt) {
 #pragma unroll
                     for (int kb = 0; kb < KBD; ++kb)
                         M::mma(acc[t], frag_rowmajor<T>(s.k, p.ld, 16 * t, kb * M::KB), fq[kb]);
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 16 * t + 4 * g + j;
-                    float v = (t < p.NT) ? acc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx) : NEG_BIG;
+                    float v = (t < nt) ? acc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx, Ls) : NEG_BIG;
                     acc[t][j] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
-            if (g == 0 && q < p.L && p.lse) p.lse[((long)seq * p.nH + h) * p.L + q] = mx + __logf(sum);
+            if (g == 0 && q < Ls && p.lse) p.lse[((long)seq * p.nH + h) * p.L + q] = mx + __logf(sum);
             const bool drop = p.drop_thresh != 0;
 #pragma unroll
             for (int t = 0; t < KT; ++t)
@@ -265,16 +275,16 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
             for (int td = 0; td < TD; ++td) o[td] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < KBT; ++kb) {
-                if (kb * TPB < p.NT) {
+                if (kb * TPB < nt) {
                     const typename M::Frag fp = frag_acc<KT>(acc, kb, T());
 #pragma unroll
                     for (int td = 0; td < TD; ++td) M::mma(o[td], frag_tok(s.v, p.ld, 16 * td, kb), fp);
                 }
             }
-            if (q < p.L) {
+            if (q < Ls) {
 #pragma unroll
                 for (int td = 0; td < TD; ++td)
-                    store4f(out + ((long)seq * p.L + q) * C + h * HD + 16 * td + 4 * g, o[td]);
+                    store4f(out + (rs + q) * C + h * HD + 16 * td + 4 * g, o[td]);
             }
         }
     }
@@ -306,14 +316,19 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
     const T* qkv_g = reinterpret_cast<const T*>(p.qkv);
     Stager<T, HD, KT * 16> gq, gk, gv, gd;
     auto issue = [&](int sq) {
-        const T* base = qkv_g + (long)sq * p.L * 3 * C + h * HD;
-        gq.load(base, 3 * C, 0, p.rows_alloc, p.L);
-        gk.load(base + C, 3 * C, 0, p.rows_alloc, p.L);
-        gv.load(base + 2 * C, 3 * C, 0, p.rows_alloc, p.L);
-        gd.load(dout + (long)sq * p.L * C + h * HD, C, 0, p.rows_alloc, p.L);
+        const long r0 = seq_row0(p, sq);
+        const int ln = seq_length(p, sq);
+        const T* base = qkv_g + r0 * 3 * C + h * HD;
+        gq.load(base, 3 * C, 0, p.rows_alloc, ln);
+        gk.load(base + C, 3 * C, 0, p.rows_alloc, ln);
+        gv.load(base + 2 * C, 3 * C, 0, p.rows_alloc, ln);
+        gd.load(dout + r0 * C + h * HD, C, 0, p.rows_alloc, ln);
     };
     if (SWIN && (int)blockIdx.x < p.nseq) issue(blockIdx.x);
     for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
+        const long rs = seq_row0(p, seq);
+        const int Ls = seq_length(p, seq);
+        const int nt = p.seq_len ? (Ls + 15) >> 4 : p.NT;
         if (!SWIN) issue(seq);
         __syncthreads();
         gq.store(s.q, p.ld, p.rows_alloc);
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
         stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, true);
         // lse_q (delta_q = rowsum(P .* dP) is produced by phase A in registers: no O / dO pre-pass)
         for (int q = threadIdx.x; q < p.rows_alloc; q += 256)
-            s.lse[q] = q < p.L ? p.lse[((long)seq * p.nH + h) * p.L + q] : 0.f;
+            s.lse[q] = q < Ls ? p.lse[((long)seq * p.nH + h) * p.L + q] : 0.f;
         __syncthreads();
         if (SWIN && seq + (int)gridDim.x < p.nseq) issue(seq + gridDim.x);      // next window in flight
         int wy = 0, wx = 0;
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
         }
 
         // ---- phase A: keys on accumulator rows, one query tile per wave -> dQ, dBias
-        for (int tq = wave; tq < p.NT; tq += 4) {
+        for (int tq = wave; tq < nt; tq += 4) {
             f32x4 sc[KT], dp[KT];
 #pragma unroll
             for (int t = 0; t < KT; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = sc[t]; }
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
             }
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                if (t < p.NT) {
+                if (t < nt) {
 #pragma unroll
                     for (int kb = 0; kb < KBD; ++kb) {
                         M::mma(sc[t], frag_rowmajor<T>(s.k, p.ld, 16 * t, kb * M::KB), fq[kb]);
@@ -364,8 +379,8 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
                 for (int j = 0; j < 4; ++j) {
                     const int k = 16 * t + 4 * g + j;
                     float pr = 0.f, dpv = 0.f;
-                    if (t < p.NT && k < p.L && q < p.L) {
-                        const float lg = sc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx);
+                    if (t < nt && k < Ls && q < Ls) {
+                        const float lg = sc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx, Ls);
                         pr = __expf(lg - lse_q);
                         dpv = dp[t][j];
                         if (drop) {
@@ -393,22 +408,22 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
             for (int td = 0; td < TD; ++td) dq[td] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < KBT; ++kb) {
-                if (kb * TPB < p.NT) {
+                if (kb * TPB < nt) {
                     const typename M::Frag fs = frag_acc<KT>(sc, kb, T());
 #pragma unroll
                     for (int td = 0; td < TD; ++td) M::mma(dq[td], frag_tok(s.k, p.ld, 16 * td, kb), fs);
                 }
             }
-            if (q < p.L) {
+            if (q < Ls) {
 #pragma unroll
                 for (int td = 0; td < TD; ++td)
-                    store4f(dqkv + ((long)seq * p.L + q) * 3 * C + h * HD + 16 * td + 4 * g, dq[td]);
+                    store4f(dqkv + (rs + q) * 3 * C + h * HD + 16 * td + 4 * g, dq[td]);
             }
         }
 
         __syncthreads();      // delta of every query tile is in LDS
         // ---- phase B: queries on accumulator rows, one key tile per wave -> dK, dV
-        for (int tk = wave; tk < p.NT; tk += 4) {
+        for (int tk = wave; tk < nt; tk += 4) {
             f32x4 sc[KT], dp[KT];
 #pragma unroll
             for (int t = 0; t < KT; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = sc[t]; }
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
             }
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                if (t < p.NT) {
+                if (t < nt) {
 #pragma unroll
                     for (int kb = 0; kb < KBD; ++kb) {
                         M::mma(sc[t], frag_rowmajor<T>(s.q, p.ld, 16 * t, kb * M::KB), fk[kb]);
@@ -435,8 +450,8 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
                 for (int j = 0; j < 4; ++j) {
                     const int q = 16 * t + 4 * g + j;
                     float pd = 0.f, ds = 0.f;
-                    if (t < p.NT && k < p.L && q < p.L) {
-                        const float lg = sc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx);
+                    if (t < nt && k < Ls && q < Ls) {
+                        const float lg = sc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx, Ls);
                         const float pr = __expf(lg - s.lse[q]);
                         float dpv = dp[t][j];
                         pd = pr;
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
             for (int td = 0; td < TD; ++td) { dk[td] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[td] = dk[td]; }
 #pragma unroll
             for (int kb = 0; kb < KBT; ++kb) {
-                if (kb * TPB < p.NT) {
+                if (kb * TPB < nt) {
                     const typename M::Frag fs = frag_acc<KT>(sc, kb, T());
                     const typename M::Frag fp = frag_acc<KT>(dp, kb, T());
 #pragma unroll
@@ -465,10 +480,10 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
                     }
                 }
             }
-            if (k < p.L) {
+            if (k < Ls) {
 #pragma unroll
                 for (int td = 0; td < TD; ++td) {
-                    T* base = dqkv + ((long)seq * p.L + k) * 3 * C + h * HD + 16 * td + 4 * g;
+                    T* base = dqkv + (rs + k) * 3 * C + h * HD + 16 * td + 4 * g;
                     store4f(base + C, dk[td]);
                     store4f(base + 2 * C, dv[td]);
                 }
@@ -479,13 +494,14 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
         // Swin has NT == 4 == number of waves: wave w owns query tile w in every window
         const int tqw = wave;
         if (tqw < p.NT) {
+            const int Ls = p.L;
             const int q = 16 * tqw + c15;
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 16 * t + 4 * g + j;
-                    if (q < p.L && k < p.L) atomicAdd(&s.tblg[rel_index(q, k)], dbacc[t][j]);
+                    if (q < Ls && k < Ls) atomicAdd(&s.tblg[rel_index(q, k)], dbacc[t][j]);
                 }
         }
         __syncthreads();
@@ -527,23 +543,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
     T* dqkv = reinterpret_cast<T*>(p.dqkv);
     const bool drop = p.drop_thresh != 0;
     const long rowbase = ((long)seq * p.nH + h) * p.L;
+    const long rs = seq_row0(p, seq);
+    const int Ls = seq_length(p, seq);
+    const int nt = p.seq_len ? (Ls + 15) >> 4 : p.NT;
     {
         // PHASE 0: F1,F2 = K,V   P1,P2 = Q,dO     PHASE 1: F1,F2 = Q,dO   P1,P2 = K,V
         const int C3 = 3 * p.nH * HD, C1 = p.nH * HD;
-        const T* qb = reinterpret_cast<const T*>(p.qkv) + (long)seq * p.L * C3 + h * HD;
-        const T* db = reinterpret_cast<const T*>(p.dout) + (long)seq * p.L * C1 + h * HD;
+        const T* qb = reinterpret_cast<const T*>(p.qkv) + rs * C3 + h * HD;
+        const T* db = reinterpret_cast<const T*>(p.dout) + rs * C1 + h * HD;
         Stager<T, HD, KT * 16> f1, f2;
         Stager<T, HD, 64> p1, p2;
         if (PHASE == 0) {
-            f1.load(qb + C1, C3, 0, p.rows_alloc, p.L);
-            f2.load(qb + 2 * C1, C3, 0, p.rows_alloc, p.L);
-            p1.load(qb, C3, 16 * zt0, 64, p.L);
-            p2.load(db, C1, 16 * zt0, 64, p.L);
+            f1.load(qb + C1, C3, 0, p.rows_alloc, Ls);
+            f2.load(qb + 2 * C1, C3, 0, p.rows_alloc, Ls);
+            p1.load(qb, C3, 16 * zt0, 64, Ls);
+            p2.load(db, C1, 16 * zt0, 64, Ls);
         } else {
-            f1.load(qb, C3, 0, p.rows_alloc, p.L);
-            f2.load(db, C1, 0, p.rows_alloc, p.L);
-            p1.load(qb + C1, C3, 16 * zt0, 64, p.L);
-            p2.load(qb + 2 * C1, C3, 16 * zt0, 64, p.L);
+            f1.load(qb, C3, 0, p.rows_alloc, Ls);
+            f2.load(db, C1, 0, p.rows_alloc, Ls);
+            p1.load(qb + C1, C3, 16 * zt0, 64, Ls);
+            p2.load(qb + 2 * C1, C3, 16 * zt0, 64, Ls);
         }
         f1.store(F1, p.ld, p.rows_alloc);
         f2.store(F2, p.ld, p.rows_alloc);
@@ -552,12 +571,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
     }
     stage_small<false>(p, kmask, nullptr, nullptr, seq, h, true);
     for (int q = threadIdx.x; q < p.rows_alloc; q += 256) {
-        lse_s[q] = q < p.L ? p.lse[rowbase + q] : 0.f;
-        if (PHASE == 1) delta_s[q] = q < p.L ? p.delta_ws[rowbase + q] : 0.f;
+        lse_s[q] = q < Ls ? p.lse[rowbase + q] : 0.f;
+        if (PHASE == 1) delta_s[q] = q < Ls ? p.delta_ws[rowbase + q] : 0.f;
     }
     __syncthreads();
     const int tile = zt0 + wave;
-    if (tile >= p.NT) return;
+    if (tile >= nt) return;
     f32x4 sc[KT], dp[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = sc[t]; }
@@ -569,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
     }
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        if (t < p.NT) {
+        if (t < nt) {
 #pragma unroll
             for (int kb = 0; kb < KBD; ++kb) {
                 M::mma(sc[t], frag_rowmajor<T>(F1, p.ld, 16 * t, kb * M::KB), f1[kb]);
@@ -587,8 +606,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
             for (int j = 0; j < 4; ++j) {
                 const int k = 16 * t + 4 * g + j;
                 float pr = 0.f, dpv = 0.f;
-                if (t < p.NT && k < p.L && q < p.L) {
-                    const float lg = sc[t][j] * p.scale + logit_bias<false>(p, kmask, nullptr, q, k, 0, 0);
+                if (t < nt && k < Ls && q < Ls) {
+                    const float lg = sc[t][j] * p.scale + logit_bias<false>(p, kmask, nullptr, q, k, 0, 0, Ls);
                     pr = __expf(lg - lse_q);
                     dpv = dp[t][j];
                     if (drop) dpv = rng_keep(p.seed, p.tag, (uint32_t)((rowbase + q) * p.L + k), p.drop_thresh) ? dpv * p.drop_scale : 0.0f;
@@ -598,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
             }
         dl += __shfl_xor(dl, 16, 64);
         dl += __shfl_xor(dl, 32, 64);
-        if (g == 0 && q < p.L) p.delta_ws[rowbase + q] = dl;
+        if (g == 0 && q < Ls) p.delta_ws[rowbase + q] = dl;
 #pragma unroll
         for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -608,16 +627,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
         for (int td = 0; td < TD; ++td) dq[td] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < KBT; ++kb) {
-            if (kb * TPB < p.NT) {
+            if (kb * TPB < nt) {
                 const typename M::Frag fs = frag_acc<KT>(sc, kb, T());
 #pragma unroll
                 for (int td = 0; td < TD; ++td) M::mma(dq[td], frag_tok(F1, p.ld, 16 * td, kb), fs);
             }
         }
-        if (q < p.L) {
+        if (q < Ls) {
 #pragma unroll
             for (int td = 0; td < TD; ++td)
-                store4f(dqkv + ((long)seq * p.L + q) * 3 * C + h * HD + 16 * td + 4 * g, dq[td]);
+                store4f(dqkv + (rs + q) * 3 * C + h * HD + 16 * td + 4 * g, dq[td]);
         }
     } else {
         const int k = 16 * tile + c15;
@@ -627,8 +646,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
             for (int j = 0; j < 4; ++j) {
                 const int q = 16 * t + 4 * g + j;
                 float pd = 0.f, ds = 0.f;
-                if (t < p.NT && k < p.L && q < p.L) {
-                    const float lg = sc[t][j] * p.scale + logit_bias<false>(p, kmask, nullptr, q, k, 0, 0);
+                if (t < nt && k < Ls && q < Ls) {
+                    const float lg = sc[t][j] * p.scale + logit_bias<false>(p, kmask, nullptr, q, k, 0, 0, Ls);
                     const float pr = __expf(lg - lse_s[q]);
                     float dpv = dp[t][j];
                     pd = pr;
@@ -646,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
         for (int td = 0; td < TD; ++td) { dk[td] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[td] = dk[td]; }
 #pragma unroll
         for (int kb = 0; kb < KBT; ++kb) {
-            if (kb * TPB < p.NT) {
+            if (kb * TPB < nt) {
                 const typename M::Frag fs = frag_acc<KT>(sc, kb, T());
                 const typename M::Frag fp = frag_acc<KT>(dp, kb, T());
 #pragma unroll
@@ -656,10 +675,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
                 }
             }
         }
-        if (k < p.L) {
+        if (k < Ls) {
 #pragma unroll
             for (int td = 0; td < TD; ++td) {
-                T* base = dqkv + ((long)seq * p.L + k) * 3 * C + h * HD + 16 * td + 4 * g;
+                T* base = dqkv + (rs + k) * 3 * C + h * HD + 16 * td + 4 * g;
                 store4f(base + C, dk[td]);
                 store4f(base + 2 * C, dv[td]);
             }
@@ -753,6 +772,9 @@ int run(const MvltAttn* p, bool bwd, void* stream) {
     d.drop_scale = 1.0f / (1.0f - p->dropout_p);
     d.seed = p->seed; d.tag = p->tag;
     d.dout = p->dout; d.dqkv = p->dqkv; d.dbias = p->dbias_table; d.delta_ws = p->delta_ws;
+    MVLT_CHECK((p->row_start == nullptr) == (p->seq_len == nullptr), MVLT_ERR_ARG);
+    MVLT_CHECK(p->row_start == nullptr || p->mode != MVLT_ATTN_SWIN, MVLT_ERR_ARG);
+    d.row_start = p->row_start; d.seq_len = p->seq_len;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p->dtype == MVLT_F32) return dispatch<float>(d, bwd, MVLT_F32, s);
     if (p->dtype == MVLT_BF16) return dispatch<bf16_t>(d, bwd, MVLT_BF16, s);

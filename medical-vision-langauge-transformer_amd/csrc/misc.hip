@@ -36,7 +36,13 @@ struct EmbDev {
     const int64_t* text; const void* img; const float* word; const float* pos; const float* type;
     int cls_id, sep_id, pos_offset, type_override;
     void* out; const void* dout; void* dimage; float* dword; float* dpos; float* dtype_emb;
+    const int* row_start; const int* seq_len;
 };
+// row of (b, posi) in the activation matrix, -1 when the position is not materialised (packed layout)
+MVLT_DEV long emb_row(const EmbDev& p, int b, int posi) {
+    if (!p.row_start) return (long)b * p.L + posi;
+    return posi < p.seq_len[b] ? (long)p.row_start[b] + posi : -1;
+}
 
 MVLT_DEV int emb_word_id(const EmbDev& p, int b, int posi) {
     // returns word id, or -1 when the source is the image feature
@@ -56,13 +62,15 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbDev p) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % HV) * 4;
         const int posi = (int)((idx / HV) % p.L), b = (int)(idx / ((long)HV * p.L));
+        const long row = emb_row(p, b, posi);
+        if (row < 0) continue;
         const int wid = emb_word_id(p, b, posi);
         f32x4 v = wid >= 0 ? load4f(p.word + (long)wid * p.H + c)
                            : load4f(img + ((long)b * p.n_img + (posi - 1)) * p.H + c);
         const int ty = p.type_override >= 0 ? p.type_override : (posi <= p.n_img + 1 ? 1 : 0);
         v += load4f(p.type + (long)ty * p.H + c);
         v += load4f(p.pos + (long)(posi + p.pos_offset) * p.H + c);
-        store4f(out + ((long)b * p.L + posi) * p.H + c, v);
+        store4f(out + row * p.H + c, v);
     }
 }
 
@@ -76,7 +84,9 @@ __global__ __launch_bounds__(256) void embed_bwd_tokens_kernel(const EmbDev p) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % HV) * 4;
         const int posi = (int)((idx / HV) % p.L), b = (int)(idx / ((long)HV * p.L));
-        const f32x4 g = load4f(dout + ((long)b * p.L + posi) * p.H + c);
+        const long row = emb_row(p, b, posi);
+        if (row < 0) continue;
+        const f32x4 g = load4f(dout + row * p.H + c);
         const int wid = emb_word_id(p, b, posi);
         if (wid < 0) { if (dimg) store4f(dimg + ((long)b * p.n_img + (posi - 1)) * p.H + c, g); }
         else if (p.dword && posi != 0 && posi != p.n_img + 1) {
@@ -94,7 +104,10 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const EmbDev p) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % p.H), posi = (int)(idx / p.H);
         float s = 0.f;
-        for (int b = 0; b < p.B; ++b) s += to_f(dout[((long)b * p.L + posi) * p.H + c]);
+        for (int b = 0; b < p.B; ++b) {
+            const long row = emb_row(p, b, posi);
+            if (row >= 0) s += to_f(dout[row * p.H + c]);
+        }
         if (p.dpos) p.dpos[(long)(posi + p.pos_offset) * p.H + c] += s;
         if (p.dword && p.n_img >= 0) {
             if (posi == 0) atomicAdd(&p.dword[(long)p.cls_id * p.H + c], s);
@@ -379,6 +392,8 @@ static int fill_emb(const MvltEmbed* p, EmbDev& d) {
     d.text = p->text_ids; d.img = p->image_feature; d.word = p->word_emb; d.pos = p->pos_emb; d.type = p->type_emb;
     d.cls_id = p->cls_id; d.sep_id = p->sep_id; d.pos_offset = p->pos_offset; d.type_override = p->type_override;
     d.out = p->out; d.dout = p->dout; d.dimage = p->dimage; d.dword = p->dword; d.dpos = p->dpos; d.dtype_emb = p->dtype_emb;
+    MVLT_CHECK((p->row_start == nullptr) == (p->seq_len == nullptr), MVLT_ERR_ARG);
+    d.row_start = p->row_start; d.seq_len = p->seq_len;
     if (p->n_img >= 0) MVLT_CHECK(p->image_feature || p->dout, MVLT_ERR_ARG);
     return MVLT_OK;
 }

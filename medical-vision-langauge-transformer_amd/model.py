@@ -365,24 +365,39 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
         self.ITM_mlp = nn.Linear(config.hidden_size, 2)
         self.last_seq2seq = None
 
-    def forward(self, image, caption_masked, caption_label, image_text_label, image_mask=None):
+    def forward(self, image, caption_masked, caption_label, image_text_label, image_mask=None, text_lengths=None):
+        """Reference signature (model.py:372) plus one optional argument: ``text_lengths`` (host ints [B], the
+        tokeniser's caption lengths).  When given, the encoder runs on packed rows -- the zero-padded tail of
+        every caption is not materialised (MVLBert.forward_packed); loss and gradients are those of the dense
+        computation.  A non-zero id or a label at or beyond the stated length turns the loss into NaN."""
         Arena.of(self, compute_dtype_of(self))       # one arena for the whole model
         image_feature = self.conv(image)
         text_idx = caption_masked
         text_mask = None          # == (text_idx > 0); rebuilt in-kernel from the ids
         seq2seq_mask = random.random() < 0.5
         self.last_seq2seq = seq2seq_mask
-        text_out, _, pooled, _ = self.MVLBert(text_idx, text_mask, image_feature, image_mask,
-                                              seq2seq_mask=seq2seq_mask, output_text_image_seperate=True)
+        packed = text_lengths is not None and image_mask is None
+        B, T = text_idx.shape
+        n_img = image_feature.shape[1]
+        if packed:
+            hidden, pooled, row_start, seq_len = self.MVLBert.forward_packed(text_idx, image_feature, text_lengths,
+                                                                             seq2seq_mask=seq2seq_mask)
+            H = hidden.shape[1]
+            beyond = torch.arange(T, device=hidden.device)[None, :] >= (seq_len.to(torch.int64) - (n_img + 2))[:, None]
+            bad_len = (((text_idx != 0) | (caption_label.reshape(B, T) >= 0)) & beyond).any()
+        else:
+            text_out, _, pooled, _ = self.MVLBert(text_idx, text_mask, image_feature, image_mask,
+                                                  seq2seq_mask=seq2seq_mask, output_text_image_seperate=True)
+            H = text_out.shape[2]
         head = self.MLM_head_seq2seq if seq2seq_mask else self.MLM_head_bidir
         dev = image_feature.device
         mlm_loss = torch.zeros((1, 1))
         itm_loss = None
         if self.config.MLM_task:
-            B, T, H = text_out.shape
             labels = caption_label.reshape(-1).to(torch.int64).contiguous()
             cap = getattr(self.config, "mlm_max_labels_per_sample", None)
-            if cap is not None and cap * B < B * T:
+            compact = cap is not None and cap * B < B * T
+            if compact:
                 # Only labelled positions contribute to F.cross_entropy(ignore_index=-100) (model.py:410),
                 # so the MLM head (768x30522 decoder, 312 MB of f32 logits in the reference) is evaluated on
                 # a fixed-capacity gather of them: a stable sort puts labelled rows first, the padding rows
@@ -390,13 +405,24 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
                 # average would drop rows, which turns the loss into NaN instead of a silently wrong value.
                 valid = labels >= 0
                 order = torch.argsort((~valid).to(torch.int8), stable=True)[: cap * B]
-                x = text_out.reshape(B * T, H)[order]
                 sel_labels = labels[order].contiguous()
-                mlm_loss = _MlmLossFn.apply(_token(head, dev), x.contiguous(), head, sel_labels, torch.is_grad_enabled())
-                mlm_loss = torch.where(valid.sum() > cap * B, torch.full_like(mlm_loss, float("nan")), mlm_loss)
+            if packed:
+                # flat (b, t) -> packed row of caption position t; rows of unlabelled picks are clamped into
+                # range (their label is -100, whatever they gather is ignored)
+                flat = order if compact else torch.arange(B * T, device=dev)
+                b_of = torch.div(flat, T, rounding_mode="floor")
+                rows = (row_start[b_of] + (n_img + 2) + (flat - b_of * T)).clamp_(max=hidden.shape[0] - 1)
+                x = hidden[rows]
+            elif compact:
+                x = text_out.reshape(B * T, H)[order]
             else:
-                x = text_out.reshape(B * T, H).contiguous()
-                mlm_loss = _MlmLossFn.apply(_token(head, dev), x, head, labels, torch.is_grad_enabled())
+                x = text_out.reshape(B * T, H)
+            mlm_loss = _MlmLossFn.apply(_token(head, dev), x.contiguous(), head, sel_labels if compact else labels,
+                                        torch.is_grad_enabled())
+            if compact:
+                mlm_loss = torch.where(valid.sum() > cap * B, torch.full_like(mlm_loss, float("nan")), mlm_loss)
+            if packed:
+                mlm_loss = torch.where(bad_len, torch.full_like(mlm_loss, float("nan")), mlm_loss)
         if self.config.ITM_task:
             itm_loss = _LinearCEFn.apply(_token(self.ITM_mlp, dev), pooled, self.ITM_mlp,
                                          image_text_label.reshape(-1).to(torch.int64).contiguous(),

@@ -357,8 +357,11 @@ class LnReduceQueue:
 
 # ----------------------------------------------------------------------------- attention
 def _attn_struct(qkv, out, lse, mode, nseq, Lq, nH, hd, scale, *, bias_table=None, nW=0, win_res=0, shift=0,
-                 text_ids=None, image_mask=None, obj_end=0, dropout=None):
+                 text_ids=None, image_mask=None, obj_end=0, dropout=None, pack=None):
     p = L.MvltAttn()
+    if pack is not None:          # (row_start int32 [nseq], seq_len int32 [nseq], total rows): packed activations
+        assert pack[0].dtype == torch.int32 and pack[1].dtype == torch.int32 and pack[0].numel() == nseq
+        p.row_start, p.seq_len = _p(pack[0]), _p(pack[1])
     p.dtype, p.mode, p.nseq, p.L, p.nH, p.hd = _dt(qkv), mode, nseq, Lq, nH, hd
     p.qkv, p.out, p.lse, p.scale = _p(qkv), _p(out), _p(lse), float(scale)
     if bias_table is not None:
@@ -376,10 +379,12 @@ def _attn_struct(qkv, out, lse, mode, nseq, Lq, nH, hd, scale, *, bias_table=Non
 
 
 def attn_fwd(qkv, mode, nseq, Lq, nH, hd, scale, **kw):
-    """qkv: [nseq*L, 3*nH*hd] -> (out [nseq*L, nH*hd], lse [nseq,nH,L])."""
+    """qkv: [nseq*L, 3*nH*hd] -> (out [nseq*L, nH*hd], lse [nseq,nH,L]); with pack= the rows are packed
+    ([R, ...], sequence s at rows row_start[s] .. +seq_len[s])."""
     _need_cuda(qkv)
-    assert qkv.is_contiguous() and qkv.shape == (nseq * Lq, 3 * nH * hd)
-    out = torch.empty((nseq * Lq, nH * hd), dtype=qkv.dtype, device=qkv.device)
+    rows = nseq * Lq if kw.get("pack") is None else kw["pack"][2]
+    assert qkv.is_contiguous() and qkv.shape == (rows, 3 * nH * hd)
+    out = torch.empty((rows, nH * hd), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((nseq, nH, Lq), dtype=torch.float32, device=qkv.device)
     p = _attn_struct(qkv, out, lse, mode, nseq, Lq, nH, hd, scale, **kw)
     L.check(L.lib().mvlt_attn_fwd(C.byref(p), _stream()), "mvlt_attn_fwd")
@@ -425,7 +430,7 @@ def _embed_struct(dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_i
 
 
 def embed_fwd(text_ids, image_feature, word, pos, typ, cls_id, sep_id, *, dtype=None, pos_offset=0,
-              type_override=-1):
+              type_override=-1, pack=None):
     """MVLBert.get_embedding sum.  image_feature None -> cached-step (text only) layout."""
     if image_feature is not None:
         B, n_img, H = image_feature.shape
@@ -435,21 +440,28 @@ def embed_fwd(text_ids, image_feature, word, pos, typ, cls_id, sep_id, *, dtype=
         B, n_img, H = text_ids.shape[0], -1, word.shape[1]
     T = 0 if text_ids is None else text_ids.shape[1]
     Lq = T if n_img < 0 else n_img + 2 + T
-    out = torch.empty((B, Lq, H), dtype=dtype, device=word.device)
+    out = torch.empty((B, Lq, H) if pack is None else (pack[2], H), dtype=dtype, device=word.device)
     p = _embed_struct(dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_id, pos_offset, type_override)
     p.image_feature, p.out = _p(image_feature), _p(out)
+    if pack is not None:
+        p.row_start, p.seq_len = _p(pack[0]), _p(pack[1])
     L.check(L.lib().mvlt_embed_fwd(C.byref(p), _stream()), "mvlt_embed_fwd")
     return out
 
 
 def embed_bwd(dout, text_ids, n_img, word, pos, typ, cls_id, sep_id, dword, dpos, dtype_emb, *, want_dimage=True,
-              pos_offset=0, type_override=-1):
-    B, Lq, H = dout.shape
+              pos_offset=0, type_override=-1, pack=None, B=None):
+    if pack is None:
+        B, Lq, H = dout.shape
+    else:
+        H = dout.shape[1]            # dout: packed [R, H]; B given by the caller
     T = 0 if text_ids is None else text_ids.shape[1]
     dimg = torch.empty((B, n_img, H), dtype=dout.dtype, device=dout.device) if (want_dimage and n_img > 0) else None
     p = _embed_struct(dout.dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_id, pos_offset, type_override)
     assert dout.is_contiguous()
     p.dout, p.dimage, p.dword, p.dpos, p.dtype_emb = _p(dout), _p(dimg), _p(dword), _p(dpos), _p(dtype_emb)
+    if pack is not None:
+        p.row_start, p.seq_len = _p(pack[0]), _p(pack[1])
     L.check(L.lib().mvlt_embed_bwd(C.byref(p), _stream()), "mvlt_embed_bwd")
     return dimg
 

@@ -7,7 +7,7 @@ import torch
 from .optim import FusedAdamW
 
 
-def synthetic_batch(B, T, device, seed, vocab=30522, itm=True):
+def synthetic_batch(B, T, device, seed, vocab=30522, itm=True, with_lengths=False):
     """image N(0,1) [B,3,224,224]; caption ids U{1000..vocab-1}, last real id = [END]=104,
     zero padded; <=10 MLM labels per sample (20%), 80% of them replaced by [MASK]=103;
     ITM labels Bernoulli(0.5) (run_pretrain_rgc_roco_medicat.py:134-212)."""
@@ -25,7 +25,10 @@ def synthetic_batch(B, T, device, seed, vocab=30522, itm=True):
         row[pos[: max(1, int(0.8 * nm))]] = 103
         ids[b, :ln] = row
     itm_l = torch.randint(0, 2, (B,), generator=g) if itm else torch.ones(B, dtype=torch.long)
-    return tuple(t.to(device) for t in (image, ids, labels, itm_l))
+    out = tuple(t.to(device) for t in (image, ids, labels, itm_l))
+    if with_lengths:        # caption lengths as the tokeniser knows them (host side): enables packed rows
+        out += ((ids != 0).sum(1).to(torch.int32),)
+    return out
 
 
 class PretrainStep:
@@ -60,7 +63,8 @@ class PretrainStep:
         return loss
 
     def _step(self, batch):
-        loss = self.model(*batch)
+        # batch = (image, caption_masked, caption_label, image_text_label[, text_lengths (host ints)])
+        loss = self.model(*batch[:4], text_lengths=batch[4]) if len(batch) > 4 else self.model(*batch)
         loss.backward()
         self.opt.step()
         return loss

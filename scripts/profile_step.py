@@ -11,7 +11,7 @@ cfg.mlm_max_labels_per_sample = int(os.environ.get('MLM_CAP', 10)) or None   # d
 model = M.MVLBertForPretraining(cfg).cuda().train()
 M.manual_seed(1)
 step = PretrainStep(model)
-batch = synthetic_batch(B, 80, "cuda", 1234)
+batch = synthetic_batch(B, 80, "cuda", 1234, with_lengths=os.environ.get("PACK", "1") == "1")
 import random; random.seed(5678)
 for i in range(warm):
     l = step(batch)

@@ -476,3 +476,52 @@ def test_optimizer_overlapped_with_backward_equals_plain_step(M, specs, monkeypa
     assert len(moved) > 150 and all(deltas[1][k].abs().max() > 0 for k in moved)
     bad = [(k, rel_err(deltas[1][k], deltas[0][k])) for k in moved if rel_err(deltas[1][k], deltas[0][k]) > 5e-2]
     assert not bad, bad[:10]
+
+
+# ------------------------------------------------------------------ packed rows (zero-padded caption tails dropped)
+@pytest.mark.parametrize("name", ["seq2seq", "bidir"])
+def test_packed_rows_give_the_dense_loss_and_gradients(M, specs, monkeypatch, name):
+    """text_lengths -> the encoder runs on packed rows; every kept row sees the operands of the dense layout,
+    so loss and all gradients must agree with the dense run (f32: summation order only)."""
+    cfg = tiny_cfg(M, ITM_task=True)
+    cfg.ITM_task = True
+    cfg.mlm_max_labels_per_sample = 6
+    model = M.MVLBertForPretraining(cfg)
+    load_formula(model, specs["tiny_pretrain"])
+    model = M.set_compute_dtype(model.cuda().eval(), F32)
+    image, ids, labels, itm = synth_batch(5, 24, seed=43, vocab=3000)
+    lengths = (ids != 0).sum(1)
+    assert lengths.min() < 24 and (ids[torch.arange(5), lengths - 1] != 0).all()      # real padding, prefix-shaped
+    monkeypatch.setattr(random, "random", lambda: 0.1 if name == "seq2seq" else 0.9)
+    runs = []
+    for tl in (None, lengths):
+        loss = model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda(), text_lengths=tl)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = runs
+    assert abs(l0 - l1) < 2e-6 * abs(l0), (l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 150
+    bad = [(k, rel_err(g1[k], g0[k])) for k in g0
+           if rel_err(g1[k], g0[k]) > 2e-4 and not k.endswith("key.bias") and g0[k].abs().max() > 1e-9]
+    assert not bad, bad[:10]
+    # a length that cuts off real tokens must not pass silently
+    short = lengths.clone()
+    short[0] -= 1
+    assert torch.isnan(model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda(), text_lengths=short))
+
+
+def test_packed_rows_full_size_bf16(M, monkeypatch):
+    """Swin-S + BERT-base, B=8, bf16, eval mode: packed vs dense loss."""
+    from mvlt_amd.train import synthetic_batch
+    cfg = M.MVLBertPretrainConfig()
+    cfg.ITM_task = True
+    cfg.mlm_max_labels_per_sample = 10
+    torch.manual_seed(0)
+    model = M.MVLBertForPretraining(cfg).cuda().eval()
+    batch = synthetic_batch(8, 80, "cuda", 77, with_lengths=True)
+    monkeypatch.setattr(random, "random", lambda: 0.9)
+    with torch.no_grad():
+        dense = model(*batch[:4]).item()
+        packed = model(*batch[:4], text_lengths=batch[4]).item()
+    assert abs(dense - packed) < 3e-3 * abs(dense), (dense, packed)
