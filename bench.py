@@ -28,7 +28,7 @@ PEAK_BF16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PER_GPU_BATCH, SEQ = 32, 80
 
 
-DOMINANT = (1, 64, 128, 1, 1)   # gemm_kernel<bf16, BM=64, BN=128, A k-major, B k-major>: the weight-gradient
+DOMINANT = ("group", 1, 64, 128)   # gemm_kernel<bf16, BM=64, BN=128, A k-major, B k-major>: the weight-gradient
                                 # GEMM, the symbol with the largest share of GPU time (profiles/r1_*_kernel_stats.csv)
 
 
@@ -39,7 +39,7 @@ class KernelTimer:
 
     def __init__(self, key, every=8):
         self.key, self.pairs, self.flops = key, [], 0.0
-        self.layout = (key[3], key[4])
+        self.layout = (key[3], key[4]) if key[0] != "group" else None      # single-GEMM keys: operand layout watched
         self.every, self.seen = every, 0
 
     def __call__(self, flops, key):

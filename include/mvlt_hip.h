@@ -83,6 +83,12 @@ int mvlt_gemm(const MvltGemm* p, void* stream);
 size_t mvlt_gemm_workspace_bytes(const MvltGemm* p);
 /* introspection: tile (= kernel instantiation gemm_kernel<dtype,bm,bn,a_kmajor,b_kmajor>) and split-K chosen for p */
 int mvlt_gemm_plan(const MvltGemm* p, int* bm, int* bn, int* split_k);
+/* n (<= 8) independent products in ONE launch -- the weight gradients of one layer (dW_i = dY_i^T X_i, the
+ * backward of the nn.Linear calls of one SwinTransformerBlock / BertLayer).  All items must have both operands
+ * k-major, the same dtype and output widths that are all multiples of 128 or all multiples of 96; the tile
+ * lists are concatenated (gemm_group_kernel<dtype,64,bn>), no split-K, no workspace.
+ * MVLT_ERR_UNSUPPORTED if the items do not qualify (launch them one by one then). */
+int mvlt_gemm_group(const MvltGemm* items, int n, void* stream);
 
 /* column sums: out[n] = sum_m x[m*ld + n]  (bias gradients), f32 out.
  * workspace: f32 [mvlt_colsum_workspace_rows(M)][N]. */

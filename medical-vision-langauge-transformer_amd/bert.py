@@ -308,11 +308,10 @@ class MVLBert(nn.Module):
             dx_in = ops.gemm(dqkv, ar.compute(sa.query.weight, 3 * H), b_kmajor=True, residual=dy1)
             # weight / bias gradients on the side stream (off the critical path)
             with ops.on_side(dx.device, dz2, a, dh, x1, dz1, ctx, dqkv, x):
-                ops.gemm(dz2, a, a_kmajor=True, b_kmajor=True, out=g(lo.dense.weight), out_f32=True, a_colsum=g(lo.dense.bias))
-                ops.gemm(dh, x1, a_kmajor=True, b_kmajor=True, out=g(li.dense.weight), out_f32=True, a_colsum=g(li.dense.bias))
-                ops.gemm(dz1, ctx, a_kmajor=True, b_kmajor=True, out=g(so.dense.weight), out_f32=True, a_colsum=g(so.dense.bias))
-                ops.gemm(dqkv, x, a_kmajor=True, b_kmajor=True, out=g(sa.query.weight, 3 * H), out_f32=True,
-                         a_colsum=g(sa.query.bias, 3 * H))
+                ops.wgrad_group([(dz2, a, g(lo.dense.weight), g(lo.dense.bias)),
+                                 (dh, x1, g(li.dense.weight), g(li.dense.bias)),
+                                 (dz1, ctx, g(so.dense.weight), g(so.dense.bias)),
+                                 (dqkv, x, g(sa.query.weight, 3 * H), g(sa.query.bias, 3 * H))])
             dx = dx_in
             ar.mark(lo.LayerNorm.weight, lo.LayerNorm.bias, lo.dense.weight, lo.dense.bias, li.dense.weight,
                     li.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, so.dense.weight, so.dense.bias,

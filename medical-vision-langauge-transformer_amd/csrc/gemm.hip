@@ -182,28 +182,23 @@ MVLT_DEV typename Mma<T>::Frag tile_frag(const T* lds, int row0, int kb) {
     return *reinterpret_cast<const typename Mma<T>::Frag*>(lds + row * G::BKE + ch * G::E);
 }
 
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
+// L2), so give every XCD one contiguous chunk of the tile list -> neighbouring tiles (same
+// A rows / B columns) hit the same L2.  Bijective for any count; speed only.
+MVLT_DEV int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// one output tile (bx, by) of one k-split bz
 template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2>
-__global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
+MVLT_DEV void gemm_body(const GemmDev& p, const int bx, const int by, const int bz, T* sA, T* sB) {
     using GA = TileGeom<T, BM, AK>;
     using GB = TileGeom<T, BN, BK_>;
     using Vec = typename TypeInfo<T>::Vec;
     constexpr int FM = BM / 32, FN = BN / 32;
-    __shared__ __attribute__((aligned(16))) T sA[GA::ELEMS];
-    __shared__ __attribute__((aligned(16))) T sB[GB::ELEMS];
-
-    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
-    // L2), so give every XCD one contiguous chunk of the tile grid -> neighbouring tiles (same
-    // A rows / B columns) hit the same L2.  Bijective for any grid size; speed only.
-    int bx = blockIdx.x, by = blockIdx.y;
-    {
-        const int gx = gridDim.x, nwg = gx * gridDim.y;
-        const int orig = by * gx + bx;
-        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        by = t / gx; bx = t - by * gx;
-    }
     const int m0 = by * BM, n0 = bx * BN;
-    const int ks = blockIdx.z * p.k_per_split;
+    const int ks = bz * p.k_per_split;
     const int ke = min(p.K, ks + p.k_per_split);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -303,7 +298,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     if (AK && do_colsum) {
         const int m = m0 + threadIdx.x;
         if (m < p.M) {
-            if (p.split_k > 1) p.ws_colsum[(long)blockIdx.z * p.M + m] = csum;
+            if (p.split_k > 1) p.ws_colsum[(long)bz * p.M + m] = csum;
             else p.a_colsum[m] = (p.epi & MVLT_EPI_ACCUM) ? p.a_colsum[m] + csum : csum;
         }
     }
@@ -317,7 +312,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
             const int n = n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4);
             if (p.split_k > 1) {
                 if (m < p.M && n < p.N) {
-                    float* w = p.ws + ((long)blockIdx.z * p.M + m) * p.N + n;
+                    float* w = p.ws + ((long)bz * p.M + m) * p.N + n;
                     if ((p.N & 3) == 0) store4f(w, acc[i][j]);
                     else for (int r = 0; r < 4; ++r) if (n + r < p.N) w[r] = acc[i][j][r];
                 }
@@ -326,6 +321,35 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
             }
         }
     }
+}
+
+template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2>
+__global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
+    __shared__ __attribute__((aligned(16))) T sA[TileGeom<T, BM, AK>::ELEMS];
+    __shared__ __attribute__((aligned(16))) T sB[TileGeom<T, BN, BK_>::ELEMS];
+    const int gx = gridDim.x;
+    const int t = xcd_remap(blockIdx.y * gx + blockIdx.x, gx * gridDim.y);
+    const int by = t / gx;
+    gemm_body<T, BM, BN, AK, BK_, PF2>(p, t - by * gx, by, blockIdx.z, sA, sB);
+}
+
+// Several independent products in one launch (the weight gradients of one layer): the tile lists of the
+// items are concatenated, a workgroup finds its item by a scan of the (<= 8) prefix counts.
+constexpr int GROUP_MAX = 8;
+struct GemmGroupDev { int n; int start[GROUP_MAX + 1]; GemmDev g[GROUP_MAX]; };
+
+template <typename T, int BM, int BN, bool AK, bool BK_>
+__global__ __launch_bounds__(256, 3) void gemm_group_kernel(const GemmGroupDev gp) {
+    __shared__ __attribute__((aligned(16))) T sA[TileGeom<T, BM, AK>::ELEMS];
+    __shared__ __attribute__((aligned(16))) T sB[TileGeom<T, BN, BK_>::ELEMS];
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    int i = 0;
+    while (i + 1 < gp.n && t >= gp.start[i + 1]) ++i;
+    const GemmDev& p = gp.g[i];
+    const int local = t - gp.start[i];
+    const int gx = (p.N + BN - 1) / BN;
+    const int by = local / gx;
+    gemm_body<T, BM, BN, AK, BK_, false>(p, local - by * gx, by, 0, sA, sB);
 }
 
 // slabs -> output: 64 output quads per block, the slabs are shared out over 4 waves and combined in LDS
@@ -431,10 +455,9 @@ extern "C" int mvlt_gemm_plan(const MvltGemm* p, int* bm, int* bn, int* split_k)
     return MVLT_OK;
 }
 
+// MvltGemm -> kernel argument block for a given plan
 template <typename T>
-static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
-    Plan pl = choose_plan(p);
-    GemmDev d;
+static int fill_dev(const MvltGemm* p, const Plan& pl, GemmDev& d) {
     d.M = p->M; d.N = p->N; d.K = p->K;
     d.A = p->A; d.lda = p->lda; d.B = p->B; d.ldb = p->ldb; d.C = p->C; d.ldc = p->ldc;
     d.epi = p->epilogue; d.bias = p->bias; d.pre = p->pre; d.residual = p->residual; d.ldr = p->ldr;
@@ -467,6 +490,14 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     if (epi & MVLT_EPI_SAVE_PRE) ev = ev && aligned16(p->pre);
     if (epi & MVLT_EPI_MUL_GELU_GRAD) ev = ev && aligned16(p->aux);
     d.epi_vec = ev;
+    return MVLT_OK;
+}
+
+template <typename T>
+static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
+    Plan pl = choose_plan(p);
+    GemmDev d;
+    { const int rc = fill_dev<T>(p, pl, d); if (rc != MVLT_OK) return rc; }
     dim3 grid(ceil_div(p->N, pl.bn), ceil_div(p->M, pl.bm), d.split_k);
     const bool ak = p->a_kmajor != 0, bk = p->b_kmajor != 0;
     if (pl.bm == 128 && pl.bn == 128) launch_layout<T, 128, 128>(d, ak, bk, grid, s);
@@ -486,7 +517,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     return MVLT_OK;
 }
 
-extern "C" int mvlt_gemm(const MvltGemm* p, void* stream) {
+static int check_gemm_args(const MvltGemm* p) {
     MVLT_CHECK(p && p->A && p->B && p->C, MVLT_ERR_ARG);
     MVLT_CHECK(p->M > 0 && p->N > 0 && p->K > 0, MVLT_ERR_ARG);
     MVLT_CHECK(p->lda > 0 && p->ldb > 0 && p->ldc >= p->N, MVLT_ERR_ARG);
@@ -500,6 +531,44 @@ extern "C" int mvlt_gemm(const MvltGemm* p, void* stream) {
     if (e & MVLT_EPI_MUL_GELU_GRAD) MVLT_CHECK(p->aux, MVLT_ERR_ARG);
     if (e & MVLT_EPI_DROPOUT) MVLT_CHECK(p->dropout_p >= 0.f && p->dropout_p < 1.f, MVLT_ERR_ARG);
     if (p->a_colsum) MVLT_CHECK(p->a_kmajor, MVLT_ERR_ARG);
+    return MVLT_OK;
+}
+
+// Grouped launch: weight gradients only (both operands k-major), 64-row tiles, no split-K.
+template <typename T>
+static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
+    GemmGroupDev g{};
+    g.n = n;
+    int bn = 0;
+    for (int i = 0; i < n; ++i) {
+        const MvltGemm* p = items + i;
+        MVLT_CHECK(p->a_kmajor && p->b_kmajor && p->dtype == items[0].dtype, MVLT_ERR_UNSUPPORTED);
+        const int want = (p->N % 128 == 0) ? 128 : (p->N % 96 == 0 ? 96 : 0);
+        MVLT_CHECK(want != 0 && (bn == 0 || bn == want), MVLT_ERR_UNSUPPORTED);
+        bn = want;
+        Plan pl{64, bn, 1};
+        { const int rc = fill_dev<T>(p, pl, g.g[i]); if (rc != MVLT_OK) return rc; }
+        g.start[i] = i == 0 ? 0 : g.start[i];
+        g.start[i + 1] = g.start[i] + ceil_div(p->M, 64) * ceil_div(p->N, bn);
+    }
+    const int total = g.start[n];
+    if (bn == 128) hipLaunchKernelGGL((gemm_group_kernel<T, 64, 128, true, true>), dim3(total), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_group_kernel<T, 64, 96, true, true>), dim3(total), dim3(256), 0, s, g);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_gemm_group(const MvltGemm* items, int n, void* stream) {
+    MVLT_CHECK(items && n >= 1 && n <= GROUP_MAX, MVLT_ERR_ARG);
+    for (int i = 0; i < n; ++i) { const int rc = check_gemm_args(items + i); if (rc != MVLT_OK) return rc; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (items[0].dtype == MVLT_F32) return gemm_group_dispatch<float>(items, n, s);
+    if (items[0].dtype == MVLT_BF16) return gemm_group_dispatch<bf16_t>(items, n, s);
+    return MVLT_ERR_UNSUPPORTED;
+}
+
+extern "C" int mvlt_gemm(const MvltGemm* p, void* stream) {
+    { const int rc = check_gemm_args(p); if (rc != MVLT_OK) return rc; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p->dtype == MVLT_F32) return gemm_dispatch<float>(p, s);
     if (p->dtype == MVLT_BF16) return gemm_dispatch<bf16_t>(p, s);

@@ -220,6 +220,45 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
     return out
 
 
+def wgrad_group(items):
+    """Weight gradients of one layer: items = [(dY [R,No], X [R,Ni], dW f32 [No,Ni], dbias f32 [No] | None), ...]
+    -> dW_i = dY_i^T X_i (and dbias_i = column sums of dY_i).  When the items qualify (mvlt_gemm_group) and
+    their 64-row tiles together fill the GPU, they go out as ONE launch without split-K -- instead of
+    len(items) split-K launches plus their reduce kernels; otherwise one gemm() each."""
+    lib = L.lib()
+    n = len(items)
+    bn = 128 if all(x.shape[1] % 128 == 0 for _, x, _, _ in items) else (96 if all(x.shape[1] % 96 == 0 for _, x, _, _ in items) else 0)
+    tiles = sum(((dy.shape[1] + 63) // 64) * ((x.shape[1] + bn - 1) // bn) for dy, x, _, _ in items) if bn else 0
+    if not (1 < n <= 8 and bn and tiles >= 200):
+        for dy, x, dw, db in items:
+            gemm(dy, x, a_kmajor=True, b_kmajor=True, out=dw, out_f32=True, a_colsum=db)
+        return
+    arr = (L.MvltGemm * n)()
+    flops = 0.0
+    for i, (dy, x, dw, db) in enumerate(items):
+        _need_cuda(dy, x)
+        assert dy.dtype == x.dtype and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0]
+        assert dw.dtype == torch.float32 and dw.shape == (dy.shape[1], x.shape[1]) and dw.stride(1) == 1
+        p = arr[i]
+        p.dtype, p.M, p.N, p.K = _dt(dy), dy.shape[1], x.shape[1], dy.shape[0]
+        p.A, p.lda, p.a_kmajor = _p(dy), dy.stride(0), 1
+        p.B, p.ldb, p.b_kmajor = _p(x), x.stride(0), 1
+        p.C, p.ldc = _p(dw), dw.stride(0)
+        p.epilogue, p.split_k = L.EPI_OUT_F32, 1
+        if db is not None:
+            assert db.dtype == torch.float32 and db.numel() == dy.shape[1]
+            p.a_colsum = _p(db)
+        flops += 2.0 * p.M * p.N * p.K
+    evs = GEMM_TIMER(flops, ("group", arr[0].dtype, 64, bn)) if GEMM_TIMER is not None else None
+    st = None
+    if evs is not None:
+        st = side_stream(items[0][0].device) if _stream_cache[1] == "side" else torch.cuda.current_stream()
+        evs[0].record(st)
+    L.check(lib.mvlt_gemm_group(arr, n, _stream()), "mvlt_gemm_group")
+    if evs is not None:
+        evs[1].record(st)
+
+
 def colsum(x, out=None, accumulate=False):
     """out[n] = sum_m x[m,n] (f32) -- bias gradients."""
     _need_cuda(x)

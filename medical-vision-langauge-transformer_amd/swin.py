@@ -346,10 +346,10 @@ class SwinTransformer(nn.Module):
                                 g(blk.norm1.bias), dy_rowmap=n2w, dres=dx1, defer=self.__dict__["_lnq"])
         # ---- weight / bias gradients (only the optimizer consumes them): side stream, overlapping the next block
         with ops.on_side(dx2.device, dy2, a, dh, xn2, dyw, ao, dqkv, xn1w):
-            ops.gemm(dy2, a, a_kmajor=True, b_kmajor=True, out=g(mlp.fc2.weight), out_f32=True, a_colsum=g(mlp.fc2.bias))
-            ops.gemm(dh, xn2, a_kmajor=True, b_kmajor=True, out=g(mlp.fc1.weight), out_f32=True, a_colsum=g(mlp.fc1.bias))
-            ops.gemm(dyw, ao, a_kmajor=True, b_kmajor=True, out=g(at.proj.weight), out_f32=True, a_colsum=g(at.proj.bias))
-            ops.gemm(dqkv, xn1w, a_kmajor=True, b_kmajor=True, out=g(at.qkv.weight), out_f32=True, a_colsum=g(at.qkv.bias))
+            ops.wgrad_group([(dy2, a, g(mlp.fc2.weight), g(mlp.fc2.bias)),
+                             (dh, xn2, g(mlp.fc1.weight), g(mlp.fc1.bias)),
+                             (dyw, ao, g(at.proj.weight), g(at.proj.bias)),
+                             (dqkv, xn1w, g(at.qkv.weight), g(at.qkv.bias))])
         ar.mark(mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, blk.norm1.weight, blk.norm1.bias,
                 blk.norm2.weight, blk.norm2.bias, at.qkv.weight, at.qkv.bias, at.proj.weight, at.proj.bias,
                 at.relative_position_bias_table)

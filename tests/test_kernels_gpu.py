@@ -111,6 +111,28 @@ def test_gemm_epilogues(ops, dt):
     assert rel(out, hf.grad) < tol(dt)
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("widths,R", [([(768, 3072), (3072, 768), (768, 768), (2304, 768)], 1573),      # one BERT layer, ragged R
+                                      ([(384, 1536), (1536, 384), (384, 384), (1152, 384)], 6272),      # one Swin stage-2 block
+                                      ([(192, 768), (768, 192), (192, 192), (576, 192)], 1000),         # widths multiple of 96 only
+                                      ([(96, 384), (384, 96)], 500)])                                   # too few tiles -> one by one
+def test_wgrad_group(ops, dt, widths, R):
+    """mvlt_gemm_group: the weight gradients of one layer in one launch == the products one by one."""
+    items, refs = [], []
+    for i, (no, ni) in enumerate(widths):
+        dy, x = rnd((R, no), dt, 10 + i, 0.5), rnd((R, ni), dt, 20 + i, 0.5)
+        dw = torch.full((no, ni), float("nan"), device="cuda")
+        db = torch.full((no,), float("nan"), device="cuda") if i != 2 else None
+        items.append((dy, x, dw, db))
+        refs.append((dy.float().t() @ x.float(), dy.float().sum(0)))
+    ops.wgrad_group(items)
+    torch.cuda.synchronize()
+    for (dy, x, dw, db), (rw, rb) in zip(items, refs):
+        assert rel(dw, rw) < tol(dt)
+        if db is not None:
+            assert rel(db, rb) < tol(dt)
+
+
 def test_gemm_bad_args(ops):
     A = torch.zeros(4, 4, device="cuda")
     with pytest.raises(AssertionError):
