@@ -342,14 +342,19 @@ template <typename T, int BM, int BN, bool AK, bool BK_>
 __global__ __launch_bounds__(256, 3) void gemm_group_kernel(const GemmGroupDev gp) {
     __shared__ __attribute__((aligned(16))) T sA[TileGeom<T, BM, AK>::ELEMS];
     __shared__ __attribute__((aligned(16))) T sB[TileGeom<T, BN, BK_>::ELEMS];
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    int i = 0;
-    while (i + 1 < gp.n && t >= gp.start[i + 1]) ++i;
-    const GemmDev& p = gp.g[i];
-    const int local = t - gp.start[i];
-    const int gx = (p.N + BN - 1) / BN;
-    const int by = local / gx;
-    gemm_body<T, BM, BN, AK, BK_, false>(p, local - by * gx, by, 0, sA, sB);
+    // persistent: the grid may be smaller than the tile list (the launcher caps the workgroups per CU so the
+    // dgrad chain on the main stream keeps most of every CU); gemm_body ends on a barrier, so LDS is reusable
+    const int total = gp.start[gp.n];
+    for (int t0 = blockIdx.x; t0 < total; t0 += gridDim.x) {
+        const int t = xcd_remap(t0, total);
+        int i = 0;
+        while (i + 1 < gp.n && t >= gp.start[i + 1]) ++i;
+        const GemmDev& p = gp.g[i];
+        const int local = t - gp.start[i];
+        const int gx = (p.N + BN - 1) / BN;
+        const int by = local / gx;
+        gemm_body<T, BM, BN, AK, BK_, false>(p, local - by * gx, by, 0, sA, sB);
+    }
 }
 
 // slabs -> output: 64 output quads per block, the slabs are shared out over 4 waves and combined in LDS
@@ -551,7 +556,11 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
         g.start[i] = i == 0 ? 0 : g.start[i];
         g.start[i + 1] = g.start[i] + ceil_div(p->M, 64) * ceil_div(p->N, bn);
     }
-    const int total = g.start[n];
+    // at most 2 workgroups per CU (of the 3 that fit): the group runs on the side stream beside the dgrad
+    // chain, which should keep a share of every CU (16.8 vs 17.1 ms/step uncapped; MVLT_GROUP_WGS=n overrides, 0 = no cap)
+    int total = g.start[n], per_cu = 2;
+    if (const char* ov = getenv("MVLT_GROUP_WGS")) per_cu = atoi(ov);
+    if (per_cu > 0 && total > per_cu * 256) total = per_cu * 256;
     if (bn == 128) hipLaunchKernelGGL((gemm_group_kernel<T, 64, 128, true, true>), dim3(total), dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_group_kernel<T, 64, 96, true, true>), dim3(total), dim3(256), 0, s, g);
     MVLT_LAUNCH_CHECK();
