@@ -252,6 +252,8 @@ typedef struct MvltAttnCached {
     void* k_cache; void* v_cache;       /* [B, nH, cache_cap, hd]; new K/V appended at `past` */
     void* out;                          /* [B*n_new, nH*hd] */
     float scale;
+    const int32_t* past_dev;            /* optional: `past` read from device memory instead (a decode loop that
+                                           is replayed without host involvement keeps its position on the GPU) */
 } MvltAttnCached;
 int mvlt_attn_cached(const MvltAttnCached* p, void* stream);
 /* argmax over V of logits [rows, ld] -> int64 ids (greedy_search, model.py:896-900) */

@@ -80,7 +80,7 @@ class MvltEmbed(C.Structure):
 class MvltAttnCached(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("nH", i32), ("hd", i32), ("past", i32), ("n_new", i32),
                 ("cache_cap", i32),
-                ("qkv_new", vp), ("k_cache", vp), ("v_cache", vp), ("out", vp), ("scale", f32)]
+                ("qkv_new", vp), ("k_cache", vp), ("v_cache", vp), ("out", vp), ("scale", f32), ("past_dev", vp)]
 
 
 # every symbol include/mvlt_hip.h declares: name -> (restype, argtypes)

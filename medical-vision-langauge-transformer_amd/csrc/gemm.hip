@@ -333,6 +333,49 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     gemm_body<T, BM, BN, AK, BK_, PF2>(p, t - by * gx, by, blockIdx.z, sA, sB);
 }
 
+// Skinny products (M <= 64: the 2-token decode step, poolers, classifier heads): the weight matrix is read once
+// and nothing is reused inside a workgroup, so there is no LDS staging -- every wave loads its MFMA fragments
+// straight from global memory (16 B per lane, k-contiguous rows).  Workgroup = 16 output columns x all rows;
+// its 4 waves split K, partial accumulators meet in LDS, wave i finishes row tile i.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmDev p) {
+    using M_ = Mma<T>;
+    using Frag = typename M_::Frag;
+    constexpr int KB = M_::KB, E = TypeInfo<T>::E;
+    __shared__ f32x4 red[4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r15 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+    const T* brow = B + (long)min(n0 + r15, p.N - 1) * p.ldb + g * E;
+    const T* arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) arow[i] = A + (long)min(16 * i + r15, p.M - 1) * p.lda + g * E;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkb = p.K / KB;
+#pragma unroll 2
+    for (int kb = wave; kb < nkb; kb += 4) {
+        const int k = kb * KB;
+        const Frag fb = *reinterpret_cast<const Frag*>(brow + k);
+        Frag fa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const Frag*>(arow[i] + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) M_::mma(acc[i], fb, fa[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    const int i = wave;                                  // row tile finished by this wave
+    if (16 * i < p.M) {
+        const f32x4 v = red[0][i][lane] + red[1][i][lane] + red[2][i][lane] + red[3][i][lane];
+        // acc[r] <-> n = n0 + 4*g + r, m = 16*i + (lane & 15)   (same orientation as gemm_body)
+        epilogue4<T>(p, 16 * i + r15, n0 + 4 * g, v);
+    }
+}
+
 // Several independent products in one launch (the weight gradients of one layer): the tile lists of the
 // items are concatenated, a workgroup finds its item by a scan of the (<= 8) prefix counts.
 constexpr int GROUP_MAX = 8;
@@ -447,14 +490,29 @@ Plan choose_plan(const MvltGemm* p) {
 
 }  // namespace
 
+// M <= 64, both operands k-contiguous, whole k-blocks, no split requested -> gemm_skinny_kernel
+template <typename T>
+static bool is_skinny(const MvltGemm* p) {
+    return p->M <= 64 && !p->a_kmajor && !p->b_kmajor && p->K % Mma<T>::KB == 0 && p->split_k <= 1 && !p->a_colsum;
+}
+
+static bool is_skinny_any(const MvltGemm* p) {
+    return p->dtype == MVLT_BF16 ? is_skinny<bf16_t>(p) : (p->dtype == MVLT_F32 && is_skinny<float>(p));
+}
+
 extern "C" size_t mvlt_gemm_workspace_bytes(const MvltGemm* p) {
     if (!p) return 0;
+    if (is_skinny_any(p)) return 0;
     Plan pl = choose_plan(p);
     return pl.split > 1 ? (size_t)pl.split * p->M * ((size_t)p->N + 1) * sizeof(float) : 0;
 }
 
 extern "C" int mvlt_gemm_plan(const MvltGemm* p, int* bm, int* bn, int* split_k) {
     if (!p || !bm || !bn || !split_k) return MVLT_ERR_ARG;
+    if (is_skinny_any(p)) {      // (alignment permitting)
+        *bm = 64; *bn = 16; *split_k = 1;
+        return MVLT_OK;
+    }
     Plan pl = choose_plan(p);
     *bm = pl.bm; *bn = pl.bn; *split_k = pl.split;
     return MVLT_OK;
@@ -501,8 +559,17 @@ static int fill_dev(const MvltGemm* p, const Plan& pl, GemmDev& d) {
 template <typename T>
 static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     Plan pl = choose_plan(p);
+    const bool skinny = is_skinny<T>(p) && (p->lda % TypeInfo<T>::E == 0) && (p->ldb % TypeInfo<T>::E == 0) &&
+                        aligned16(p->A) && aligned16(p->B);
+    if (is_skinny<T>(p)) pl.split = 1;          // (no workspace was requested for it)
     GemmDev d;
     { const int rc = fill_dev<T>(p, pl, d); if (rc != MVLT_OK) return rc; }
+    if (skinny) {
+        hipLaunchKernelGGL((gemm_skinny_kernel<T>), dim3(ceil_div(p->N, 16)), dim3(256), 0, s, d);
+        MVLT_LAUNCH_CHECK();
+        if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
+        return MVLT_OK;
+    }
     dim3 grid(ceil_div(p->N, pl.bn), ceil_div(p->M, pl.bm), d.split_k);
     const bool ak = p->a_kmajor != 0, bk = p->b_kmajor != 0;
     if (pl.bm == 128 && pl.bn == 128) launch_layout<T, 128, 128>(d, ak, bk, grid, s);

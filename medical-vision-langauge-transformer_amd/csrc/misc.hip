@@ -300,10 +300,117 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 }
 
 // ------------------------------------------------------------------ decode: cached attention + argmax
+// One wave = one (b, head): all n_new query rows share every K/V load.  Lanes are (key group kg) x (16-byte
+// feature chunk fc): a wave instruction reads 64/FC consecutive cache rows of 128 B (1 KB, coalesced); the
+// partial dot products are reduced over the fc lanes by xor shuffles, scores/probabilities live in LDS, and the
+// P.V partial sums are reduced over the key groups at the end.  (The serial kernel below walked the keys one
+// at a time with a dependent 2-byte load each: 68 us per layer at past = 200, now ~6.)
+constexpr int CACHED_MAXNEW = 4, CACHED_MAXK = 512;
 template <typename T>
 __global__ __launch_bounds__(64) void attn_cached_kernel(const MvltAttnCached p) {
+    constexpr int E = TypeInfo<T>::E, HD = 64, FC = HD / E, KG = 64 / FC;
+    using Vec = typename TypeInfo<T>::Vec;
+    __shared__ float sq[CACHED_MAXNEW][HD];
+    __shared__ float sc[CACHED_MAXNEW][CACHED_MAXK];
+    __shared__ float sinv[CACHED_MAXNEW];
+    const int lane = threadIdx.x, fc = lane % FC, kg = lane / FC;
+    const int h = blockIdx.x % p.nH, b = blockIdx.x / p.nH;
+    const int past = p.past_dev ? *p.past_dev : p.past;
+    const int C = p.nH * HD;
+    const T* qkv = reinterpret_cast<const T*>(p.qkv_new) + (long)b * p.n_new * 3 * C + h * HD;
+    T* kc = reinterpret_cast<T*>(p.k_cache) + ((long)b * p.nH + h) * p.cache_cap * HD;
+    T* vc = reinterpret_cast<T*>(p.v_cache) + ((long)b * p.nH + h) * p.cache_cap * HD;
+    const int nk = past + p.n_new;
+    for (int i = lane; i < p.n_new * HD; i += 64) {
+        const int r = i / HD, d = i % HD;
+        const T* src = qkv + (long)r * 3 * C + d;
+        sq[r][d] = to_f(src[0]) * p.scale;
+        kc[(long)(past + r) * HD + d] = src[C];          // append (read back below from qkv_new, not from the cache)
+        vc[(long)(past + r) * HD + d] = src[2 * C];
+    }
+    __syncthreads();
+    // ---- scores: s[r][k] = q_r . K_k for k <= past + r (causal over the new tokens, model.py:97-104)
+#pragma unroll 4
+    for (int k0 = 0; k0 < nk; k0 += KG) {
+        const int k = k0 + kg;
+        float part[CACHED_MAXNEW];
+#pragma unroll
+        for (int r = 0; r < CACHED_MAXNEW; ++r) part[r] = 0.f;
+        if (k < nk) {
+            const T* src = k < past ? kc + (long)k * HD + fc * E : qkv + (long)(k - past) * 3 * C + C + fc * E;
+            const Vec kv = *reinterpret_cast<const Vec*>(src);
+#pragma unroll
+            for (int r = 0; r < CACHED_MAXNEW; ++r)
+                if (r < p.n_new) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) part[r] += sq[r][fc * E + e] * to_f(kv[e]);
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < CACHED_MAXNEW; ++r) {
+#pragma unroll
+            for (int o = 1; o < FC; o <<= 1) part[r] += __shfl_xor(part[r], o, 64);
+            if (fc == 0 && k < nk && r < p.n_new) sc[r][k] = k <= past + r ? part[r] : -3.0e38f;
+        }
+    }
+    __syncthreads();
+    // ---- softmax over the keys of each row (unnormalised probabilities stay in LDS)
+    for (int r = 0; r < p.n_new; ++r) {
+        float mx = -3.0e38f;
+        for (int k = lane; k < nk; k += 64) mx = fmaxf(mx, sc[r][k]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int k = lane; k < nk; k += 64) { const float e = __expf(sc[r][k] - mx); sc[r][k] = e; sum += e; }
+        sum = wave_sum(sum);
+        if (lane == 0) sinv[r] = 1.0f / sum;
+    }
+    __syncthreads();
+    // ---- O_r = sum_k p[r][k] V_k
+    float o[CACHED_MAXNEW][E];
+#pragma unroll
+    for (int r = 0; r < CACHED_MAXNEW; ++r)
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[r][e] = 0.f;
+#pragma unroll 4
+    for (int k0 = 0; k0 < nk; k0 += KG) {
+        const int k = k0 + kg;
+        if (k < nk) {
+            const T* src = k < past ? vc + (long)k * HD + fc * E : qkv + (long)(k - past) * 3 * C + 2 * C + fc * E;
+            const Vec vv = *reinterpret_cast<const Vec*>(src);
+#pragma unroll
+            for (int r = 0; r < CACHED_MAXNEW; ++r)
+                if (r < p.n_new) {
+                    const float pr = sc[r][k];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) o[r][e] += pr * to_f(vv[e]);
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < CACHED_MAXNEW; ++r) {
+        if (r >= p.n_new) break;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            float v = o[r][e];
+#pragma unroll
+            for (int off = FC; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            o[r][e] = v * sinv[r];
+        }
+        if (kg == 0) {
+            Vec ov;
+#pragma unroll
+            for (int e = 0; e < E; ++e) ov[e] = from_f<T>(o[r][e]);
+            *reinterpret_cast<Vec*>(reinterpret_cast<T*>(p.out) + ((long)b * p.n_new + r) * C + h * HD + fc * E) = ov;
+        }
+    }
+}
+
+// fallback (head_dim < 64, more than 4 new rows or more than 512 keys): one wave per (b, head, new row), keys serial
+template <typename T>
+__global__ __launch_bounds__(64) void attn_cached_serial_kernel(const MvltAttnCached p) {
     // one wave = one (b, head, new row); hd = 64 -> lane owns one feature; keys streamed from the cache
     const int lane = threadIdx.x;
+    const int past = p.past_dev ? *p.past_dev : p.past;
     const int row = blockIdx.x % p.n_new, h = (blockIdx.x / p.n_new) % p.nH, b = blockIdx.x / (p.n_new * p.nH);
     const int C = p.nH * p.hd;
     const T* qkv = reinterpret_cast<const T*>(p.qkv_new);
@@ -312,17 +419,17 @@ __global__ __launch_bounds__(64) void attn_cached_kernel(const MvltAttnCached p)
     // append this row's K/V (each (b,h,row) wave appends its own row)
     const T* src = qkv + ((long)b * p.n_new + row) * 3 * C + h * p.hd;
     if (lane < p.hd) {
-        kc[(long)(p.past + row) * p.hd + lane] = src[C + lane];
-        vc[(long)(p.past + row) * p.hd + lane] = src[2 * C + lane];
+        kc[(long)(past + row) * p.hd + lane] = src[C + lane];
+        vc[(long)(past + row) * p.hd + lane] = src[2 * C + lane];
     }
     const float q = lane < p.hd ? to_f(src[lane]) * p.scale : 0.f;
-    const int nk = p.past + row + 1;                     // causal over the new tokens (model.py:97-104)
+    const int nk = past + row + 1;                     // causal over the new tokens (model.py:97-104)
     float m = -3.0e38f, l = 0.f, o = 0.f;
     for (int k = 0; k < nk; ++k) {
         float kv, vv;
-        if (k < p.past) { kv = lane < p.hd ? to_f(kc[(long)k * p.hd + lane]) : 0.f; vv = lane < p.hd ? to_f(vc[(long)k * p.hd + lane]) : 0.f; }
+        if (k < past) { kv = lane < p.hd ? to_f(kc[(long)k * p.hd + lane]) : 0.f; vv = lane < p.hd ? to_f(vc[(long)k * p.hd + lane]) : 0.f; }
         else {   // rows appended in this launch: read them from qkv_new (other waves may not have stored yet)
-            const T* s2 = qkv + ((long)b * p.n_new + (k - p.past)) * 3 * C + h * p.hd;
+            const T* s2 = qkv + ((long)b * p.n_new + (k - past)) * 3 * C + h * p.hd;
             kv = lane < p.hd ? to_f(s2[C + lane]) : 0.f; vv = lane < p.hd ? to_f(s2[2 * C + lane]) : 0.f;
         }
         const float s = wave_sum(q * kv);
@@ -542,10 +649,20 @@ extern "C" int mvlt_adamw(float* param, const float* grad, float* exp_avg, float
 
 extern "C" int mvlt_attn_cached(const MvltAttnCached* p, void* stream) {
     MVLT_CHECK(p && p->qkv_new && p->k_cache && p->v_cache && p->out, MVLT_ERR_ARG);
-    MVLT_CHECK(p->hd > 0 && p->hd <= 64 && p->B > 0 && p->nH > 0 && p->n_new > 0 && p->past + p->n_new <= p->cache_cap, MVLT_ERR_ARG);
-    dim3 grid(p->B * p->nH * p->n_new);
-    BY_DTYPE(p->dtype, hipLaunchKernelGGL(attn_cached_kernel<float>, grid, dim3(64), 0, STREAM(stream), *p),
-             hipLaunchKernelGGL(attn_cached_kernel<bf16_t>, grid, dim3(64), 0, STREAM(stream), *p));
+    MVLT_CHECK(p->hd > 0 && p->hd <= 64 && p->B > 0 && p->nH > 0 && p->n_new > 0, MVLT_ERR_ARG);
+    // with a device-side `past` the host cannot check the bound: the caller guarantees *past_dev + n_new <= cache_cap
+    MVLT_CHECK(p->past_dev || p->past + p->n_new <= p->cache_cap, MVLT_ERR_ARG);
+    const bool fast = p->hd == 64 && p->n_new <= CACHED_MAXNEW && p->cache_cap <= CACHED_MAXK &&
+                      aligned16(p->qkv_new) && aligned16(p->k_cache) && aligned16(p->v_cache) && aligned16(p->out);
+    if (fast) {
+        dim3 grid(p->B * p->nH);
+        BY_DTYPE(p->dtype, hipLaunchKernelGGL(attn_cached_kernel<float>, grid, dim3(64), 0, STREAM(stream), *p),
+                 hipLaunchKernelGGL(attn_cached_kernel<bf16_t>, grid, dim3(64), 0, STREAM(stream), *p));
+    } else {
+        dim3 grid(p->B * p->nH * p->n_new);
+        BY_DTYPE(p->dtype, hipLaunchKernelGGL(attn_cached_serial_kernel<float>, grid, dim3(64), 0, STREAM(stream), *p),
+                 hipLaunchKernelGGL(attn_cached_serial_kernel<bf16_t>, grid, dim3(64), 0, STREAM(stream), *p));
+    }
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }

@@ -602,12 +602,19 @@ def adamw(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weigh
                                float(grad_scale), _stream()), "mvlt_adamw")
 
 
-def attn_cached(qkv_new, k_cache, v_cache, past, scale):
+def attn_cached(qkv_new, k_cache, v_cache, past, scale, out=None):
+    """past: int, or an int32 device tensor [1] (position kept on the GPU by a replayed decode loop)."""
     B, nH, cap, hd = k_cache.shape
     n_new = qkv_new.shape[0] // B
-    out = torch.empty((B * n_new, nH * hd), dtype=qkv_new.dtype, device=qkv_new.device)
+    if out is None:
+        out = torch.empty((B * n_new, nH * hd), dtype=qkv_new.dtype, device=qkv_new.device)
     p = L.MvltAttnCached()
-    p.dtype, p.B, p.nH, p.hd, p.past, p.n_new, p.cache_cap = _dt(qkv_new), B, nH, hd, past, n_new, cap
+    p.dtype, p.B, p.nH, p.hd, p.n_new, p.cache_cap = _dt(qkv_new), B, nH, hd, n_new, cap
+    if torch.is_tensor(past):
+        assert past.dtype == torch.int32 and past.is_cuda
+        p.past_dev = _p(past)
+    else:
+        p.past = past
     p.qkv_new, p.k_cache, p.v_cache, p.out, p.scale = _p(qkv_new), _p(k_cache), _p(v_cache), _p(out), float(scale)
     L.check(L.lib().mvlt_attn_cached(C.byref(p), _stream()), "mvlt_attn_cached")
     return out

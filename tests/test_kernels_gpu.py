@@ -133,6 +133,31 @@ def test_wgrad_group(ops, dt, widths, R):
             assert rel(db, rb) < tol(dt)
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(64, 2304, 768), (64, 768, 3072), (32, 3000, 256), (5, 2, 768), (33, 30, 64), (64, 16, 32)])
+def test_gemm_skinny(ops, dt, M, N, K):
+    """M <= 64 products (decode step, poolers, classifier heads) take gemm_skinny_kernel: same contract."""
+    import ctypes as C
+    from mvlt_amd import _lib as L
+    a, w = rnd((M, K), dt, 1, 0.5), rnd((N, K), dt, 2, 0.5)
+    bias = rnd((N,), torch.float32, 3)
+    res = rnd((M, N), dt, 4)
+    p = L.MvltGemm()
+    p.dtype, p.M, p.N, p.K = (L.BF16 if dt == torch.bfloat16 else L.F32), M, N, K
+    bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
+    assert L.lib().mvlt_gemm_plan(C.byref(p), C.byref(bm), C.byref(bn), C.byref(sp)) == 0
+    assert (bm.value, bn.value, sp.value) == (64, 16, 1)
+    ref = a.float() @ w.float().t()
+    assert rel(ops.gemm(a, w), ref) < tol(dt)
+    assert rel(ops.gemm(a, w, bias=bias, residual=res), ref + bias + res.float()) < tol(dt)
+    pre = torch.empty((M, N), dtype=dt, device="cuda")
+    out = ops.gemm(a, w, bias=bias, gelu=True, save_pre=pre)
+    assert rel(out, F.gelu(ref + bias)) < tol(dt) and rel(pre, ref + bias) < tol(dt)
+    # strided A (rows of a [B, L, H] tensor: the pooler's hidden[:, 0])
+    big = rnd((M, 3, K), dt, 5, 0.5)
+    assert rel(ops.gemm(big[:, 1], w), big[:, 1].float() @ w.float().t()) < tol(dt)
+
+
 def test_gemm_bad_args(ops):
     A = torch.zeros(4, 4, device="cuda")
     with pytest.raises(AssertionError):
@@ -377,25 +402,27 @@ def test_adamw_matches_torch(ops):
 
 
 @pytest.mark.parametrize("dt", DT)
-def test_cached_attention_and_argmax(ops, dt):
-    B, nH, hd, past, cap = 2, 4, 64, 51, 80
+@pytest.mark.parametrize("past,n_new,cap,dev_past", [(51, 2, 80, False), (200, 2, 202, True), (3, 1, 16, False),
+                                                     (100, 4, 128, False), (97, 2, 600, False), (60, 5, 80, True)])
+def test_cached_attention_and_argmax(ops, dt, past, n_new, cap, dev_past):
+    """mvlt_attn_cached (one wave per (b, head); serial fallback for > 512 cache slots or > 4 new rows)."""
+    B, nH, hd = 2, 4, 64
     kc = torch.zeros(B, nH, cap, hd, dtype=dt, device="cuda")
     vc = torch.zeros_like(kc)
     kc[:, :, :past] = rnd((B, nH, past, hd), dt, 100)
     vc[:, :, :past] = rnd((B, nH, past, hd), dt, 101)
-    qkv = rnd((B * 2, 3 * nH * hd), dt, 102)
+    qkv = rnd((B * n_new, 3 * nH * hd), dt, 102)
     kref, vref = kc.clone(), vc.clone()
-    out = ops.attn_cached(qkv, kc, vc, past, 0.125)
-    q, k, v = qkv.float().view(B, 2, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    out = ops.attn_cached(qkv, kc, vc, torch.tensor([past], dtype=torch.int32, device="cuda") if dev_past else past, 0.125)
+    q, k, v = qkv.float().view(B, n_new, 3, nH, hd).permute(2, 0, 3, 1, 4)
     K = torch.cat([kref[:, :, :past].float(), k], 2)
     V_ = torch.cat([vref[:, :, :past].float(), v], 2)
     att = (q @ K.transpose(-1, -2)) * 0.125
-    causal = torch.ones(2, past + 2, dtype=torch.bool, device="cuda")
-    causal[0, -1] = False
+    causal = torch.arange(past + n_new, device="cuda")[None, :] <= past + torch.arange(n_new, device="cuda")[:, None]
     att = att.masked_fill(~causal[None, None], float("-inf")).softmax(-1)
-    ref = (att @ V_).transpose(1, 2).reshape(B * 2, nH * hd)
+    ref = (att @ V_).transpose(1, 2).reshape(B * n_new, nH * hd)
     assert rel(out, ref) < tol(dt)
-    assert rel(kc[:, :, past:past + 2], k) < 1e-6 and rel(vc[:, :, past:past + 2], v) < 1e-6
+    assert rel(kc[:, :, past:past + n_new], k) < 1e-6 and rel(vc[:, :, past:past + n_new], v) < 1e-6
     logits = rnd((5, 3008), dt, 103)
     assert torch.equal(ops.argmax(logits, 3000), logits[:, :3000].float().argmax(-1))
 
