@@ -336,13 +336,15 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
 // Skinny products (M <= 64: the 2-token decode step, poolers, classifier heads): the weight matrix is read once
 // and nothing is reused inside a workgroup, so there is no LDS staging -- every wave loads its MFMA fragments
 // straight from global memory (16 B per lane, k-contiguous rows).  Workgroup = 16 output columns x all rows;
-// its 4 waves split K, partial accumulators meet in LDS, wave i finishes row tile i.
+// its 8 waves split K (3 k-blocks in flight per wave: the loop is latency bound, so memory-level parallelism is
+// what matters), partial accumulators meet in LDS, wave i < 4 finishes row tile i.
+constexpr int SKINNY_WAVES = 8, SKINNY_UNROLL = 3;
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmDev p) {
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const GemmDev p) {
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
     constexpr int KB = M_::KB, E = TypeInfo<T>::E;
-    __shared__ f32x4 red[4][4][64];
+    __shared__ f32x4 red[SKINNY_WAVES][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r15 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const T* A = reinterpret_cast<const T*>(p.A);
@@ -355,22 +357,32 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmDev p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nkb = p.K / KB;
-#pragma unroll 2
-    for (int kb = wave; kb < nkb; kb += 4) {
-        const int k = kb * KB;
-        const Frag fb = *reinterpret_cast<const Frag*>(brow + k);
-        Frag fa[4];
+    for (int kb0 = wave; kb0 < nkb; kb0 += SKINNY_WAVES * SKINNY_UNROLL) {
+        Frag fb[SKINNY_UNROLL], fa[SKINNY_UNROLL][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const Frag*>(arow[i] + k);
+        for (int u = 0; u < SKINNY_UNROLL; ++u) {
+            const int kb = kb0 + u * SKINNY_WAVES;
+            const int k = (kb < nkb ? kb : kb0) * KB;          // past the end: reload a valid block, never multiplied
+            fb[u] = *reinterpret_cast<const Frag*>(brow + k);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) M_::mma(acc[i], fb, fa[i]);
+            for (int i = 0; i < 4; ++i) fa[u][i] = *reinterpret_cast<const Frag*>(arow[i] + k);
+        }
+#pragma unroll
+        for (int u = 0; u < SKINNY_UNROLL; ++u) {
+            if (kb0 + u * SKINNY_WAVES < nkb) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) M_::mma(acc[i], fb[u], fa[u][i]);
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
     __syncthreads();
     const int i = wave;                                  // row tile finished by this wave
-    if (16 * i < p.M) {
-        const f32x4 v = red[0][i][lane] + red[1][i][lane] + red[2][i][lane] + red[3][i][lane];
+    if (i < 4 && 16 * i < p.M) {
+        f32x4 v = red[0][i][lane];
+#pragma unroll
+        for (int w = 1; w < SKINNY_WAVES; ++w) v += red[w][i][lane];
         // acc[r] <-> n = n0 + 4*g + r, m = 16*i + (lane & 15)   (same orientation as gemm_body)
         epilogue4<T>(p, 16 * i + r15, n0 + 4 * g, v);
     }
@@ -565,7 +577,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     GemmDev d;
     { const int rc = fill_dev<T>(p, pl, d); if (rc != MVLT_OK) return rc; }
     if (skinny) {
-        hipLaunchKernelGGL((gemm_skinny_kernel<T>), dim3(ceil_div(p->N, 16)), dim3(256), 0, s, d);
+        hipLaunchKernelGGL((gemm_skinny_kernel<T>), dim3(ceil_div(p->N, 16)), dim3(64 * SKINNY_WAVES), 0, s, d);
         MVLT_LAUNCH_CHECK();
         if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
         return MVLT_OK;

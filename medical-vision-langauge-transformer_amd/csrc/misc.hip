@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64) void attn_cached_kernel(const MvltAttnCached p)
     }
     __syncthreads();
     // ---- scores: s[r][k] = q_r . K_k for k <= past + r (causal over the new tokens, model.py:97-104)
-#pragma unroll 4
+#pragma unroll 8
     for (int k0 = 0; k0 < nk; k0 += KG) {
         const int k = k0 + kg;
         float part[CACHED_MAXNEW];
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64) void attn_cached_kernel(const MvltAttnCached p)
     for (int r = 0; r < CACHED_MAXNEW; ++r)
 #pragma unroll
         for (int e = 0; e < E; ++e) o[r][e] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int k0 = 0; k0 < nk; k0 += KG) {
         const int k = k0 + kg;
         if (k < nk) {

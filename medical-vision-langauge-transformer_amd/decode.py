@@ -140,19 +140,27 @@ def greedy_search(model, image_feature, learning_strategy='unilm', sample_mode='
         _fill_cache_from_qkv(saved["layers"][i][1], B, L0, nH, hd, kc[i], vc[i], past)
     del saved
     unfinished = torch.ones(B, dtype=torch.int64, device=dev)
-    input_ids = None
-    scores = []
+    ids_cols, scores, alive = [], [], []
     hlast = hidden[:, -1]
     cur_len = 0
+    n_out = None                     # number of generated columns once every sequence has emitted [END]
+    # The reference asks the device "all finished?" after every token (model.py:954), which serialises host and
+    # GPU.  Finished sequences only emit PAD, so running a few steps past the end changes nothing that is kept:
+    # the flag of every step is recorded on the device, read back every `sync_every` steps, and the outputs are
+    # cut at the exact step the reference would have stopped at.
+    sync_every = 8
     while cur_len < max_length:
         nxt, score = next_from(hlast)
         if eos is not None:
             nxt = nxt * unfinished + pad * (1 - unfinished)
-        input_ids = nxt[:, None] if input_ids is None else torch.cat([input_ids, nxt[:, None]], dim=-1)
-        if eos is not None:
             unfinished = unfinished * (nxt != eos).long()
-        if int(unfinished.max()) == 0:          # host sync per token, as in the reference (model.py:954)
-            break
+            alive.append(unfinished.max())
+        ids_cols.append(nxt[:, None])
+        if eos is not None and (len(alive) % sync_every == 0 or cur_len + 1 >= max_length):
+            flags = torch.stack(alive[-sync_every:]).tolist()          # one host sync per `sync_every` tokens
+            if 0 in flags:
+                n_out = len(alive) - len(flags) + flags.index(0) + 1
+                break
         cur_len += 1
         scores.append(score)
         if cur_len >= max_length:
@@ -162,5 +170,8 @@ def greedy_search(model, image_feature, learning_strategy='unilm', sample_mode='
         h = _layers_cached(mv, ar, x, kc, vc, past, 2).view(B, 2, H)
         past += 1                                                         # drop the [MASK] slot (model.py:890-894)
         hlast = h[:, -1]
+    if n_out is not None:            # the reference breaks before appending the score of the finishing step
+        ids_cols, scores = ids_cols[:n_out], scores[:n_out - 1]
+    input_ids = torch.cat(ids_cols, dim=-1) if ids_cols else None
     token_scores = torch.cat(scores, dim=-1) if scores else torch.empty(0, device=dev)
     return input_ids, token_scores

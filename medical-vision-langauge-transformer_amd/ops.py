@@ -135,6 +135,12 @@ def workspace(name, nbytes, device):
 
 
 # ----------------------------------------------------------------------------- GEMM
+def _ld(t):
+    """Row stride of a 2-D operand; torch leaves the stride of a size-1 dimension arbitrary (a one-row matrix
+    sliced out of a batch, B = 1 decode), so one-row matrices report their width."""
+    return t.stride(0) if t.shape[0] != 1 else max(t.shape[1], 1)
+
+
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=None, gelu=False,
          save_pre=None, dropout=None, rowscale=None, residual=None, rowmap=None, mul_gelu_grad=None,
          accumulate=False, split_k=0, ldc=None, a_colsum=None):
@@ -156,9 +162,9 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
     assert out.dtype == odt and out.stride(-1) == 1
     p = L.MvltGemm()
     p.dtype, p.M, p.N, p.K = _dt(A), M, N, K
-    p.A, p.lda, p.a_kmajor = _p(A), A.stride(0), int(a_kmajor)
-    p.B, p.ldb, p.b_kmajor = _p(B), B.stride(0), int(b_kmajor)
-    p.C, p.ldc = _p(out), out.stride(0) if out.dim() == 2 else N
+    p.A, p.lda, p.a_kmajor = _p(A), _ld(A), int(a_kmajor)
+    p.B, p.ldb, p.b_kmajor = _p(B), _ld(B), int(b_kmajor)
+    p.C, p.ldc = _p(out), _ld(out) if out.dim() == 2 else N
     epi = 0
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N
@@ -167,7 +173,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
     if gelu:
         epi |= L.EPI_GELU
         if save_pre is not None:
-            assert save_pre.dtype == A.dtype and save_pre.stride(0) == p.ldc
+            assert save_pre.dtype == A.dtype and _ld(save_pre) == p.ldc
             epi |= L.EPI_SAVE_PRE
             p.pre = _p(save_pre)
     if dropout is not None and dropout[0] > 0.0:
@@ -179,13 +185,13 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
     if residual is not None:
         assert residual.dtype == A.dtype and residual.stride(-1) == 1
         epi |= L.EPI_RESIDUAL
-        p.residual, p.ldr = _p(residual), residual.stride(0)
+        p.residual, p.ldr = _p(residual), _ld(residual)
     if rowmap is not None:
         assert rowmap.dtype == torch.int32
         epi |= L.EPI_ROWMAP
         p.rowmap = _p(rowmap)
     if mul_gelu_grad is not None:
-        assert mul_gelu_grad.dtype == A.dtype and mul_gelu_grad.stride(0) == p.ldc
+        assert mul_gelu_grad.dtype == A.dtype and _ld(mul_gelu_grad) == p.ldc
         epi |= L.EPI_MUL_GELU_GRAD
         p.aux = _p(mul_gelu_grad)
     if out_f32:

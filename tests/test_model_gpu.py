@@ -525,3 +525,37 @@ def test_packed_rows_full_size_bf16(M, monkeypatch):
         dense = model(*batch[:4]).item()
         packed = model(*batch[:4], text_lengths=batch[4]).item()
     assert abs(dense - packed) < 3e-3 * abs(dense), (dense, packed)
+
+
+def test_greedy_decode_stops_where_the_per_token_check_would(M, specs):
+    """The all-finished flag is read back every 8 tokens instead of every token (model.py:954); the returned
+    ids / scores must be cut exactly where the reference's per-token check stops, finished rows emit PAD."""
+    model, _ = _tiny_caption(M, specs, F32)
+    image, _, _, _ = synth_batch(2, 24, seed=78, vocab=3000)
+    cfg = model.config
+    old_eos = cfg.eos_token_id
+    try:
+        cfg.eos_token_id = None
+        full, full_scores = model(image.cuda(), None, 1, 'unilm')
+        full = full.cpu()
+        n = full.shape[1]
+        assert n == cfg.max_length
+        # an [END] id that row 0 emits at step j >= 2 (first occurrence) -- row 1 may or may not ever emit it
+        j = next(t for t in range(2, n) if full[0, t].item() not in full[0, :t].tolist())
+        eos = full[0, j].item()
+        cfg.eos_token_id = eos
+        got, got_scores = model(image.cuda(), None, 1, 'unilm')
+        got = got.cpu()
+        first = [next((t for t in range(n) if full[b, t].item() == eos), None) for b in range(2)]
+        stop = max(first) + 1 if all(f is not None for f in first) else n
+        want = full[:, :stop].clone()
+        for b in range(2):
+            if first[b] is not None:
+                want[b, first[b] + 1:] = cfg.pad_token_id
+        assert got.shape == want.shape and torch.equal(got, want), (got, want)
+        assert got_scores.numel() in (2 * (stop - 1), 2 * stop)
+        # single image: the loop must stop right after its [END]
+        one, one_scores = model(image[:1].cuda(), None, 1, 'unilm')
+        assert one.shape == (1, first[0] + 1) and one[0, -1].item() == eos and one_scores.numel() == first[0]
+    finally:
+        cfg.eos_token_id = old_eos
