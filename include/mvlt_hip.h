@@ -201,6 +201,7 @@ typedef struct MvltEmbed {
     const void* dout; void* dimage; float* dword; float* dpos; float* dtype_emb;
     /* packed rows (optional): sequence b is written to / read from rows row_start[b] + pos, pos < seq_len[b] */
     const int32_t* row_start; const int32_t* seq_len;
+    const int32_t* pos_offset_dev;      /* optional (forward): added to pos_offset, read on the device (replayed decode step) */
 } MvltEmbed;
 int mvlt_embed_fwd(const MvltEmbed* p, void* stream);
 int mvlt_embed_bwd(const MvltEmbed* p, void* stream);  /* dword/dpos/dtype_emb are ACCUMULATED (zero them first) */

@@ -36,7 +36,7 @@ struct EmbDev {
     const int64_t* text; const void* img; const float* word; const float* pos; const float* type;
     int cls_id, sep_id, pos_offset, type_override;
     void* out; const void* dout; void* dimage; float* dword; float* dpos; float* dtype_emb;
-    const int* row_start; const int* seq_len;
+    const int* row_start; const int* seq_len; const int* pos_offset_dev;
 };
 // row of (b, posi) in the activation matrix, -1 when the position is not materialised (packed layout)
 MVLT_DEV long emb_row(const EmbDev& p, int b, int posi) {
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbDev p) {
     const long total = (long)p.B * p.L * HV;
     const T* img = reinterpret_cast<const T*>(p.img);
     T* out = reinterpret_cast<T*>(p.out);
+    const int pos_off = p.pos_offset + (p.pos_offset_dev ? *p.pos_offset_dev : 0);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % HV) * 4;
         const int posi = (int)((idx / HV) % p.L), b = (int)(idx / ((long)HV * p.L));
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbDev p) {
                            : load4f(img + ((long)b * p.n_img + (posi - 1)) * p.H + c);
         const int ty = p.type_override >= 0 ? p.type_override : (posi <= p.n_img + 1 ? 1 : 0);
         v += load4f(p.type + (long)ty * p.H + c);
-        v += load4f(p.pos + (long)(posi + p.pos_offset) * p.H + c);
+        v += load4f(p.pos + (long)(posi + pos_off) * p.H + c);
         store4f(out + row * p.H + c, v);
     }
 }
@@ -500,7 +501,7 @@ static int fill_emb(const MvltEmbed* p, EmbDev& d) {
     d.cls_id = p->cls_id; d.sep_id = p->sep_id; d.pos_offset = p->pos_offset; d.type_override = p->type_override;
     d.out = p->out; d.dout = p->dout; d.dimage = p->dimage; d.dword = p->dword; d.dpos = p->dpos; d.dtype_emb = p->dtype_emb;
     MVLT_CHECK((p->row_start == nullptr) == (p->seq_len == nullptr), MVLT_ERR_ARG);
-    d.row_start = p->row_start; d.seq_len = p->seq_len;
+    d.row_start = p->row_start; d.seq_len = p->seq_len; d.pos_offset_dev = p->pos_offset_dev;
     if (p->n_img >= 0) MVLT_CHECK(p->image_feature || p->dout, MVLT_ERR_ARG);
     return MVLT_OK;
 }

@@ -8,9 +8,14 @@ Layout: one preallocated cache ``[layers][B, nH, cap, hd]`` per K and V
 ``[last_token, [MASK]]`` at positions ``past, past+1`` (type 0), appends their
 K/V in place and attends causally (``mvlt_attn_cached``).  "Trimming the [MASK]
 slot" (model.py:890-894) is just ``past += 1``: the next step overwrites it.
+Greedy mode replays one captured HIP graph per token (``_GreedyGraph``: position,
+output column and finished flags live on the device; ``MVLT_DECODE_GRAPH=0`` selects
+the eager loop, which 'sample' mode always uses).
 Beam search is not built.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 
@@ -89,6 +94,115 @@ def cached_forward(mv, text_idx, image_feature, past_key_values, seq2seq_mask):
     return EncoderOutput(h, tuple((kc[i], vc[i]) for i in range(nl))), None
 
 
+class _GreedyGraph:
+    """The whole per-token work of greedy decoding -- last-row MLM head + argmax + [END]/PAD bookkeeping + the
+    2-token cached forward -- captured ONCE as a HIP graph and replayed per token.  Everything a replay needs
+    lives in static device buffers: the cache position (``past``: read by the embedding and attention kernels
+    through ``pos_offset_dev`` / ``past_dev``), the output column index, the ids fed to the next step, the
+    unfinished flags, and the [B, max_length] output matrices.  The host only replays and, every 8 tokens, reads
+    the all-finished flags back."""
+
+    def __init__(self, model, B, n_img, max_length, cd, pad, eos, mask_id, key):
+        mv, cfg = model.MVLBert, model.config
+        dev = next(model.parameters()).device
+        H, nH = cfg.hidden_size, cfg.num_attention_heads
+        nl = len(mv.encoder.layer)
+        self.key, self.model, self.B, self.max_length, self.eos, self.pad = key, model, B, max_length, eos, pad
+        cap = n_img + 2 + max_length + 1
+        self.kc = [torch.zeros((B, nH, cap, H // nH), dtype=cd, device=dev) for _ in range(nl)]
+        self.vc = [torch.zeros((B, nH, cap, H // nH), dtype=cd, device=dev) for _ in range(nl)]
+        self.past = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.col = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.new_ids = torch.full((B, 2), mask_id, dtype=torch.int64, device=dev)       # [last token, MASK]
+        self.hlast = torch.zeros((B, H), dtype=cd, device=dev)
+        self.unfinished = torch.ones(B, dtype=torch.int64, device=dev)
+        self.ids = torch.zeros((B, max_length), dtype=torch.int64, device=dev)
+        self.scores = torch.zeros((B, max_length), dtype=torch.float32, device=dev)
+        self.alive = torch.ones(max_length, dtype=torch.int64, device=dev)
+        self.cd, self.graph = cd, None
+
+    def head(self):
+        """token <- argmax(MLM head(hlast)); record it in column `col`."""
+        model = self.model
+        ar = Arena.of(model, self.cd)
+        hd = model.MLM_head_seq2seq
+        V = hd.predictions.decoder.out_features
+        _, _, t2, _, _ = hd._transform(ar, self.hlast, False)
+        logits, _ = hd._logits(ar, t2)
+        nxt = ops.argmax(logits, V)
+        score = logits[:, :V].float().gather(1, nxt[:, None]).squeeze(1)
+        if self.eos is not None:
+            nxt = nxt * self.unfinished + self.pad * (1 - self.unfinished)
+            self.unfinished.mul_((nxt != self.eos).long())
+            self.alive.index_copy_(0, self.col, self.unfinished.max()[None])
+        self.ids.index_copy_(1, self.col, nxt[:, None])
+        self.scores.index_copy_(1, self.col, score[:, None])
+        self.new_ids[:, 0].copy_(nxt)
+        self.col.add_(1)
+
+    def forward2(self):
+        """2-token cached forward of [last token, MASK] at positions past, past+1 (model.py:82-108)."""
+        mv = self.model.MVLBert
+        ar = Arena.of(self.model, self.cd)
+        B, H = self.B, mv.config.hidden_size
+        x = _embed_new(mv, self.new_ids, self.past, self.cd).view(B * 2, H)
+        h = _layers_cached(mv, ar, x, self.kc, self.vc, self.past, 2).view(B, 2, H)
+        self.hlast.copy_(h[:, -1])
+        self.past.add_(1)                        # the [MASK] slot is overwritten by the next step (model.py:890-894)
+
+    def capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):            # warm-up outside the capture (allocator, lazy module state)
+            self.head(); self.forward2()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.head(); self.forward2()
+        self.graph = g
+
+
+def _greedy_graph_loop(model, feat, max_length, pad, eos, mask_id, cd):
+    mv, cfg = model.MVLBert, model.config
+    B, n_img, H = feat.shape
+    nH = cfg.num_attention_heads
+    nl = len(mv.encoder.layer)
+    ar = Arena.of(model, cd)
+    key = (B, n_img, max_length, cd, pad, eos, mask_id, ar.flat.data_ptr(), feat.device.index)
+    gg = model.__dict__.get("_mvlt_greedy_graph")
+    if gg is None or gg.key != key:
+        gg = _GreedyGraph(model, B, n_img, max_length, cd, pad, eos, mask_id, key)
+        gg.capture()
+        model.__dict__["_mvlt_greedy_graph"] = gg
+    # ---- step 0: [CLS] img [SEP] [MASK], full seq2seq forward (model.py:110-160), eager
+    mask_col = gg.new_ids[:, 1:2].contiguous()
+    hidden, _, saved = mv._forward(feat, mask_col, mask_col, None, True, True)
+    L0 = n_img + 3
+    for i in range(nl):
+        _fill_cache_from_qkv(saved["layers"][i][1], B, L0, nH, H // nH, gg.kc[i], gg.vc[i], L0 - 1)
+    del saved
+    gg.past.fill_(L0 - 1); gg.col.zero_(); gg.unfinished.fill_(1); gg.alive.fill_(1)
+    gg.hlast.copy_(hidden[:, -1])
+    done = 0
+    for t in range(max_length - 1):
+        gg.graph.replay()                        # token t, then the forward that prepares token t+1
+        done = t + 1
+        if eos is not None and done % 8 == 0 and 0 in gg.alive[done - 8:done].tolist():   # one host sync per 8 tokens
+            break
+    else:
+        gg.head()                                # last token: head only
+        done = max_length
+    flags = gg.alive[:done].tolist() if eos is not None else []
+    if 0 in flags:       # cut where the reference's per-token check stops; it breaks before appending that step's score
+        n_out = flags.index(0) + 1
+        n_scores = n_out - 1
+    else:
+        n_out = n_scores = done
+    ids = gg.ids[:, :n_out].clone()
+    scores = gg.scores[:, :n_scores].t().reshape(-1).clone() if n_scores > 0 else torch.empty(0, device=feat.device)
+    return ids, scores
+
+
 @torch.no_grad()
 def greedy_search(model, image_feature, learning_strategy='unilm', sample_mode='greedy', max_length=None,
                   pad_token_id=None, eos_token_id=None):
@@ -106,6 +220,8 @@ def greedy_search(model, image_feature, learning_strategy='unilm', sample_mode='
     tok = getattr(model, "tokenizer", None)
     mask_id = tok.mask_token_id if tok is not None else cfg.mask_token_id
     feat = image_feature.to(cd).contiguous()
+    if sample_mode == 'greedy' and os.environ.get("MVLT_DECODE_GRAPH", "1") == "1":
+        return _greedy_graph_loop(model, feat, max_length, pad, eos, mask_id, cd)
     B, n_img, H = feat.shape
     nH = cfg.num_attention_heads
     hd = H // nH

@@ -470,12 +470,17 @@ def _embed_struct(dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_i
         assert text_ids.dtype == torch.int64 and text_ids.is_contiguous()
         p.text_ids = _p(text_ids)
     p.word_emb, p.pos_emb, p.type_emb = _p(word), _p(pos), _p(typ)
-    p.cls_id, p.sep_id, p.pos_offset, p.type_override = cls_id, sep_id, pos_offset, type_override
+    if torch.is_tensor(pos_offset):          # position kept on the device (replayed decode step)
+        assert pos_offset.dtype == torch.int32 and pos_offset.is_cuda
+        p.pos_offset, p.pos_offset_dev = 0, _p(pos_offset)
+    else:
+        p.pos_offset = pos_offset
+    p.cls_id, p.sep_id, p.type_override = cls_id, sep_id, type_override
     return p
 
 
 def embed_fwd(text_ids, image_feature, word, pos, typ, cls_id, sep_id, *, dtype=None, pos_offset=0,
-              type_override=-1, pack=None):
+              type_override=-1, pack=None, out=None):
     """MVLBert.get_embedding sum.  image_feature None -> cached-step (text only) layout."""
     if image_feature is not None:
         B, n_img, H = image_feature.shape
@@ -485,7 +490,8 @@ def embed_fwd(text_ids, image_feature, word, pos, typ, cls_id, sep_id, *, dtype=
         B, n_img, H = text_ids.shape[0], -1, word.shape[1]
     T = 0 if text_ids is None else text_ids.shape[1]
     Lq = T if n_img < 0 else n_img + 2 + T
-    out = torch.empty((B, Lq, H) if pack is None else (pack[2], H), dtype=dtype, device=word.device)
+    if out is None:
+        out = torch.empty((B, Lq, H) if pack is None else (pack[2], H), dtype=dtype, device=word.device)
     p = _embed_struct(dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_id, pos_offset, type_override)
     p.image_feature, p.out = _p(image_feature), _p(out)
     if pack is not None:

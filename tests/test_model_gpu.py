@@ -285,10 +285,13 @@ def _tiny_caption(M, specs, cd):
     return M.set_compute_dtype(model.cuda().eval(), cd), sd
 
 
-def test_greedy_decode_matches_full_recompute_oracle(M, specs):
-    """greedy_search with the KV cache (2-token steps) == the oracle's full-sequence recompute
-    (the reference's own greedy loop does not run under the installed HF)."""
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_greedy_decode_matches_full_recompute_oracle(M, specs, monkeypatch, graph):
+    """greedy_search with the KV cache (2-token steps; replayed HIP graph / eager loop) == the oracle's
+    full-sequence recompute (the reference's own greedy loop does not run under the
+    installed HF)."""
     from oracle import mvlt_oracle as O
+    monkeypatch.setenv("MVLT_DECODE_GRAPH", graph)
     model, sd = _tiny_caption(M, specs, F32)
     image, ids, _, _ = synth_batch(3, 24, seed=77, vocab=3000)
     out_ids, scores = model(image.cuda(), None, 1, 'unilm')
@@ -527,9 +530,11 @@ def test_packed_rows_full_size_bf16(M, monkeypatch):
     assert abs(dense - packed) < 3e-3 * abs(dense), (dense, packed)
 
 
-def test_greedy_decode_stops_where_the_per_token_check_would(M, specs):
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_greedy_decode_stops_where_the_per_token_check_would(M, specs, monkeypatch, graph):
     """The all-finished flag is read back every 8 tokens instead of every token (model.py:954); the returned
     ids / scores must be cut exactly where the reference's per-token check stops, finished rows emit PAD."""
+    monkeypatch.setenv("MVLT_DECODE_GRAPH", graph)
     model, _ = _tiny_caption(M, specs, F32)
     image, _, _, _ = synth_batch(2, 24, seed=78, vocab=3000)
     cfg = model.config
