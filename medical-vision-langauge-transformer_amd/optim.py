@@ -47,6 +47,41 @@ class FusedAdamW:
         """Gradients are overwritten (not accumulated) by every backward pass and
         parameters without a gradient are tracked per step, so nothing to clear."""
 
+    # ------------------------------------------------------------------ checkpoint / resume (absent in the reference)
+    def state_dict(self):
+        """Moments and per-parameter step counts keyed by parameter NAME (independent of the arena layout)."""
+        ar = self._state()
+        out = {"hyper": dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay),
+               "state": {}}
+        for name, p in zip(ar.names, ar.params):
+            o, n = ar.offset[id(p)], p.numel()
+            if ar.steps[id(p)] > 0:
+                out["state"][name] = dict(step=ar.steps[id(p)],
+                                          exp_avg=ar.exp_avg[o:o + n].view(p.shape).detach().cpu().clone(),
+                                          exp_avg_sq=ar.exp_avg_sq[o:o + n].view(p.shape).detach().cpu().clone())
+        return out
+
+    def load_state_dict(self, sd):
+        ar = self._state()
+        hp = sd.get("hyper", {})
+        self.lr = hp.get("lr", self.lr)
+        self.betas = tuple(hp.get("betas", self.betas))
+        self.eps = hp.get("eps", self.eps)
+        self.weight_decay = hp.get("weight_decay", self.weight_decay)
+        byname = dict(zip(ar.names, ar.params))
+        unknown = [k for k in sd["state"] if k not in byname]
+        if unknown:
+            raise KeyError(f"optimizer state for unknown parameters: {unknown[:5]}")
+        ar.exp_avg.zero_(); ar.exp_avg_sq.zero_()
+        for p in ar.params:
+            ar.steps[id(p)] = 0
+        for name, st in sd["state"].items():
+            p = byname[name]
+            o, n = ar.offset[id(p)], p.numel()
+            ar.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            ar.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            ar.steps[id(p)] = int(st["step"])
+
     # ------------------------------------------------------------------ update of a set of element ranges
     def _apply(self, ar: Arena, params) -> None:
         """AdamW over ``params`` (arena order): one launch per contiguous run with equal step count."""

@@ -564,3 +564,36 @@ def test_greedy_decode_stops_where_the_per_token_check_would(M, specs, monkeypat
         assert one.shape == (1, first[0] + 1) and one[0, -1].item() == eos and one_scores.numel() == first[0]
     finally:
         cfg.eos_token_id = old_eos
+
+
+def test_optimizer_state_resume_continues_identically(M, specs, monkeypatch, tmp_path):
+    """save_pretrained + FusedAdamW.state_dict -> fresh process-equivalent reload -> the next steps are the same."""
+    from mvlt_amd.train import PretrainStep
+    monkeypatch.setattr(random, "random", lambda: 0.9)
+    image, ids, labels, itm = (t.cuda() for t in synth_batch(3, 24, seed=41, vocab=3000))
+
+    def fresh():
+        cfg = tiny_cfg(M, ITM_task=True)
+        cfg.ITM_task = True
+        m = M.MVLBertForPretraining(cfg)
+        load_formula(m, specs["tiny_pretrain"])
+        return M.set_compute_dtype(m.cuda().eval(), F32)
+
+    a = fresh()
+    sa = PretrainStep(a, lr=1e-4)
+    for _ in range(2):
+        sa((image, ids, labels, itm))
+    a.save_pretrained(str(tmp_path))
+    torch.save(sa.opt.state_dict(), str(tmp_path / "optimizer.pt"))
+    la = [sa((image, ids, labels, itm)).item() for _ in range(2)]
+    b = M.MVLBertForPretraining.from_pretrained(str(tmp_path), config=a.config)
+    b = M.set_compute_dtype(b.cuda().eval(), F32)
+    sb = PretrainStep(b, lr=1e-4)
+    sb.opt.load_state_dict(torch.load(str(tmp_path / "optimizer.pt")))
+    lb = [sb((image, ids, labels, itm)).item() for _ in range(2)]
+    assert all(abs(x - y) < 2e-5 * abs(x) for x, y in zip(la, lb)), (la, lb)
+    # without the optimizer state the continuation differs (bias correction restarts): the check has teeth
+    c = M.set_compute_dtype(M.MVLBertForPretraining.from_pretrained(str(tmp_path), config=a.config).cuda().eval(), F32)
+    sc = PretrainStep(c, lr=1e-4)
+    lc = [sc((image, ids, labels, itm)).item() for _ in range(2)]
+    assert abs(lc[1] - la[1]) > 1e-6 * abs(la[1])
