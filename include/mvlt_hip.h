@@ -260,6 +260,29 @@ int mvlt_attn_cached(const MvltAttnCached* p, void* stream);
 /* argmax over V of logits [rows, ld] -> int64 ids (greedy_search, model.py:896-900) */
 int mvlt_argmax(int dtype, const void* logits, int64_t ld, int rows, int V, int64_t* out, void* stream);
 
+/* ------------------------------------------------------------------ input pipeline
+ * The reference prepares every sample on the host (run_pretrain_rgc_roco_medicat.py:94-212); these two entry
+ * points move the per-step arithmetic of that code to the GPU for pre-resized / pre-tokenised shards.
+ *
+ * Image normalisation (:107-110, :127-130): HWC uint8 RGB [B,H,W,3] -> CHW f32 [B,3,H,W] with, per image and
+ * channel, (x - mean_c) / var_c -- the reference divides by np.var (population VARIANCE, not the standard
+ * deviation); a constant channel gives 0/0 = NaN exactly as numpy does.  Sums are exact integers. */
+int mvlt_image_normalize(const uint8_t* hwc, float* chw, int B, int H, int W, void* stream);
+/* MLM masking, _random_mask_word (:188-212) + the truncation of :170-176, on already truncated id rows:
+ * n = min(10, max(1, round(0.2 * full_len[b]))) distinct token positions drawn uniformly from [0, full_len[b]);
+ * each: 80 % -> mask_id, 10 % -> uniform random id in [0, vocab_size), 10 % unchanged; label = original id.
+ * Position i of the untruncated caption lives at column i (i < T-1 or full_len <= T), the last token ([END]) at
+ * column T-1 when full_len > T; other positions were cut off and their masks are dropped, like the reference.
+ * Rows with itm_label[b] == 0 are left unmasked (:160-164).  Counter RNG (seed, row, position): statistically
+ * equivalent to the reference's Python `random`, not bit-identical.  ids_in/ids_out/labels: int64 [B,T]. */
+typedef struct MvltMlmMask {
+    int B, T, vocab_size, mask_id;
+    const int64_t* ids_in; const int32_t* full_len; const int64_t* itm_label;   /* itm_label may be NULL */
+    int64_t* ids_out; int64_t* labels;
+    uint64_t seed;
+} MvltMlmMask;
+int mvlt_mlm_mask(const MvltMlmMask* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

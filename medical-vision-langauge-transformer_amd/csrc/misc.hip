@@ -472,6 +472,59 @@ __global__ __launch_bounds__(64) void softmax_rows_kernel(const T* x, long ld, i
     for (int c = threadIdx.x; c < V; c += 64) out[(long)blockIdx.x * V + c] = __expf(to_f(r[c]) - mx) / s;
 }
 
+// ------------------------------------------------------------------ input pipeline
+// one workgroup per (image, channel): exact integer sums -> mean / population variance in f64 -> normalise
+__global__ __launch_bounds__(256) void image_normalize_kernel(const uint8_t* hwc, float* chw, int H, int W) {
+    __shared__ unsigned long long red[2][4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const long n = (long)H * W;
+    const uint8_t* src = hwc + (long)b * n * 3 + c;
+    unsigned long long s1 = 0, s2 = 0;
+    for (long i = threadIdx.x; i < n; i += 256) { const unsigned v = src[i * 3]; s1 += v; s2 += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = (double)s1 / (double)n;
+    const double var = (double)s2 / (double)n - mean * mean;
+    const float fm = (float)mean, fv = (float)var;
+    float* dst = chw + ((long)b * 3 + c) * n;
+    for (long i = threadIdx.x; i < n; i += 256) dst[i] = ((float)src[i * 3] - fm) / fv;
+}
+
+// one wave per caption
+__global__ __launch_bounds__(64) void mlm_mask_kernel(const MvltMlmMask p) {
+    __shared__ uint32_t key[1024];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t* in = p.ids_in + (long)b * p.T;
+    int64_t* out = p.ids_out + (long)b * p.T;
+    int64_t* lab = p.labels + (long)b * p.T;
+    for (int t = lane; t < p.T; t += 64) { out[t] = in[t]; lab[t] = -100; }
+    if (p.itm_label && p.itm_label[b] == 0) return;
+    const int Lf = min(p.full_len[b], 1024);
+    if (Lf <= 0) return;
+    int n = (int)rint(0.2 * (double)Lf);                 // Python round(): half to even, like rint
+    n = min(10, max(1, n));
+    for (int i = lane; i < Lf; i += 64) key[i] = rng_u32(p.seed, 2u * (uint32_t)b, (uint32_t)i);
+    __syncthreads();
+    for (int i = lane; i < Lf; i += 64) {
+        const uint32_t k = key[i];
+        int rank = 0;
+        for (int j = 0; j < Lf; ++j) rank += (key[j] < k) || (key[j] == k && j < i);
+        if (rank >= n) continue;                         // the n smallest keys = a uniform n-subset
+        int col = i;
+        if (Lf > p.T) { if (i == Lf - 1) col = p.T - 1; else if (i >= p.T - 1) continue; }   // cut off by :170-176
+        if (col >= p.T) continue;
+        const uint32_t r = rng_u32(p.seed, 2u * (uint32_t)b + 1u, (uint32_t)i);
+        const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+        lab[col] = in[col];
+        if (u < 0.8f) out[col] = p.mask_id;
+        else if (u < 0.9f) out[col] = (int64_t)(mix32(r ^ 0x85ebca6bU) % (uint32_t)p.vocab_size);
+    }
+}
+
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -671,6 +724,21 @@ extern "C" int mvlt_argmax(int dtype, const void* logits, int64_t ld, int rows, 
     MVLT_CHECK(logits && out && rows > 0 && V > 0 && ld >= V, MVLT_ERR_ARG);
     BY_DTYPE(dtype, hipLaunchKernelGGL(argmax_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), (const float*)logits, (long)ld, V, out),
              hipLaunchKernelGGL(argmax_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, (long)ld, V, out));
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_image_normalize(const uint8_t* hwc, float* chw, int B, int H, int W, void* stream) {
+    MVLT_CHECK(hwc && chw && B > 0 && H > 0 && W > 0, MVLT_ERR_ARG);
+    MVLT_CHECK((long)H * W < (1L << 24), MVLT_ERR_ARG);            // the u64 sums of squares cannot overflow far below this
+    hipLaunchKernelGGL(image_normalize_kernel, dim3(3, B), dim3(256), 0, STREAM(stream), hwc, chw, H, W);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+extern "C" int mvlt_mlm_mask(const MvltMlmMask* p, void* stream) {
+    MVLT_CHECK(p && p->ids_in && p->full_len && p->ids_out && p->labels, MVLT_ERR_ARG);
+    MVLT_CHECK(p->B > 0 && p->T > 0 && p->T <= 1024 && p->vocab_size > 0, MVLT_ERR_ARG);
+    hipLaunchKernelGGL(mlm_mask_kernel, dim3(p->B), dim3(64), 0, STREAM(stream), *p);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }
