@@ -742,6 +742,7 @@ int dispatch(AttnDev d, bool bwd, int dtype, hipStream_t s) {
     if (bwd && d.delta_ws) {           // two-launch backward (dQ+delta, then dK/dV): 2 workgroups per CU
         if (d.NT <= 5) return launch_split<T, 64, 5>(d, dtype, s);
         if (d.NT <= 9) return launch_split<T, 64, 9>(d, dtype, s);
+        if (d.NT <= 13) return launch_split<T, 64, 13>(d, dtype, s);      // seq 128 (L = 179, BASELINE config #5)
         return MVLT_ERR_UNSUPPORTED;
     }
     if (d.NT <= 5) return launch<T, 64, 5, false>(d, bwd, dtype, s);

@@ -55,6 +55,14 @@ class MVLBertConfig:
         for k, v in kwargs.items():
             setattr(self, k, v)
 
+    def use_swin_base(self, drop_path_rate=0.5):
+        """Swin-B (swin_base_patch4_window7_224: embed 128, depths 2/2/18/2, heads 4/8/16/32, drop path 0.5).
+        Its tokens are 1024-d: the reference has no way to feed them to the 768-d encoder, so this
+        build adds one Linear(1024, hidden_size) after the GELU (``conv.feature_proj``, BASELINE config #5)."""
+        self.swin.update(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], drop_path_rate=drop_path_rate)
+        self.swin_feature_proj = True
+        return self
+
     def update_special_tokens(self, tokenizer):
         self.eos_token_id, self.cls_token_id, self.sep_token_id, self.mask_token_id = \
             tokenizer.convert_tokens_to_ids(['[END]', '[CLS]', '[SEP]', '[MASK]'])
@@ -126,11 +134,15 @@ class Conv_layer(nn.Module):
         ckpt = getattr(config, "swin_checkpoint", None)
         if ckpt is not None and os.path.exists(ckpt):     # reference: torch.load(...)['model'], strict=False (model.py:222-226)
             conv.load_state_dict(torch.load(ckpt, map_location='cpu')['model'], strict=False)
-        if conv.num_features != config.hidden_size:
-            raise ValueError(f"Swin emits {conv.num_features}-d tokens but hidden_size is {config.hidden_size} "
-                             "(the reference has no projection for Swin features either, model.py:263)")
         self.conv = nn.Sequential(conv, _GeluMarker())
         self.resnet_fc = nn.Linear(2048, config.hidden_size)    # unused with Swin; kept for state-dict parity
+        self.feature_proj = None
+        if conv.num_features != config.hidden_size:
+            if not getattr(config, "swin_feature_proj", False):
+                raise ValueError(f"Swin emits {conv.num_features}-d tokens but hidden_size is {config.hidden_size} "
+                                 "(the reference has no projection for Swin features either, model.py:263); "
+                                 "set config.swin_feature_proj = True / config.use_swin_base() for the added Linear")
+            self.feature_proj = nn.Linear(conv.num_features, config.hidden_size)     # build-added (config #5)
 
     def forward(self, v):
         swin = self.conv[0]
@@ -138,9 +150,17 @@ class Conv_layer(nn.Module):
             # both views go through the (shared-weight) Swin as ONE batch of n*B images: one backward pass
             # produces the summed weight gradient, and the kernels see twice the rows
             B, n = v.shape[0], v.shape[1]
-            f = swin(v.transpose(0, 1).reshape(n * B, *v.shape[2:]), fuse_gelu=True)       # [n*B, 49, C]
+            f = self._project(swin(v.transpose(0, 1).reshape(n * B, *v.shape[2:]), fuse_gelu=True))   # [n*B, 49, H]
             return f.view(n, B, f.shape[1], f.shape[2]).transpose(0, 1).reshape(B, n * f.shape[1], f.shape[2])
-        return swin(v, fuse_gelu=True)
+        return self._project(swin(v, fuse_gelu=True))
+
+    def _project(self, f):
+        if self.feature_proj is None:
+            return f
+        B, n, C = f.shape
+        out = _FeatureProjFn.apply(_token(self.feature_proj, f.device), f.reshape(B * n, C).contiguous(),
+                                   self.feature_proj, torch.is_grad_enabled())
+        return out.view(B, n, -1)
 
 
 # ----------------------------------------------------------------------------- MLM head holders (HF BertOnlyMLMHead)
@@ -288,6 +308,30 @@ class _LinearCEFn(torch.autograd.Function):
         ar.mark(lin.weight, lin.bias)
         ctx.saved = None
         return None, dx, None, None, None
+
+
+class _FeatureProjFn(torch.autograd.Function):
+    """Linear in the compute dtype (Swin-B 1024-d tokens -> hidden_size)."""
+
+    @staticmethod
+    def forward(ctx, token, x, lin, save):
+        ar = Arena.of(lin, x.dtype)
+        ar.refresh_shadow()
+        ctx.lin, ctx.saved = lin, (ar, x) if save else None
+        return ops.gemm(x, ar.compute(lin.weight), bias=lin.bias.data)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ar, x = ctx.saved
+        backward_begin(ar)
+        lin = ctx.lin
+        dy = dy.contiguous()
+        dx = ops.gemm(dy, ar.compute(lin.weight), b_kmajor=True)
+        ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=ar.grad_view(lin.weight), out_f32=True,
+                 a_colsum=ar.grad_view(lin.bias))
+        ar.mark(lin.weight, lin.bias)
+        ctx.saved = None
+        return None, dx, None, None
 
 
 class _LinearFn(torch.autograd.Function):

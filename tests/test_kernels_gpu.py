@@ -278,7 +278,7 @@ def bert_ref(qkv, B, Lq, nH, mask_add, scale, keep=None, p=0.0):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("T,seq2seq,p", [(80, False, 0.0), (80, True, 0.0), (23, False, 0.0), (24, True, 0.1),
-                                         (80, False, 0.1)])
+                                         (80, False, 0.1), (128, False, 0.1), (128, True, 0.0)])   # 128: config #5 (L=179)
 def test_bert_attention(ops, dt, T, seq2seq, p):
     from mvlt_amd._lib import ATTN_BIDIR, ATTN_SEQ2SEQ
     from oracle import mvlt_oracle as O

@@ -597,3 +597,37 @@ def test_optimizer_state_resume_continues_identically(M, specs, monkeypatch, tmp
     sc = PretrainStep(c, lr=1e-4)
     lc = [sc((image, ids, labels, itm)).item() for _ in range(2)]
     assert abs(lc[1] - la[1]) > 1e-6 * abs(la[1])
+
+
+def test_swin_b_config5_projection_and_training_step(M):
+    """BASELINE config #5: Swin-B tokens (1024-d) + the build-added Linear(1024, 768) + BERT; not runnable in the
+    reference, so the check is against the oracle's Swin + an explicit torch Linear, then one step."""
+    import torch.nn.functional as F
+    from oracle import mvlt_oracle as O
+    from mvlt_amd.train import PretrainStep, synthetic_batch
+    cfg = M.MVLBertPretrainConfig(num_hidden_layers=2).use_swin_base(drop_path_rate=0.0)
+    cfg.swin.update(depths=[2, 2, 2, 2])              # Swin-B widths, fewer stage-2 blocks (test time)
+    cfg.ITM_task = True
+    with pytest.raises(ValueError):
+        bad = M.MVLBertPretrainConfig()
+        bad.swin.update(embed_dim=128, num_heads=[4, 8, 16, 32])
+        M.MVLBertForPretraining(bad)
+    torch.manual_seed(5)
+    model = M.MVLBertForPretraining(cfg)
+    assert "conv.feature_proj.weight" in model.state_dict() and model.conv.feature_proj.weight.shape == (768, 1024)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = M.set_compute_dtype(model.cuda().eval(), F32)
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        feat = model.conv(img.cuda())
+    assert feat.shape == (2, 49, 768)
+    scfg = O.SwinCfg(embed_dim=128, depths=(2, 2, 2, 2), num_heads=(4, 8, 16, 32), drop_path_rate=0.0)
+    with torch.no_grad():
+        ref = F.linear(F.gelu(O.swin_forward(img, sd, "conv.conv.0.", scfg)), sd["conv.feature_proj.weight"], sd["conv.feature_proj.bias"])
+    assert rel_err(feat.float().cpu(), ref) < 2e-4
+    model = M.set_compute_dtype(model.train(), BF16)
+    step = PretrainStep(model)
+    batch = synthetic_batch(4, 128, "cuda", 3, with_lengths=True)        # config #5 uses seq 128 -> L = 179
+    l0 = step(batch).item()
+    l1 = step(batch).item()
+    assert l0 == l0 and l1 == l1 and model.conv.feature_proj.weight.grad is not None
