@@ -272,7 +272,11 @@ class MVLBert(nn.Module):
         nH = cfg.num_attention_heads
         seed, p_h, p_a = sv["seed"], sv["p_h"], sv["p_a"]
         pack, rows = sv["pack"], sv["rows"]
-        dx = dhidden.contiguous().view(rows, H)
+        if dhidden is None:                      # only the pooled output was used (VQA / retrieval heads)
+            dx = torch.zeros((rows, H), dtype=sv["layers"][0][0].dtype, device=sv["layers"][0][0].device)
+            dhidden = dx.new_empty(0)
+        else:
+            dx = dhidden.contiguous().view(rows, H)
         if dx.data_ptr() == dhidden.data_ptr() and self.pooler is not None and sv["pooled"] is not None:
             dx = dx.clone()                      # we accumulate the pooler gradient into it
         if self.pooler is not None and sv["pooled"] is not None and dpooled is not None:

@@ -632,3 +632,78 @@ def test_swin_b_config5_projection_and_training_step(M):
     l0 = step(batch).item()
     l1 = step(batch).item()
     assert l0 == l0 and l1 == l1 and model.conv.feature_proj.weight.grad is not None
+
+
+# ------------------------------------------------------------------ fine-tuning paths: gradients vs the oracle
+def _tiny_oracle_cfgs():
+    from oracle import mvlt_oracle as O
+    scfg = O.SwinCfg(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), drop_path_rate=0.2)
+    bcfg = O.BertCfg(vocab_size=3000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024)
+    return O, scfg, bcfg
+
+
+def _grad_check(model, osd, keys, tol=5e-3):
+    named = dict(model.named_parameters())
+    bad = []
+    for k in keys:
+        g, r = named[k].grad, osd[k].grad
+        assert g is not None and r is not None, k
+        if rel_err(g.cpu(), r) > tol:
+            bad.append((k, rel_err(g.cpu(), r)))
+    assert not bad, bad
+
+
+def test_vqa_training_step_gradients_vs_oracle(M, specs):
+    """run_vqa.py trains MVLBertForVQA with CE on the logits (model.py:329-349): gradients, f32, eval-mode dropout."""
+    import torch.nn.functional as F
+    O, scfg, bcfg = _tiny_oracle_cfgs()
+    cfg = tiny_cfg(M, cls=M.MVLBertConfigforVQA)
+    cfg.result_num = 37
+    model = M.MVLBertForVQA(cfg)
+    torch.manual_seed(11)
+    for p in model.parameters():
+        if p.dim() > 1:
+            torch.nn.init.normal_(p, std=0.05)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = M.set_compute_dtype(model.cuda().eval(), F32)
+    image, ids, _, _ = synth_batch(3, 23, seed=51, vocab=3000)
+    label = torch.tensor([3, 17, 36])
+    prob, logits = model(image.cuda(), ids.cuda(), None)
+    F.cross_entropy(logits, label.cuda()).backward()
+    osd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    rprob, rlogits = O.vqa_forward(osd, scfg, bcfg, image, ids)
+    assert rel_err(logits.detach().cpu(), rlogits.detach()) < 2e-4
+    F.cross_entropy(rlogits, label).backward()
+    _grad_check(model, osd, ["final_mlp.1.weight", "final_mlp.1.bias", "MVLBert.pooler.dense.weight",
+                             "MVLBert.encoder.layer.1.output.dense.weight", "MVLBert.encoder.layer.0.attention.self.query.weight",
+                             "MVLBert.word_embeddings.weight", "conv.conv.0.layers.2.blocks.1.mlp.fc1.weight",
+                             "conv.conv.0.layers.0.blocks.1.attn.relative_position_bias_table", "conv.conv.0.patch_embed.proj.weight"])
+
+
+@pytest.mark.parametrize("strategy", ["unilm", "normal"])
+def test_caption_encode_forward_gradients_vs_oracle(M, specs, strategy):
+    """Report-generation training (run_report_generation_cxr.py): MVLBertForImageCaption.forward(num_beams=0) ->
+    encode_forward (model.py:519-546) -> CE on the [B, V, T] logits; IU-Xray image pairs (5-D input)."""
+    import torch.nn.functional as F
+    O, scfg, bcfg = _tiny_oracle_cfgs()
+    model, sd = _tiny_caption(M, specs, F32)
+    image, ids, _, _ = synth_batch(2, 12, seed=61, vocab=3000)
+    pair = torch.stack([image, image.flip(0)], 1)                 # [B, 2, 3, 224, 224]
+    target = torch.where(ids > 0, ids, torch.full_like(ids, -100))
+    logits = model(pair.cuda(), ids.cuda(), 0, strategy)          # [B, V, T]
+    assert logits.shape[0] == 2 and logits.shape[2] == 12
+    F.cross_entropy(logits.float(), target.cuda(), ignore_index=-100).backward()
+    osd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    feat = O.conv_layer(pair, osd, scfg)
+    o = O.mvlbert_forward(osd, bcfg, ids, feat, True)
+    n_img = feat.shape[1]
+    hidden = o["hidden"]
+    text, sep = hidden[:, n_img + 2:], hidden[:, n_img + 1]
+    src = text if strategy == "unilm" else torch.cat([sep[:, None], text[:, :-1]], 1)
+    ref = O.mlm_head(src, osd, "MLM_head_seq2seq", bcfg).transpose(1, 2)
+    assert rel_err(logits.detach().float().cpu(), ref.detach()) < 2e-4
+    F.cross_entropy(ref, target, ignore_index=-100).backward()
+    _grad_check(model, osd, ["MLM_head_seq2seq.predictions.decoder.weight", "MLM_head_seq2seq.predictions.transform.dense.weight",
+                             "MVLBert.encoder.layer.1.intermediate.dense.weight", "MVLBert.encoder.layer.0.attention.self.value.weight",
+                             "MVLBert.position_embeddings.weight", "conv.conv.0.layers.3.blocks.0.attn.qkv.weight",
+                             "conv.conv.0.layers.1.downsample.reduction.weight", "conv.conv.0.norm.weight"])
