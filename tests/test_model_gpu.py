@@ -707,3 +707,32 @@ def test_caption_encode_forward_gradients_vs_oracle(M, specs, strategy):
                              "MVLBert.encoder.layer.1.intermediate.dense.weight", "MVLBert.encoder.layer.0.attention.self.value.weight",
                              "MVLBert.position_embeddings.weight", "conv.conv.0.layers.3.blocks.0.attn.qkv.weight",
                              "conv.conv.0.layers.1.downsample.reduction.weight", "conv.conv.0.norm.weight"])
+
+
+def test_retrieval_head_training_gradients_vs_torch(M, specs):
+    """MVLBertForRetrieval with a label (model.py:444-476): logits through transform + Linear(H, 2); the gradient
+    of a CE loss reaches the head, the pooler, the encoder and the Swin (pooled-output-only backward path)."""
+    import torch.nn.functional as F
+    O, scfg, bcfg = _tiny_oracle_cfgs()
+    model = M.MVLBertForRetrieval(tiny_cfg(M, cls=M.MVLBertRetrieval))
+    torch.manual_seed(13)
+    for p in model.parameters():
+        if p.dim() > 1:
+            torch.nn.init.normal_(p, std=0.05)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = M.set_compute_dtype(model.cuda().eval(), F32)
+    image, ids, _, itm = synth_batch(3, 20, seed=71, vocab=3000)
+    logits = model(image.cuda(), ids.cuda(), itm.cuda())
+    assert logits.shape == (3, 2)
+    F.cross_entropy(logits.float(), itm.cuda()).backward()
+    osd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    feat = O.conv_layer(image, osd, scfg)
+    pooled = O.mvlbert_forward(osd, bcfg, ids, feat, False)["pooled"]
+    t = F.layer_norm(F.gelu(F.linear(pooled, osd["final_mlp.0.dense.weight"], osd["final_mlp.0.dense.bias"])), (256,),
+                     osd["final_mlp.0.LayerNorm.weight"], osd["final_mlp.0.LayerNorm.bias"], 1e-12)
+    ref = F.linear(t, osd["final_mlp.1.weight"], osd["final_mlp.1.bias"])
+    assert rel_err(logits.detach().float().cpu(), ref.detach()) < 2e-4
+    F.cross_entropy(ref, itm).backward()
+    _grad_check(model, osd, ["final_mlp.1.weight", "final_mlp.0.dense.weight", "final_mlp.0.LayerNorm.weight",
+                             "MVLBert.pooler.dense.weight", "MVLBert.encoder.layer.0.intermediate.dense.weight",
+                             "conv.conv.0.layers.2.blocks.0.attn.proj.weight"])
