@@ -26,9 +26,25 @@ MVLT_DEV float to_f(bf16_t x) { return (float)x; }
 template <typename T> MVLT_DEV T from_f(float x) { return (T)x; }
 
 // ---------------------------------------------------------------- math
-MVLT_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (nn.GELU default, HF "gelu").  erfc(z), z >= 0, by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, the
+// size of an f32 rounding step of the result): branch-free, one v_rcp + one v_exp -- libm's erff costs ~3x as
+// many instructions and sits in the epilogue of every FFN-in GEMM and its backward.  exp(-z^2) is returned too:
+// the backward needs the Gaussian density exp(-x^2/2) = exp(-z^2) with z = |x|/sqrt(2).
+MVLT_DEV float erfc_pos(float z, float& gauss) {
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    gauss = __expf(-z * z);
+    return poly * gauss;
+}
+MVLT_DEV float gelu_f(float x) {
+    float gauss;
+    const float ec = erfc_pos(fabsf(x) * 0.70710678118654752f, gauss);
+    return 0.5f * x * (x >= 0.f ? 2.0f - ec : ec);           // 1 + erf(x / sqrt 2)
+}
 MVLT_DEV float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    float gauss;
+    const float ec = erfc_pos(fabsf(x) * 0.70710678118654752f, gauss);
+    return 0.5f * (x >= 0.f ? 2.0f - ec : ec) + x * 0.3989422804014327f * gauss;
 }
 
 // Counter-based dropout RNG: keep(seed, tag, idx) is a pure function so the
