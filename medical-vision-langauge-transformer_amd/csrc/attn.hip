@@ -94,7 +94,12 @@ MVLT_DEV int rel_index(int q, int k) {
 // LDS carve-up (all float-aligned): images Q,K,V,(dO) then small arrays
 template <typename T> struct Smem {
     T* q; T* k; T* v; T* d; float* kmask; float* lse; float* delta; float* tbl; float* tblg;
+    f32x4* lb;       // Swin backward: per-lane bias values, [orientation A/B][KT][256 threads] (SwinLane)
 };
+__host__ __device__ inline size_t lane_bias_offset(int rows_alloc, int ld, size_t es, bool bwd) {
+    const size_t b = (size_t)(bwd ? 4 : 3) * rows_alloc * ld * es + (3 * (size_t)rows_alloc + 352) * sizeof(float);
+    return (b + 15) & ~(size_t)15;
+}
 template <typename T>
 MVLT_DEV Smem<T> carve(char* base, const AttnDev& p, bool bwd) {
     Smem<T> s;
@@ -104,11 +109,13 @@ MVLT_DEV Smem<T> carve(char* base, const AttnDev& p, bool bwd) {
     float* f = reinterpret_cast<float*>(base + (bwd ? 4 : 3) * img);
     s.kmask = f; s.lse = f + p.rows_alloc; s.delta = f + 2 * p.rows_alloc;
     s.tbl = f + 3 * p.rows_alloc; s.tblg = s.tbl + 176;
+    s.lb = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + lane_bias_offset(p.rows_alloc, p.ld, sizeof(T), bwd));
     return s;
 }
-static size_t smem_bytes(int dtype, int rows_alloc, int ld, bool bwd) {
+static size_t smem_bytes(int dtype, int rows_alloc, int ld, bool bwd, bool swin = false) {
     const size_t es = dtype == MVLT_BF16 ? 2 : 4;
-    return (size_t)(bwd ? 4 : 3) * rows_alloc * ld * es + (3 * (size_t)rows_alloc + 352) * sizeof(float);
+    // Swin backward: + two lane-bias tables of KT(=4) x 256 x 16 B
+    return lane_bias_offset(rows_alloc, ld, es, bwd) + ((bwd && swin) ? 2 * 4 * 256 * sizeof(f32x4) : 0);
 }
 
 // Register-batched staging of one [rows x HD] head slice: all 16-byte global loads of a slice are issued
@@ -177,6 +184,36 @@ MVLT_DEV void stage_small(const AttnDev& p, float* kmask, float* tbl, float* tbl
     }
 }
 
+// Swin: the (query, key) a lane's accumulator element belongs to is the same in every window, so the
+// relative-position bias of its KT*4 elements and, for shifted blocks, which of them straddle an image border
+// when the window lies in the last window row / column, are computed ONCE per workgroup (the per-element
+// work in the window loop drops to one fma and a bit test).  Orientation: KEYS_ON_ROWS -> element (t, j) is
+// key 16t + 4g + j against query `other`; otherwise query 16t + 4g + j against key `other`.
+template <int KT, bool KEYS_ON_ROWS>
+struct SwinLane {
+    float bias[KT][4];
+    uint32_t rowbits, colbits;
+    MVLT_DEV void init(const float* tbl, int other, int g, int shift) {
+        rowbits = colbits = 0;
+        const int oc = min(other, 48);
+        const int oy = div7(oc), ox = oc - 7 * oy;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tok = 16 * t + 4 * g + j;
+                const bool valid = tok < 49 && other < 49;
+                const int tc = min(tok, 48);
+                const int q = KEYS_ON_ROWS ? oc : tc, k = KEYS_ON_ROWS ? tc : oc;
+                bias[t][j] = valid ? tbl[rel_index(q, k)] : NEG_BIG;
+                const int ty = div7(tc), tx = tc - 7 * ty;
+                // last window row: image rows >= res-7, split at res-shift  <=>  token row < 7-shift or not
+                if (valid && ((ty < 7 - shift) != (oy < 7 - shift))) rowbits |= 1u << (4 * t + j);
+                if (valid && ((tx < 7 - shift) != (ox < 7 - shift))) colbits |= 1u << (4 * t + j);
+            }
+    }
+};
+
 // ------------------------------------------------------------------ forward
 template <typename T, int HD, int KT, bool SWIN>
 __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const AttnDev p) {
@@ -202,6 +239,12 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
         gv.load(base + 2 * C, 3 * C, 0, p.rows_alloc, ln);
     };
     if (SWIN && (int)blockIdx.x < p.nseq) issue(blockIdx.x);
+    SwinLane<SWIN ? KT : 1, true> sl;
+    if (SWIN) {
+        stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, 0, h, false);     // bias-table column of this head: once
+        __syncthreads();
+        sl.init(s.tbl, 16 * wave + c15, g, p.shift);                   // NT == 4 == waves: wave w owns query tile w
+    }
     for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
         const long rs = seq_row0(p, seq);
         const int Ls = seq_length(p, seq);
@@ -211,14 +254,15 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
         gq.store(s.q, p.ld, p.rows_alloc);
         gk.store(s.k, p.ld, p.rows_alloc);
         gv.store(s.v, p.ld, p.rows_alloc);
-        stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, false);
+        if (!SWIN) stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, false);
         __syncthreads();
         if (SWIN && seq + (int)gridDim.x < p.nseq) issue(seq + gridDim.x);      // next window in flight
         int wy = 0, wx = 0;
+        uint32_t mbits = 0;        // Swin: elements that get the -100 shift mask in this window (:318-344)
         if (SWIN) {
             const int w = seq % p.nW, nwx = p.res / 7;
             wy = w / nwx; wx = w % nwx;
-            if (p.shift == 0 || (wy != nwx - 1 && wx != nwx - 1)) wy = -1;     // no mask for this window
+            if (p.shift != 0) mbits = (wy == nwx - 1 ? sl.rowbits : 0u) | (wx == nwx - 1 ? sl.colbits : 0u);
         }
         for (int tq = wave; tq < nt; tq += 4) {
             f32x4 acc[KT];
@@ -241,8 +285,14 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int k = 16 * t + 4 * g + j;
-                    float v = (t < nt) ? acc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx, Ls) : NEG_BIG;
+                    float v;
+                    if (SWIN) {
+                        v = fmaf(acc[t][j], p.scale, sl.bias[SWIN ? t : 0][j]);
+                        if (mbits & (1u << (4 * t + j))) v -= 100.0f;
+                    } else {
+                        const int k = 16 * t + 4 * g + j;
+                        v = (t < nt) ? acc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx, Ls) : NEG_BIG;
+                    }
                     acc[t][j] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -325,6 +375,29 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
         gd.load(dout + r0 * C + h * HD, C, 0, p.rows_alloc, ln);
     };
     if (SWIN && (int)blockIdx.x < p.nseq) issue(blockIdx.x);
+    // Swin: window-invariant per-lane bias values of both orientations go to LDS once (registers are full),
+    // the shift-mask bit sets stay in 4 registers
+    uint32_t rowA = 0, colA = 0, rowB = 0, colB = 0;
+    f32x4* lbA = s.lb;
+    f32x4* lbB = s.lb + (SWIN ? KT : 0) * 256;
+    if (SWIN) {
+        stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, 0, h, true);
+        __syncthreads();
+        {
+            SwinLane<SWIN ? KT : 1, true> la;
+            la.init(s.tbl, 16 * wave + c15, g, p.shift);
+            rowA = la.rowbits; colA = la.colbits;
+#pragma unroll
+            for (int t = 0; t < (SWIN ? KT : 1); ++t) lbA[t * 256 + threadIdx.x] = f32x4{la.bias[t][0], la.bias[t][1], la.bias[t][2], la.bias[t][3]};
+        }
+        {
+            SwinLane<SWIN ? KT : 1, false> lbv;
+            lbv.init(s.tbl, 16 * wave + c15, g, p.shift);
+            rowB = lbv.rowbits; colB = lbv.colbits;
+#pragma unroll
+            for (int t = 0; t < (SWIN ? KT : 1); ++t) lbB[t * 256 + threadIdx.x] = f32x4{lbv.bias[t][0], lbv.bias[t][1], lbv.bias[t][2], lbv.bias[t][3]};
+        }
+    }
     for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
         const long rs = seq_row0(p, seq);
         const int Ls = seq_length(p, seq);
@@ -335,17 +408,21 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
         gk.store(s.k, p.ld, p.rows_alloc);
         gv.store(s.v, p.ld, p.rows_alloc);
         gd.store(s.d, p.ld, p.rows_alloc);
-        stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, true);
+        if (!SWIN) stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, true);
         // lse_q (delta_q = rowsum(P .* dP) is produced by phase A in registers: no O / dO pre-pass)
         for (int q = threadIdx.x; q < p.rows_alloc; q += 256)
             s.lse[q] = q < Ls ? p.lse[((long)seq * p.nH + h) * p.L + q] : 0.f;
         __syncthreads();
         if (SWIN && seq + (int)gridDim.x < p.nseq) issue(seq + gridDim.x);      // next window in flight
         int wy = 0, wx = 0;
+        uint32_t mbA = 0, mbB = 0;     // elements under the -100 shift mask in this window, per orientation
         if (SWIN) {
             const int w = seq % p.nW, nwx = p.res / 7;
             wy = w / nwx; wx = w % nwx;
-            if (p.shift == 0 || (wy != nwx - 1 && wx != nwx - 1)) wy = -1;     // no mask for this window
+            if (p.shift != 0) {
+                mbA = (wy == nwx - 1 ? rowA : 0u) | (wx == nwx - 1 ? colA : 0u);
+                mbB = (wy == nwx - 1 ? rowB : 0u) | (wx == nwx - 1 ? colB : 0u);
+            }
         }
 
         // ---- phase A: keys on accumulator rows, one query tile per wave -> dQ, dBias
@@ -379,7 +456,17 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
                 for (int j = 0; j < 4; ++j) {
                     const int k = 16 * t + 4 * g + j;
                     float pr = 0.f, dpv = 0.f;
-                    if (t < nt && k < Ls && q < Ls) {
+                    if (SWIN) {        // invalid (q, k) carry bias -1e30 -> p = 0; V rows beyond L are zero in LDS
+                        float lg = fmaf(sc[t][j], p.scale, lbA[(SWIN ? t : 0) * 256 + threadIdx.x][j]);
+                        if (mbA & (1u << (4 * t + j))) lg -= 100.0f;
+                        pr = __expf(lg - lse_q);
+                        dpv = dp[t][j];
+                        if (drop) {
+                            const uint32_t idx = (uint32_t)((((long)seq * p.nH + h) * p.L + q) * p.L + k);
+                            dpv = rng_keep(p.seed, p.tag, idx, p.drop_thresh) ? dpv * p.drop_scale : 0.0f;
+                        }
+                        dl += pr * dpv;
+                    } else if (t < nt && k < Ls && q < Ls) {
                         const float lg = sc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx, Ls);
                         pr = __expf(lg - lse_q);
                         dpv = dp[t][j];
@@ -450,8 +537,14 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
                 for (int j = 0; j < 4; ++j) {
                     const int q = 16 * t + 4 * g + j;
                     float pd = 0.f, ds = 0.f;
-                    if (t < nt && k < Ls && q < Ls) {
-                        const float lg = sc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx, Ls);
+                    if (SWIN || (t < nt && k < Ls && q < Ls)) {
+                        float lg;
+                        if (SWIN) {
+                            lg = fmaf(sc[t][j], p.scale, lbB[(SWIN ? t : 0) * 256 + threadIdx.x][j]);
+                            if (mbB & (1u << (4 * t + j))) lg -= 100.0f;
+                        } else {
+                            lg = sc[t][j] * p.scale + logit_bias<SWIN>(p, s.kmask, s.tbl, q, k, wy, wx, Ls);
+                        }
                         const float pr = __expf(lg - s.lse[q]);
                         float dpv = dp[t][j];
                         pd = pr;
@@ -705,7 +798,7 @@ int launch_split(const AttnDev& d, int dtype, hipStream_t s) {
 
 template <typename T, int HD, int KT, bool SWIN>
 int launch(const AttnDev& d, bool bwd, int dtype, hipStream_t s) {
-    const size_t sh = smem_bytes(dtype, d.rows_alloc, d.ld, bwd);
+    const size_t sh = smem_bytes(dtype, d.rows_alloc, d.ld, bwd, SWIN);
     if (sh > 160 * 1024) return MVLT_ERR_UNSUPPORTED;
     int gx = d.nseq;
     if (SWIN) {   // several windows per workgroup: the LDS bias-gradient table is flushed once
