@@ -260,6 +260,11 @@ int mvlt_attn_cached(const MvltAttnCached* p, void* stream);
 /* argmax over V of logits [rows, ld] -> int64 ids (greedy_search, model.py:896-900) */
 int mvlt_argmax(int dtype, const void* logits, int64_t ld, int rows, int V, int64_t* out, void* stream);
 
+/* zero up to 32 small f32 buffers in ONE launch (the relative-position-bias gradients of all Swin blocks are
+ * accumulated with atomics and must start from zero; items is a HOST array) */
+typedef struct MvltZeroItem { float* ptr; int64_t n; } MvltZeroItem;
+int mvlt_zero_batch(const MvltZeroItem* items, int n, void* stream);
+
 /* ------------------------------------------------------------------ input pipeline
  * The reference prepares every sample on the host (run_pretrain_rgc_roco_medicat.py:94-212); these two entry
  * points move the per-step arithmetic of that code to the GPU for pre-resized / pre-tokenised shards.

@@ -83,6 +83,10 @@ class MvltAttnCached(C.Structure):
                 ("qkv_new", vp), ("k_cache", vp), ("v_cache", vp), ("out", vp), ("scale", f32), ("past_dev", vp)]
 
 
+class MvltZeroItem(C.Structure):
+    _fields_ = [("ptr", vp), ("n", i64)]
+
+
 class MvltMlmMask(C.Structure):
     _fields_ = [("B", i32), ("T", i32), ("vocab_size", i32), ("mask_id", i32),
                 ("ids_in", vp), ("full_len", vp), ("itm_label", vp), ("ids_out", vp), ("labels", vp), ("seed", u64)]
@@ -122,6 +126,7 @@ SYMBOLS = {
     "mvlt_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "mvlt_attn_cached": (i32, [C.POINTER(MvltAttnCached), vp]),
     "mvlt_argmax": (i32, [i32, vp, i64, i32, i32, vp, vp]),
+    "mvlt_zero_batch": (i32, [C.POINTER(MvltZeroItem), i32, vp]),
     "mvlt_image_normalize": (i32, [vp, vp, i32, i32, i32, vp]),
     "mvlt_mlm_mask": (i32, [C.POINTER(MvltMlmMask), vp]),
 }

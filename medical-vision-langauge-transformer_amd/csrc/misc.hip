@@ -472,6 +472,12 @@ __global__ __launch_bounds__(64) void softmax_rows_kernel(const T* x, long ld, i
     for (int c = threadIdx.x; c < V; c += 64) out[(long)blockIdx.x * V + c] = __expf(to_f(r[c]) - mx) / s;
 }
 
+struct ZeroBatch { int n; MvltZeroItem it[32]; };
+__global__ __launch_bounds__(256) void zero_batch_kernel(const ZeroBatch b) {
+    const MvltZeroItem it = b.it[blockIdx.y];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < it.n; i += (long)gridDim.x * 256) it.ptr[i] = 0.f;
+}
+
 // ------------------------------------------------------------------ input pipeline
 // one workgroup per (image, channel): exact integer sums -> mean / population variance in f64 -> normalise
 __global__ __launch_bounds__(256) void image_normalize_kernel(const uint8_t* hwc, float* chw, int H, int W) {
@@ -740,5 +746,18 @@ extern "C" int mvlt_mlm_mask(const MvltMlmMask* p, void* stream) {
     MVLT_CHECK(p->B > 0 && p->T > 0 && p->T <= 1024 && p->vocab_size > 0, MVLT_ERR_ARG);
     hipLaunchKernelGGL(mlm_mask_kernel, dim3(p->B), dim3(64), 0, STREAM(stream), *p);
     MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_zero_batch(const MvltZeroItem* items, int n, void* stream) {
+    MVLT_CHECK(items && n >= 0, MVLT_ERR_ARG);
+    for (int i0 = 0; i0 < n; i0 += 32) {
+        ZeroBatch b{};
+        b.n = n - i0 < 32 ? n - i0 : 32;
+        long mx = 1;
+        for (int i = 0; i < b.n; ++i) { MVLT_CHECK(items[i0 + i].ptr && items[i0 + i].n >= 0, MVLT_ERR_ARG); b.it[i] = items[i0 + i]; if (b.it[i].n > mx) mx = b.it[i].n; }
+        hipLaunchKernelGGL(zero_batch_kernel, dim3(grid_for(mx, 256, 64), b.n), dim3(256), 0, STREAM(stream), b);
+        MVLT_LAUNCH_CHECK();
+    }
     return MVLT_OK;
 }

@@ -265,6 +265,15 @@ def wgrad_group(items):
         evs[1].record(st)
 
 
+def zero_batch(tensors):
+    """Zero several small f32 tensors in one launch."""
+    arr = (L.MvltZeroItem * len(tensors))()
+    for i, t in enumerate(tensors):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        arr[i].ptr, arr[i].n = t.data_ptr(), t.numel()
+    L.check(L.lib().mvlt_zero_batch(arr, len(tensors), _stream()), "mvlt_zero_batch")
+
+
 def colsum(x, out=None, accumulate=False):
     """out[n] = sum_m x[m,n] (f32) -- bias gradients."""
     _need_cuda(x)
