@@ -89,6 +89,12 @@ int mvlt_gemm_plan(const MvltGemm* p, int* bm, int* bn, int* split_k);
  * lists are concatenated (gemm_group_kernel<dtype,64,bn>), no split-K, no workspace.
  * MVLT_ERR_UNSUPPORTED if the items do not qualify (launch them one by one then). */
 int mvlt_gemm_group(const MvltGemm* items, int n, void* stream);
+/* Last-row MLM head fused with the greedy pick (model.py:896-900): out_idx[m] = argmax_n (A W^T + bias)[m, n]
+ * (first index on ties), out_val[m] = that maximum (f32, may be NULL); the logits are never stored.  M <= 64,
+ * both operands k-contiguous (MVLT_ERR_UNSUPPORTED otherwise); only MVLT_EPI_BIAS is honoured; C is unused.
+ * part_val / part_idx: scratch, M * ceil(N / 16) elements each. */
+int mvlt_gemm_argmax(const MvltGemm* p, float* part_val, int32_t* part_idx, int64_t* out_idx, float* out_val,
+                     void* stream);
 
 /* column sums: out[n] = sum_m x[m*ld + n]  (bias gradients), f32 out.
  * workspace: f32 [mvlt_colsum_workspace_rows(M)][N]. */

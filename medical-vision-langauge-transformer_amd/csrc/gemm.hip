@@ -339,8 +339,12 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
 // its 8 waves split K (3 k-blocks in flight per wave: the loop is latency bound, so memory-level parallelism is
 // what matters), partial accumulators meet in LDS, wave i < 4 finishes row tile i.
 constexpr int SKINNY_WAVES = 8, SKINNY_UNROLL = 3;
-template <typename T>
-__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const GemmDev p) {
+// ARGMAX (greedy decoding, model.py:896-900): instead of storing the logits, every workgroup reduces its 16
+// columns to (max, first index of the max) per row -> part_val/part_idx [M][gridDim.x]; argmax_parts_kernel
+// finishes the rows.  The maximum is taken over the f32 accumulators (+ bias).
+struct ArgmaxOut { float* part_val; int* part_idx; };
+template <typename T, bool ARGMAX = false>
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const GemmDev p, const ArgmaxOut am) {
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
     constexpr int KB = M_::KB, E = TypeInfo<T>::E;
@@ -384,8 +388,44 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Ge
 #pragma unroll
         for (int w = 1; w < SKINNY_WAVES; ++w) v += red[w][i][lane];
         // acc[r] <-> n = n0 + 4*g + r, m = 16*i + (lane & 15)   (same orientation as gemm_body)
-        epilogue4<T>(p, 16 * i + r15, n0 + 4 * g, v);
+        if (!ARGMAX) {
+            epilogue4<T>(p, 16 * i + r15, n0 + 4 * g, v);
+        } else {
+            float best = -3.0e38f; int bi = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 4 * g + r;
+                if (n < p.N) {
+                    const float x = v[r] + ((p.epi & MVLT_EPI_BIAS) ? p.bias[n] : 0.f);
+                    if (x > best) { best = x; bi = n; }          // ascending n: ties keep the first index
+                }
+            }
+#pragma unroll
+            for (int o = 16; o < 64; o <<= 1) {
+                const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            const int m = 16 * i + r15;
+            if (g == 0 && m < p.M) { am.part_val[(long)m * gridDim.x + blockIdx.x] = best; am.part_idx[(long)m * gridDim.x + blockIdx.x] = bi; }
+        }
     }
+}
+
+// one wave per row: (max, first index) over the workgroup partials
+__global__ __launch_bounds__(64) void argmax_parts_kernel(const float* part_val, const int* part_idx, int nparts,
+                                                          int64_t* out_idx, float* out_val) {
+    const long base = (long)blockIdx.x * nparts;
+    float best = -3.0e38f; int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < nparts; i += 64) {
+        const float v = part_val[base + i]; const int idx = part_idx[base + i];
+        if (v > best || (v == best && idx < bi)) { best = v; bi = idx; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (threadIdx.x == 0) { out_idx[blockIdx.x] = bi; if (out_val) out_val[blockIdx.x] = best; }
 }
 
 // Several independent products in one launch (the weight gradients of one layer): the tile lists of the
@@ -577,7 +617,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     GemmDev d;
     { const int rc = fill_dev<T>(p, pl, d); if (rc != MVLT_OK) return rc; }
     if (skinny) {
-        hipLaunchKernelGGL((gemm_skinny_kernel<T>), dim3(ceil_div(p->N, 16)), dim3(64 * SKINNY_WAVES), 0, s, d);
+        hipLaunchKernelGGL((gemm_skinny_kernel<T, false>), dim3(ceil_div(p->N, 16)), dim3(64 * SKINNY_WAVES), 0, s, d, ArgmaxOut{nullptr, nullptr});
         MVLT_LAUNCH_CHECK();
         if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
         return MVLT_OK;
@@ -652,6 +692,33 @@ extern "C" int mvlt_gemm_group(const MvltGemm* items, int n, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (items[0].dtype == MVLT_F32) return gemm_group_dispatch<float>(items, n, s);
     if (items[0].dtype == MVLT_BF16) return gemm_group_dispatch<bf16_t>(items, n, s);
+    return MVLT_ERR_UNSUPPORTED;
+}
+
+template <typename T>
+static int gemm_argmax_dispatch(const MvltGemm* p, float* part_val, int32_t* part_idx, int64_t* out_idx, float* out_val,
+                                hipStream_t s) {
+    MVLT_CHECK(is_skinny<T>(p) && (p->lda % TypeInfo<T>::E == 0) && (p->ldb % TypeInfo<T>::E == 0) &&
+               aligned16(p->A) && aligned16(p->B), MVLT_ERR_UNSUPPORTED);
+    MVLT_CHECK((p->epilogue & ~(MVLT_EPI_BIAS)) == 0, MVLT_ERR_UNSUPPORTED);
+    GemmDev d;
+    Plan pl{64, 16, 1};
+    { const int rc = fill_dev<T>(p, pl, d); if (rc != MVLT_OK) return rc; }
+    const int nblk = ceil_div(p->N, 16);
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, true>), dim3(nblk), dim3(64 * SKINNY_WAVES), 0, s, d, ArgmaxOut{part_val, part_idx});
+    hipLaunchKernelGGL(argmax_parts_kernel, dim3(p->M), dim3(64), 0, s, part_val, part_idx, nblk, out_idx, out_val);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_gemm_argmax(const MvltGemm* p, float* part_val, int32_t* part_idx, int64_t* out_idx, float* out_val,
+                                void* stream) {
+    MVLT_CHECK(p && p->A && p->B && part_val && part_idx && out_idx, MVLT_ERR_ARG);
+    MVLT_CHECK(p->M > 0 && p->N > 0 && p->K > 0 && p->lda > 0 && p->ldb > 0, MVLT_ERR_ARG);
+    if (p->epilogue & MVLT_EPI_BIAS) MVLT_CHECK(p->bias, MVLT_ERR_ARG);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p->dtype == MVLT_F32) return gemm_argmax_dispatch<float>(p, part_val, part_idx, out_idx, out_val, s);
+    if (p->dtype == MVLT_BF16) return gemm_argmax_dispatch<bf16_t>(p, part_val, part_idx, out_idx, out_val, s);
     return MVLT_ERR_UNSUPPORTED;
 }
 

@@ -126,11 +126,9 @@ class _GreedyGraph:
         model = self.model
         ar = Arena.of(model, self.cd)
         hd = model.MLM_head_seq2seq
-        V = hd.predictions.decoder.out_features
         _, _, t2, _, _ = hd._transform(ar, self.hlast, False)
-        logits, _ = hd._logits(ar, t2)
-        nxt = ops.argmax(logits, V)
-        score = logits[:, :V].float().gather(1, nxt[:, None]).squeeze(1)
+        # decoder GEMM fused with the greedy pick: the [B, 30522] logits are never written
+        nxt, score = ops.gemm_argmax(t2, ar.compute(hd.predictions.decoder.weight), hd.predictions.decoder.bias.data)
         if self.eos is not None:
             nxt = nxt * self.unfinished + self.pad * (1 - self.unfinished)
             self.unfinished.mul_((nxt != self.eos).long())
@@ -236,6 +234,8 @@ def greedy_search(model, image_feature, learning_strategy='unilm', sample_mode='
 
     def next_from(hlast):
         pre, t1, t2, _, _ = head._transform(ar, hlast.contiguous(), False)
+        if sample_mode == 'greedy' and t2.shape[0] <= 64:
+            return ops.gemm_argmax(t2, ar.compute(head.predictions.decoder.weight), head.predictions.decoder.bias.data)
         logits, _ = head._logits(ar, t2)
         if sample_mode == 'greedy':
             nxt = ops.argmax(logits, V)

@@ -226,6 +226,27 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
     return out
 
 
+def gemm_argmax(A, W, bias=None):
+    """argmax_n (A @ W^T + bias) and its value, without materialising the logits (greedy decoding).
+    A: [M <= 64, K], W: [N, K] -> (int64 [M], f32 [M])."""
+    _need_cuda(A, W)
+    M, K = A.shape
+    N = W.shape[0]
+    p = L.MvltGemm()
+    p.dtype, p.M, p.N, p.K = _dt(A), M, N, K
+    p.A, p.lda, p.B, p.ldb = _p(A), _ld(A), _p(W), _ld(W)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+        p.epilogue, p.bias = L.EPI_BIAS, _p(bias)
+    nblk = (N + 15) // 16
+    pv = torch.empty((M, nblk), dtype=torch.float32, device=A.device)
+    pi = torch.empty((M, nblk), dtype=torch.int32, device=A.device)
+    idx = torch.empty(M, dtype=torch.int64, device=A.device)
+    val = torch.empty(M, dtype=torch.float32, device=A.device)
+    L.check(L.lib().mvlt_gemm_argmax(C.byref(p), _p(pv), _p(pi), _p(idx), _p(val), _stream()), "mvlt_gemm_argmax")
+    return idx, val
+
+
 def wgrad_group(items):
     """Weight gradients of one layer: items = [(dY [R,No], X [R,Ni], dW f32 [No,Ni], dbias f32 [No] | None), ...]
     -> dW_i = dY_i^T X_i (and dbias_i = column sums of dY_i).  When the items qualify (mvlt_gemm_group) and

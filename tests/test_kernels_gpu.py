@@ -158,6 +158,25 @@ def test_gemm_skinny(ops, dt, M, N, K):
     assert rel(ops.gemm(big[:, 1], w), big[:, 1].float() @ w.float().t()) < tol(dt)
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(32, 30522, 768), (3, 3000, 256), (64, 17, 64)])
+def test_gemm_argmax_fused(ops, dt, M, N, K):
+    """mvlt_gemm_argmax: greedy pick straight from the decoder GEMM == argmax of the materialised f32 logits."""
+    a, w = rnd((M, K), dt, 1, 0.5), rnd((N, K), dt, 2, 0.5)
+    bias = rnd((N,), torch.float32, 3)
+    idx, val = ops.gemm_argmax(a, w, bias)
+    ref = a.float() @ w.float().t() + bias
+    rv, ri = ref.max(-1)
+    assert torch.allclose(val, rv, rtol=2e-5 if dt == torch.float32 else 1e-3, atol=1e-4)
+    # near-ties may legitimately resolve differently under a different summation order: the picked logit must be the max
+    assert torch.allclose(ref.gather(1, idx[:, None]).squeeze(1), rv, rtol=2e-5 if dt == torch.float32 else 1e-3, atol=1e-4)
+    assert (idx == ri).float().mean() > 0.9
+    w2 = w.clone(); w2[5] = w2[2]                       # exact tie between columns 2 and 5 -> first index wins
+    b2 = bias.clone(); b2[5] = b2[2] = 1e4
+    idx2, _ = ops.gemm_argmax(a, w2, b2)
+    assert (idx2 == 2).all()
+
+
 def test_gemm_bad_args(ops):
     A = torch.zeros(4, 4, device="cuda")
     with pytest.raises(AssertionError):
