@@ -159,7 +159,9 @@ def main():
     model = M.MVLBertForPretraining(cfg).cuda().train()
     M.manual_seed(4321 + rank)                      # dropout stream differs per rank
     seed_coin_flip(5678)                            # seq2seq/bidir flip identical on all ranks
-    reducer = GradReducer(model) if use_dist else None
+    # MVLT_DDP_BF16=1: bf16-compressed gradient exchange (non-default; the reference-equivalent sum is f32)
+    comm = torch.bfloat16 if os.environ.get("MVLT_DDP_BF16") == "1" else torch.float32
+    reducer = GradReducer(model, comm_dtype=comm) if use_dist else None
     step = PretrainStep(model, reducer=reducer, world_size=world)
     # captions are zero-padded to seq80 (lengths U{16..79}).  The padded tail of a caption is a
     # masked key (bidir) / above the causal diagonal (seq2seq) and carries no label, so nothing that reaches

@@ -58,7 +58,16 @@ def plan_ranges(arena: Arena, lo: int, hi: int, done: set) -> List[Tuple[int, in
 
 
 class GradReducer:
-    def __init__(self, model, bucket_bytes: int = 64 << 20, process_group=None, allow_cpu: bool = False):
+    def __init__(self, model, bucket_bytes: int = 64 << 20, process_group=None, allow_cpu: bool = False,
+                 comm_dtype: torch.dtype = torch.float32):
+        """comm_dtype=torch.bfloat16: buckets are cast to bf16 for the exchange and back afterwards (half the xGMI
+        bytes; the cross-rank sum is then rounded to bf16 -- PyTorch DDP's bf16_compress_hook trade-off).  The
+        default keeps the reference-equivalent f32 sum."""
+        if comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("comm_dtype must be float32 or bfloat16")
+        self.comm_dtype = comm_dtype
+        self.comm_buf = None
+        self.pending_casts = []
         self.model = model
         self.bucket_elems = bucket_bytes // 4
         self.pg = process_group
@@ -89,6 +98,7 @@ class GradReducer:
     def _begin(self, arena: Arena) -> None:
         self.pending_hi = arena.total
         self.handles, self.launched, self.done = [], [], set()
+        self.pending_casts = []
 
     def _on_watermark(self, arena: Arena, lo: int) -> None:
         if self.pending_hi - lo >= self.bucket_elems:
@@ -101,7 +111,23 @@ class GradReducer:
             ops.LnReduceQueue.flush_all()         # LayerNorm gamma/beta gradients are reduced in deferred batches
             ops.join_side(arena.flat.device)      # weight gradients are produced on the side stream
         ranges = plan_ranges(arena, lo, hi, self.done)
-        hs = [dist.all_reduce(arena.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for a, b in ranges]
+        if self.comm_dtype == torch.float32:
+            hs = [dist.all_reduce(arena.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for a, b in ranges]
+        else:
+            if self.on_bucket is not None:
+                raise RuntimeError("compressed gradient exchange cannot feed the overlapped optimizer")
+            if self.comm_buf is None or self.comm_buf.numel() != arena.total:
+                self.comm_buf = torch.empty(arena.total, dtype=self.comm_dtype, device=arena.grad.device)
+            hs = []
+            for a, b in ranges:
+                buf = self.comm_buf[a:b]
+                if arena.grad.is_cuda:
+                    from . import ops
+                    ops.cast(arena.grad[a:b], self.comm_dtype, out=buf)
+                else:
+                    buf.copy_(arena.grad[a:b])
+                hs.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self.pending_casts.append((a, b))
         self.handles += hs
         self.launched += ranges
         if self.on_bucket is not None and ranges:
@@ -115,3 +141,10 @@ class GradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
+        for a, b in self.pending_casts:          # compressed exchange: summed bf16 -> f32 gradient arena
+            if arena.grad.is_cuda:
+                from . import ops
+                ops.cast(self.comm_buf[a:b], torch.float32, out=arena.grad[a:b])
+            else:
+                arena.grad[a:b].copy_(self.comm_buf[a:b])
+        self.pending_casts = []
