@@ -11,7 +11,8 @@ slot" (model.py:890-894) is just ``past += 1``: the next step overwrites it.
 Greedy mode replays one captured HIP graph per token (``_GreedyGraph``: position,
 output column and finished flags live on the device; ``MVLT_DECODE_GRAPH=0`` selects
 the eager loop, which 'sample' mode always uses).
-Beam search is not built.
+Beam search (``beam_search``): same cached steps over B*beams rows, cache rows gathered by beam
+index, scorer bookkeeping restated from HF transformers 4.16 (parity with the reference unpinned).
 """
 from __future__ import annotations
 
@@ -291,3 +292,174 @@ def greedy_search(model, image_feature, learning_strategy='unilm', sample_mode='
     input_ids = torch.cat(ids_cols, dim=-1) if ids_cols else None
     token_scores = torch.cat(scores, dim=-1) if scores else torch.empty(0, device=dev)
     return input_ids, token_scores
+
+
+# ----------------------------------------------------------------------------- beam search (model.py:636-816)
+class BeamHypotheses:
+    """n-best list of finished hypotheses of one sample (HF transformers 4.16 ``BeamHypotheses``)."""
+
+    def __init__(self, num_beams, length_penalty, early_stopping):
+        self.num_beams, self.length_penalty, self.early_stopping = num_beams, length_penalty, early_stopping
+        self.beams = []
+        self.worst_score = 1e9
+
+    def __len__(self):
+        return len(self.beams)
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / (len(hyp) ** self.length_penalty)
+        if len(self) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self) > self.num_beams:
+                ranked = sorted((s, i) for i, (s, _) in enumerate(self.beams))
+                del self.beams[ranked[0][1]]
+                self.worst_score = ranked[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self) < self.num_beams:
+            return False
+        if self.early_stopping:
+            return True
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+
+
+class BeamScorer:
+    """The bookkeeping of HF ``BeamSearchScorer`` as of transformers 4.16 (``process`` / ``finalize``) with the
+    reference's construction arguments (model.py:505-507: length_penalty 1.0, early stopping off, one hypothesis
+    kept per sample).  The reference pins transformers only as ``>=4.16.0`` and the installed 5.x no longer has
+    the class, so this is restated from the 4.16 semantics: parity with the reference is UNPINNED.
+    Works on host lists; the device tensors are read back once per step, as the HF scorer does (`.item()`)."""
+
+    def __init__(self, batch_size, num_beams, length_penalty=1.0, do_early_stopping=False):
+        self.num_beams = num_beams
+        self.hyps = [BeamHypotheses(num_beams, length_penalty, do_early_stopping) for _ in range(batch_size)]
+        self.done = [False] * batch_size
+
+    @property
+    def is_done(self):
+        return all(self.done)
+
+    def process(self, input_ids, next_scores, next_tokens, next_indices, pad_token_id, eos_token_id):
+        """input_ids: list[B*beams] of token lists; next_*: [B][2*beams] lists.  Returns three flat lists."""
+        nb = self.num_beams
+        cur_len = len(input_ids[0])
+        out_s, out_t, out_i = [], [], []
+        for b, hyp in enumerate(self.hyps):
+            if self.done[b]:
+                out_s += [0.0] * nb; out_t += [pad_token_id] * nb; out_i += [0] * nb
+                continue
+            kept = 0
+            for rank, (tok, sc, idx) in enumerate(zip(next_tokens[b], next_scores[b], next_indices[b])):
+                row = b * nb + idx
+                if eos_token_id is not None and tok == eos_token_id:
+                    if rank >= nb:
+                        continue
+                    hyp.add(list(input_ids[row]), sc)
+                else:
+                    out_s.append(sc); out_t.append(tok); out_i.append(row)
+                    kept += 1
+                if kept == nb:
+                    break
+            if kept < nb:
+                raise ValueError(f"At most {nb} tokens in {next_tokens[b]} can be equal to `eos_token_id`")
+            self.done[b] = self.done[b] or hyp.is_done(max(next_scores[b]), cur_len)
+        return out_s, out_t, out_i
+
+    def finalize(self, input_ids, final_beam_scores, max_length, pad_token_id, eos_token_id):
+        nb = self.num_beams
+        for b, hyp in enumerate(self.hyps):
+            if self.done[b]:
+                continue
+            for k in range(nb):
+                hyp.add(list(input_ids[b * nb + k]), final_beam_scores[b * nb + k])
+        best = [sorted(h.beams, key=lambda x: x[0])[-1][1] for h in self.hyps]
+        lengths = [len(h) for h in best]
+        width = min(max(lengths) + 1, max_length)
+        out = [[pad_token_id] * width for _ in best]
+        for i, h in enumerate(best):
+            out[i][:len(h)] = h[:width]
+            if len(h) < max_length and len(h) < width:
+                out[i][len(h)] = eos_token_id
+        return out
+
+
+@torch.no_grad()
+def beam_search(model, image_feature, num_beams, learning_strategy='unilm', max_length=None, pad_token_id=None,
+                eos_token_id=None):
+    """``MVLBertForImageCaption.beam_search`` (model.py:636-816) with the KV cache: scores = log_softmax(logits) +
+    beam score, top 2*beams over (beam, token), scorer bookkeeping, cache rows gathered by ``beam_idx`` (:758-763).
+    Step 0 runs once per image (all beams of a sample start identical and only beam 0 carries score 0, :681-682),
+    then 2-token cached steps over the B*beams rows.  Returns the sequences [B, <= max_length] (:795-815)."""
+    if learning_strategy != 'unilm':
+        raise NotImplementedError("only learning_strategy='unilm' is coherent with the KV cache (SURVEY.md 3.3)")
+    mv, cfg = model.MVLBert, model.config
+    cd = compute_dtype_of(model)
+    ar = Arena.of(model, cd)
+    ar.refresh_shadow()
+    max_length = max_length if max_length is not None else cfg.max_length
+    pad = pad_token_id if pad_token_id is not None else cfg.pad_token_id
+    eos = eos_token_id if eos_token_id is not None else cfg.eos_token_id
+    tok = getattr(model, "tokenizer", None)
+    mask_id = tok.mask_token_id if tok is not None else cfg.mask_token_id
+    feat = image_feature.to(cd).contiguous()
+    B, n_img, H = feat.shape
+    nH = cfg.num_attention_heads
+    hd = H // nH
+    nl = len(mv.encoder.layer)
+    dev = feat.device
+    head = model.MLM_head_seq2seq
+    V = head.predictions.decoder.out_features
+    nb = num_beams
+    cap = n_img + 2 + max_length + 1
+    scorer = BeamScorer(B, nb)
+
+    def logp_of(hlast):
+        _, _, t2, _, _ = head._transform(ar, hlast.contiguous(), False)
+        logits, _ = head._logits(ar, t2)
+        return torch.log_softmax(logits[:, :V].float(), dim=-1)
+
+    # ---- step 0 on the B images; caches replicated to the beams afterwards
+    mask_col = torch.full((B, 1), mask_id, dtype=torch.int64, device=dev)
+    hidden, _, saved = mv._forward(feat, mask_col, mask_col, None, True, True)
+    L0 = n_img + 3
+    past = L0 - 1
+    rep = torch.arange(B, device=dev).repeat_interleave(nb)
+    kc, vc = [], []
+    for i in range(nl):
+        k1 = torch.zeros((B, nH, cap, hd), dtype=cd, device=dev)
+        v1 = torch.zeros((B, nH, cap, hd), dtype=cd, device=dev)
+        _fill_cache_from_qkv(saved["layers"][i][1], B, L0, nH, hd, k1, v1, past)
+        kc.append(k1.index_select(0, rep)); vc.append(v1.index_select(0, rep))
+    del saved
+    logp = logp_of(hidden[:, -1]).index_select(0, rep)                        # [B*nb, V]
+    beam_scores = torch.zeros((B, nb), dtype=torch.float32, device=dev)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    input_ids = [[mask_id] for _ in range(B * nb)]        # what the reference hands the scorer at step 0 (:701-702)
+    mask2 = torch.full((B * nb, 1), mask_id, dtype=torch.int64, device=dev)
+    cur_len = 0
+    while cur_len < max_length:
+        scores = (logp + beam_scores[:, None]).view(B, nb * V)
+        top_s, top_t = torch.topk(scores, 2 * nb, dim=1, largest=True, sorted=True)
+        top_i = torch.div(top_t, V, rounding_mode="floor")
+        top_t = top_t % V
+        s_l, t_l, i_l = scorer.process(input_ids, top_s.tolist(), top_t.tolist(), top_i.tolist(), pad, eos)
+        beam_scores = torch.tensor(s_l, dtype=torch.float32, device=dev)
+        beam_tok = torch.tensor(t_l, dtype=torch.int64, device=dev)
+        beam_idx = torch.tensor(i_l, dtype=torch.int64, device=dev)
+        input_ids = [[t] for t in t_l] if cur_len == 0 else [input_ids[i] + [t] for i, t in zip(i_l, t_l)]
+        cur_len += 1
+        if scorer.is_done or cur_len >= max_length:
+            break
+        for i in range(nl):                                  # beam reorder of the cache (model.py:758-763)
+            kc[i] = kc[i].index_select(0, beam_idx)
+            vc[i] = vc[i].index_select(0, beam_idx)
+        new_ids = torch.cat([beam_tok[:, None], mask2], dim=1)
+        x = _embed_new(mv, new_ids, past, cd).view(B * nb * 2, H)
+        h = _layers_cached(mv, ar, x, kc, vc, past, 2).view(B * nb, 2, H)
+        past += 1
+        logp = logp_of(h[:, -1])
+    seqs = scorer.finalize(input_ids, beam_scores.tolist(), cfg.max_length, pad, eos)
+    return torch.tensor(seqs, dtype=torch.int64, device=dev)

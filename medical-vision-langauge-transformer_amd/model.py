@@ -558,7 +558,7 @@ class _TransformLinearFn(torch.autograd.Function):
 
 
 class MVLBertForImageCaption(MVLBertPretrainedModel):
-    """model.py:479-546 (+ greedy_search :826-984 in decode.py)."""
+    """model.py:479-546 (+ greedy_search :826-984 and beam_search :636-816 in decode.py)."""
 
     def __init__(self, config, tokenizer=None):
         super().__init__(config)
@@ -572,8 +572,8 @@ class MVLBertForImageCaption(MVLBertPretrainedModel):
         Arena.of(self, compute_dtype_of(self))
         image_feature = self.conv(image)
         if num_beams > 1:
-            raise NotImplementedError("beam search needs HF BeamSearchScorer semantics (third-party, unpinned): "
-                                      "parity unpinned -> not built; use num_beams=1 (greedy)")
+            from .decode import beam_search          # scorer restated from HF 4.16: parity unpinned
+            return beam_search(self, image_feature, num_beams, learning_strategy=learning_strategy)
         if num_beams == 1:
             from .decode import greedy_search
             return greedy_search(self, image_feature, learning_strategy=learning_strategy, sample_mode=sample_mode)

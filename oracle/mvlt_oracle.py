@@ -450,6 +450,104 @@ def greedy_decode_recompute(sd: SD, scfg: SwinCfg, bcfg: BertCfg, image: Tensor,
     return ids
 
 
+class _HypsHF416:
+    """transformers 4.16 ``BeamHypotheses`` restated (tensor hypotheses, as HF keeps them)."""
+
+    def __init__(self, num_beams, length_penalty=1.0, early_stopping=False):
+        self.num_beams, self.length_penalty, self.early_stopping = num_beams, length_penalty, early_stopping
+        self.beams, self.worst_score = [], 1e9
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / (hyp.shape[-1] ** self.length_penalty)
+        if len(self.beams) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self.beams) > self.num_beams:
+                srt = sorted([(sc, i) for i, (sc, _) in enumerate(self.beams)])
+                del self.beams[srt[0][1]]
+                self.worst_score = srt[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self.beams) < self.num_beams:
+            return False
+        if self.early_stopping:
+            return True
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+
+
+def beam_decode_recompute(sd: SD, scfg: SwinCfg, bcfg: BertCfg, image: Tensor, num_beams: int, max_len: int):
+    """Oracle for ``beam_search`` (model.py:636-816) by FULL-SEQUENCE RECOMPUTE per step (no cache), with the
+    scorer bookkeeping of transformers 4.16 ``BeamSearchScorer.process/finalize`` written out inline (the class is
+    third-party and absent from the installed transformers: PARITY WITH THE REFERENCE IS UNPINNED; this pins the
+    build's cached implementation against an independent statement of the same algorithm)."""
+    feat0 = conv_layer(image, sd, scfg)
+    B, nb = image.shape[0], num_beams
+    feat = feat0.repeat_interleave(nb, dim=0)                                   # _expand_inputs_for_generation
+    pad, eos, mask = 0, bcfg.eos_token_id, bcfg.mask_token_id
+    hyps = [_HypsHF416(nb) for _ in range(B)]
+    done = [False] * B
+    beam_scores = torch.zeros(B, nb)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    gen = None                                                                   # generated ids [B*nb, cur_len]
+    input_ids = torch.full((B * nb, 1), mask)                                    # step 0: the [MASK] column (:701-702)
+    cur_len = 0
+    V = bcfg.vocab_size
+    while cur_len < max_len:
+        inp = input_ids if gen is None else torch.cat([gen, torch.full((B * nb, 1), mask)], 1)
+        o = mvlbert_forward(sd, bcfg, inp, feat, True)
+        logits = mlm_head(o["hidden"][:, -1], sd, "MLM_head_seq2seq", bcfg)
+        scores = torch.log_softmax(logits, -1) + beam_scores[:, None]
+        scores = scores.view(B, nb * V)
+        nscores, ntok = torch.topk(scores, 2 * nb, dim=1, largest=True, sorted=True)
+        nidx = torch.div(ntok, V, rounding_mode="floor")
+        ntok = ntok % V
+        # ---- BeamSearchScorer.process
+        ids_for_scorer = input_ids if gen is None else gen
+        slen = ids_for_scorer.shape[-1]
+        nbs, nbt, nbi = torch.zeros(B, nb), torch.zeros(B, nb, dtype=torch.long), torch.zeros(B, nb, dtype=torch.long)
+        for b in range(B):
+            if done[b]:
+                nbs[b] = 0; nbt[b] = pad; nbi[b] = 0
+                continue
+            k = 0
+            for rank in range(2 * nb):
+                t, sc, ix = int(ntok[b, rank]), float(nscores[b, rank]), int(nidx[b, rank])
+                row = b * nb + ix
+                if t == eos:
+                    if rank >= nb:
+                        continue
+                    hyps[b].add(ids_for_scorer[row].clone(), sc)
+                else:
+                    nbs[b, k], nbt[b, k], nbi[b, k] = sc, t, row
+                    k += 1
+                if k == nb:
+                    break
+            assert k == nb
+            done[b] = done[b] or hyps[b].is_done(float(nscores[b].max()), slen)
+        beam_scores, btok, bidx = nbs.view(-1), nbt.view(-1), nbi.view(-1)
+        gen = btok[:, None] if cur_len == 0 else torch.cat([gen[bidx], btok[:, None]], -1)
+        cur_len += 1
+        if all(done):
+            break
+    # ---- BeamSearchScorer.finalize (num_beam_hyps_to_keep = 1, max_length = the model config's)
+    for b in range(B):
+        if done[b]:
+            continue
+        for k in range(nb):
+            hyps[b].add(gen[b * nb + k], float(beam_scores[b * nb + k]))
+    best = [sorted(h.beams, key=lambda x: x[0]).pop()[1] for h in hyps]
+    lens = [len(h) for h in best]
+    width = min(max(lens) + 1, max_len)
+    out = torch.full((B, width), pad, dtype=torch.long)
+    for i, h in enumerate(best):
+        out[i, :lens[i]] = h[:width]
+        if lens[i] < max_len:
+            out[i, lens[i]] = eos
+    return out
+
+
 # --------------------------------------------------------------------------
 # deterministic formula weights shared by the golden generator and the tests
 # --------------------------------------------------------------------------

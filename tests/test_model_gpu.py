@@ -736,3 +736,31 @@ def test_retrieval_head_training_gradients_vs_torch(M, specs):
     _grad_check(model, osd, ["final_mlp.1.weight", "final_mlp.0.dense.weight", "final_mlp.0.LayerNorm.weight",
                              "MVLBert.pooler.dense.weight", "MVLBert.encoder.layer.0.intermediate.dense.weight",
                              "conv.conv.0.layers.2.blocks.0.attn.proj.weight"])
+
+
+@pytest.mark.parametrize("num_beams,B", [(3, 2), (2, 3)])
+def test_beam_search_matches_full_recompute_oracle(M, specs, num_beams, B):
+    """Cached beam search (decode.beam_search: 2-token steps, cache rows gathered by beam index, host scorer) ==
+    the oracle's per-step full recompute with an independently written HF-4.16 scorer.  Parity with the reference
+    itself is unpinned (its scorer class is third-party and no longer shipped)."""
+    from oracle import mvlt_oracle as O
+    model, sd = _tiny_caption(M, specs, F32)
+    image, _, _, _ = synth_batch(B, 24, seed=80 + num_beams, vocab=3000)
+    out = model(image.cuda(), None, num_beams, 'unilm')
+    _, scfg, bcfg = _tiny_oracle_cfgs()
+    with torch.no_grad():
+        ref = O.beam_decode_recompute(sd, scfg, bcfg, image, num_beams, model.config.max_length)
+    assert out.shape == ref.shape and torch.equal(out.cpu(), ref), (out.cpu(), ref)
+    # with [END] forced early: make the most likely first token the end token for sample 0
+    greedy, _ = model(image.cuda(), None, 1, 'unilm')
+    old = model.config.eos_token_id
+    try:
+        model.config.eos_token_id = int(greedy[0, 1])
+        bcfg2 = O.BertCfg(vocab_size=3000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024,
+                          eos_token_id=int(greedy[0, 1]))
+        out2 = model(image.cuda(), None, num_beams, 'unilm')
+        with torch.no_grad():
+            ref2 = O.beam_decode_recompute(sd, scfg, bcfg2, image, num_beams, model.config.max_length)
+        assert out2.shape == ref2.shape and torch.equal(out2.cpu(), ref2), (out2.cpu(), ref2)
+    finally:
+        model.config.eos_token_id = old
