@@ -16,6 +16,13 @@ is restated here from the installed 5.15.0 source
 (``transformers/models/bert/modeling_bert.py:111-136,164-203,282-293,325-351,
 451-463,466-506``) and pinned through the same golden vectors.
 
+Exception -- ``beam_decode_recompute``: PARITY UNPINNED.  The reference delegates the beam
+bookkeeping to HF ``BeamSearchScorer`` (third-party, ``transformers>=4.16.0``, absent from the
+installed release, so the reference's beam search cannot run here); it is restated from the 4.16
+semantics and only pins the build's cached implementation against an independent statement of the
+same algorithm.  ``greedy_decode_recompute`` is pinned through the golden-pinned forward it calls
+(the reference's own cached loop does not run under the installed HF either).
+
 All functions take ``sd`` -- a dict of tensors with the *reference's* state-dict
 key names -- plus a key prefix, so the HIP modules' ``state_dict()`` can be fed
 to the oracle unchanged.
