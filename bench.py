@@ -28,7 +28,7 @@ PEAK_BF16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PER_GPU_BATCH, SEQ = 32, 80
 
 
-DOMINANT = ("group", 1, 64, 128)   # gemm_group_kernel<bf16, BM=64, BN=128, A k-major, B k-major>: the grouped weight-
+DOMINANT = ("group", 1, 64, 128)   # gemm_group_kernel<bf16, BM=128|64, BN=128, A k-major, B k-major>: the grouped weight-
                                    # gradient GEMM (all dW of one BertLayer / Swin block per launch), the symbol with
                                    # the largest share of GPU time (profiles/r1_bench_kernel_stats.csv)
 
@@ -197,14 +197,15 @@ def main():
         kr = timer.result()
         roofline = None
         if kr is not None:
-            roofline = {"bound": "mfma", "kernel": "gemm_group_kernel<bf16,64,128,kmajor,kmajor> (grouped weight-gradient GEMMs "
-                                                   "dW_i = dY_i^T X_i of one layer per launch, side stream, overlapped "
-                                                   "with the dgrad chain)",
+            roofline = {"bound": "mfma", "kernel": "gemm_group_kernel<bf16,{128|64},128,kmajor,kmajor> (grouped weight-gradient "
+                                                   "GEMMs dW_i = dY_i^T X_i of one layer per launch: 128-row tiles for "
+                                                   "the BertLayer groups, 64-row tiles for the Swin stage-2 groups; side "
+                                                   "stream, overlapped with the dgrad chain)",
                         "achieved": round(kr["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(kr["tflops"] / PEAK_BF16_TFLOPS, 4),
                         # HBM bytes per launch of this kernel from rocprofv3 PMC passes of the same step
                         # (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_dominant_kernel_traffic.md), not measured live
-                        "traffic": 2.06e8,
+                        "traffic": 1.85e8,
                         "launches": kr["launches"], "avg_launch_us": round(kr["avg_us"], 2),
                         "sampling": f"1 in {timer.every} launches of the kernel inside the timed region"}
         out = {"metric": "image-text pairs/sec pretrain step (Swin-S+BERT, 224px, seq80)", "value": round(value, 2),

@@ -672,15 +672,26 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
         bn = want;
         Plan pl{64, bn, 1};
         { const int rc = fill_dev<T>(p, pl, g.g[i]); if (rc != MVLT_OK) return rc; }
+    }
+    // 128-row tiles when they still give every CU a workgroup (half the LDS fragment traffic per MFMA)
+    int bm = 64;
+    if (bn == 128) {
+        long t128 = 0;
+        for (int i = 0; i < n; ++i) t128 += (long)ceil_div(items[i].M, 128) * ceil_div(items[i].N, 128);
+        if (t128 >= 256) bm = 128;
+        if (const char* ov = getenv("MVLT_GROUP_BM")) bm = atoi(ov) == 128 ? 128 : 64;
+    }
+    for (int i = 0; i < n; ++i) {
         g.start[i] = i == 0 ? 0 : g.start[i];
-        g.start[i + 1] = g.start[i] + ceil_div(p->M, 64) * ceil_div(p->N, bn);
+        g.start[i + 1] = g.start[i] + ceil_div(items[i].M, bm) * ceil_div(items[i].N, bn);
     }
     // at most 2 workgroups per CU (of the 3 that fit): the group runs on the side stream beside the dgrad
     // chain, which should keep a share of every CU (16.8 vs 17.1 ms/step uncapped; MVLT_GROUP_WGS=n overrides, 0 = no cap)
     int total = g.start[n], per_cu = 2;
     if (const char* ov = getenv("MVLT_GROUP_WGS")) per_cu = atoi(ov);
     if (per_cu > 0 && total > per_cu * 256) total = per_cu * 256;
-    if (bn == 128) hipLaunchKernelGGL((gemm_group_kernel<T, 64, 128, true, true>), dim3(total), dim3(256), 0, s, g);
+    if (bn == 128 && bm == 128) hipLaunchKernelGGL((gemm_group_kernel<T, 128, 128, true, true>), dim3(total), dim3(256), 0, s, g);
+    else if (bn == 128) hipLaunchKernelGGL((gemm_group_kernel<T, 64, 128, true, true>), dim3(total), dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_group_kernel<T, 64, 96, true, true>), dim3(total), dim3(256), 0, s, g);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
