@@ -327,6 +327,76 @@ def test_bert_attention(ops, dt, T, seq2seq, p):
     assert rel(dqkv, qr.grad) < tol(dt) * 3
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("seq2seq,p", [(False, 0.0), (True, 0.0), (False, 0.1)])
+def test_bert_attention_packed_rows_equal_dense(ops, dt, seq2seq, p):
+    """MvltAttn.row_start / seq_len: the kept rows of a packed launch == the same rows of the dense launch
+    (forward, backward, same dropout mask -- its index is (sequence, head, q, k) in both layouts)."""
+    from mvlt_amd._lib import ATTN_BIDIR, ATTN_SEQ2SEQ
+    B, nH, n_img, T = 4, 4, 49, 40
+    Lq = n_img + 2 + T
+    lens_t = [40, 13, 1, 27]
+    ids = torch.zeros(B, T, dtype=torch.long)
+    for b, ln in enumerate(lens_t):
+        ids[b, :ln] = 5 + torch.arange(ln)
+    seq_len = torch.tensor([n_img + 2 + ln for ln in lens_t], dtype=torch.int32)
+    row_start = (torch.cumsum(seq_len, 0) - seq_len).to(torch.int32)
+    R = int(seq_len.sum())
+    dense_rows = torch.cat([b * Lq + torch.arange(int(seq_len[b])) for b in range(B)]).cuda()
+    qkv = rnd((B * Lq, 3 * nH * 64), dt, 70)
+    dout = rnd((B * Lq, nH * 64), dt, 71)
+    mode = ATTN_SEQ2SEQ if seq2seq else ATTN_BIDIR
+    kw = dict(text_ids=ids.cuda(), obj_end=n_img + 1, dropout=(p, 99, 5))
+    out_d, lse_d = ops.attn_fwd(qkv, mode, B, Lq, nH, 64, 0.125, **kw)
+    # the dense backward with zero upstream gradient on the dropped rows == what the loss gives them
+    dout_d = torch.zeros_like(dout)
+    dout_d[dense_rows] = dout[dense_rows]
+    dqkv_d = ops.attn_bwd(dout_d, qkv, out_d, lse_d, mode, B, Lq, nH, 64, 0.125, **kw)
+    pack = (row_start.cuda(), seq_len.cuda(), R)
+    qkv_p, dout_p = qkv[dense_rows].contiguous(), dout[dense_rows].contiguous()
+    out_p, lse_p = ops.attn_fwd(qkv_p, mode, B, Lq, nH, 64, 0.125, pack=pack, **kw)
+    assert out_p.shape == (R, nH * 64)
+    assert rel(out_p, out_d[dense_rows]) < 1e-6 if dt == torch.float32 else rel(out_p, out_d[dense_rows]) < 1e-3
+    dqkv_p = ops.attn_bwd(dout_p, qkv_p, out_p, lse_p, mode, B, Lq, nH, 64, 0.125, pack=pack, **kw)
+    assert rel(dqkv_p, dqkv_d[dense_rows]) < (1e-5 if dt == torch.float32 else 5e-3)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_embed_packed_rows_and_zero_batch(ops, dt):
+    B, n_img, T, H = 3, 49, 24, 256
+    g = torch.Generator().manual_seed(80)
+    word, pos, typ = (torch.randn(n, H, generator=g).cuda() for n in (3001, 512, 3))
+    feat = rnd((B, n_img, H), dt, 81)
+    lens_t = [24, 7, 1]
+    ids = torch.zeros(B, T, dtype=torch.long)
+    for b, ln in enumerate(lens_t):
+        ids[b, :ln] = torch.randint(5, 3000, (ln,), generator=g)
+    ids = ids.cuda()
+    seq_len = torch.tensor([n_img + 2 + ln for ln in lens_t], dtype=torch.int32)
+    row_start = (torch.cumsum(seq_len, 0) - seq_len).to(torch.int32)
+    R = int(seq_len.sum())
+    Lq = n_img + 2 + T
+    rows = torch.cat([b * Lq + torch.arange(int(seq_len[b])) for b in range(B)]).cuda()
+    pack = (row_start.cuda(), seq_len.cuda(), R)
+    dense = ops.embed_fwd(ids, feat, word, pos, typ, 101, 102).view(B * Lq, H)
+    packed = ops.embed_fwd(ids, feat, word, pos, typ, 101, 102, pack=pack)
+    assert packed.shape == (R, H) and torch.equal(packed, dense[rows])
+    dout = rnd((B * Lq, H), dt, 82)
+    dout_zeroed = torch.zeros_like(dout)
+    dout_zeroed[rows] = dout[rows]
+    gd = [torch.zeros_like(t) for t in (word, pos, typ)]
+    gp = [torch.zeros_like(t) for t in (word, pos, typ)]
+    dimg_d = ops.embed_bwd(dout_zeroed.view(B, Lq, H), ids, n_img, word, pos, typ, 101, 102, *gd)
+    dimg_p = ops.embed_bwd(dout[rows].contiguous(), ids, n_img, word, pos, typ, 101, 102, *gp, pack=pack, B=B)
+    assert torch.equal(dimg_p, dimg_d)
+    for a, b in zip(gp, gd):
+        # the dense run also adds the (zero) gradients of the padded positions to word id 0: same sums
+        assert rel(a, b) < 1e-5
+    bufs = [torch.randn(n, device="cuda") for n in (169 * 3, 169 * 24, 5, 4096)]
+    ops.zero_batch(bufs)
+    assert all(float(t.abs().max()) == 0.0 for t in bufs)
+
+
 # ------------------------------------------------------------------ data movement, loss, optimizer
 @pytest.mark.parametrize("dt", DT)
 def test_im2col_and_embed(ops, dt):
