@@ -360,6 +360,16 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Ge
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the finishing waves fetch their bias / residual values now, so the epilogue does not start with a
+    // dependent memory round trip (the decode step is a chain of ~100 such kernels)
+    constexpr int FASTMASK = MVLT_EPI_BIAS | MVLT_EPI_GELU | MVLT_EPI_RESIDUAL;
+    const bool fast_epi = !ARGMAX && (p.epi & ~FASTMASK) == 0 && p.epi_vec && n0 + 16 <= p.N && wave < 4 && 16 * wave + r15 < p.M;
+    f32x4 pre_bias{0.f, 0.f, 0.f, 0.f}, pre_res{0.f, 0.f, 0.f, 0.f};
+    if (fast_epi) {
+        if (p.epi & MVLT_EPI_BIAS) pre_bias = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4 * g);
+        if (p.epi & MVLT_EPI_RESIDUAL)
+            pre_res = load4f(reinterpret_cast<const T*>(p.residual) + (long)(16 * wave + r15) * p.ldr + n0 + 4 * g);
+    }
     const int nkb = p.K / KB;
     for (int kb0 = wave; kb0 < nkb; kb0 += SKINNY_WAVES * SKINNY_UNROLL) {
         Frag fb[SKINNY_UNROLL], fa[SKINNY_UNROLL][4];
@@ -389,7 +399,17 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Ge
         for (int w = 1; w < SKINNY_WAVES; ++w) v += red[w][i][lane];
         // acc[r] <-> n = n0 + 4*g + r, m = 16*i + (lane & 15)   (same orientation as gemm_body)
         if (!ARGMAX) {
-            epilogue4<T>(p, 16 * i + r15, n0 + 4 * g, v);
+            if (fast_epi) {
+                f32x4 o = v + pre_bias;
+                if (p.epi & MVLT_EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = gelu_f(o[r]);
+                }
+                o += pre_res;
+                store4f(reinterpret_cast<T*>(p.C) + (long)(16 * i + r15) * p.ldc + n0 + 4 * g, o);
+            } else {
+                epilogue4<T>(p, 16 * i + r15, n0 + 4 * g, v);
+            }
         } else {
             float best = -3.0e38f; int bi = 0x7fffffff;
 #pragma unroll

@@ -302,111 +302,112 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 
 // ------------------------------------------------------------------ decode: cached attention + argmax
 // One wave = one (b, head): all n_new query rows share every K/V load.  Lanes are (key group kg) x (16-byte
-// feature chunk fc): a wave instruction reads 64/FC consecutive cache rows of 128 B (1 KB, coalesced); the
-// partial dot products are reduced over the fc lanes by xor shuffles, scores/probabilities live in LDS, and the
-// P.V partial sums are reduced over the key groups at the end.  (The serial kernel below walked the keys one
-// at a time with a dependent 2-byte load each: 68 us per layer at past = 200, now ~6.)
-constexpr int CACHED_MAXNEW = 4, CACHED_MAXK = 512;
+// feature chunk fc): a wave instruction reads 64/FC consecutive cache rows of 128 B (1 KB, coalesced).  Keys are
+// walked in blocks of KG*8: the 8 K chunks AND the 8 V chunks of a block are all in flight together (one memory
+// round trip per block), scores are reduced over the fc lanes by xor shuffles, the softmax is the online
+// (running max / sum) form, and the P.V partial sums are reduced over the key groups once at the end.  No LDS,
+// no barrier.  (The first version walked the keys one at a time with a dependent 2-byte load each: 68 us per
+// layer at past = 200; the two-pass LDS version 21 us.)
+constexpr int CACHED_MAXNEW = 4, CACHED_MAXK = 1 << 20, CACHED_U = 8;
 template <typename T>
 __global__ __launch_bounds__(64) void attn_cached_kernel(const MvltAttnCached p) {
     constexpr int E = TypeInfo<T>::E, HD = 64, FC = HD / E, KG = 64 / FC;
     using Vec = typename TypeInfo<T>::Vec;
-    __shared__ float sq[CACHED_MAXNEW][HD];
-    __shared__ float sc[CACHED_MAXNEW][CACHED_MAXK];
-    __shared__ float sinv[CACHED_MAXNEW];
     const int lane = threadIdx.x, fc = lane % FC, kg = lane / FC;
     const int h = blockIdx.x % p.nH, b = blockIdx.x / p.nH;
     const int past = p.past_dev ? *p.past_dev : p.past;
     const int C = p.nH * HD;
-    const T* qkv = reinterpret_cast<const T*>(p.qkv_new) + (long)b * p.n_new * 3 * C + h * HD;
-    T* kc = reinterpret_cast<T*>(p.k_cache) + ((long)b * p.nH + h) * p.cache_cap * HD;
-    T* vc = reinterpret_cast<T*>(p.v_cache) + ((long)b * p.nH + h) * p.cache_cap * HD;
+    const T* qkv = reinterpret_cast<const T*>(p.qkv_new) + (long)b * p.n_new * 3 * C + h * HD + fc * E;
+    T* kc = reinterpret_cast<T*>(p.k_cache) + ((long)b * p.nH + h) * p.cache_cap * HD + fc * E;
+    T* vc = reinterpret_cast<T*>(p.v_cache) + ((long)b * p.nH + h) * p.cache_cap * HD + fc * E;
     const int nk = past + p.n_new;
-    for (int i = lane; i < p.n_new * HD; i += 64) {
-        const int r = i / HD, d = i % HD;
-        const T* src = qkv + (long)r * 3 * C + d;
-        sq[r][d] = to_f(src[0]) * p.scale;
-        kc[(long)(past + r) * HD + d] = src[C];          // append (read back below from qkv_new, not from the cache)
-        vc[(long)(past + r) * HD + d] = src[2 * C];
+    float q[CACHED_MAXNEW][E], o[CACHED_MAXNEW][E], m[CACHED_MAXNEW], l[CACHED_MAXNEW];
+#pragma unroll
+    for (int r = 0; r < CACHED_MAXNEW; ++r) {
+        m[r] = -3.0e38f; l[r] = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { q[r][e] = 0.f; o[r][e] = 0.f; }
+        if (r < p.n_new) {
+            const Vec qv = *reinterpret_cast<const Vec*>(qkv + (long)r * 3 * C);
+#pragma unroll
+            for (int e = 0; e < E; ++e) q[r][e] = to_f(qv[e]) * p.scale;
+            if (kg == 0) {       // append this row's K/V chunk (the loop below reads new rows from qkv_new, not the cache)
+                *reinterpret_cast<Vec*>(kc + (long)(past + r) * HD) = *reinterpret_cast<const Vec*>(qkv + (long)r * 3 * C + C);
+                *reinterpret_cast<Vec*>(vc + (long)(past + r) * HD) = *reinterpret_cast<const Vec*>(qkv + (long)r * 3 * C + 2 * C);
+            }
+        }
     }
-    __syncthreads();
-    // ---- scores: s[r][k] = q_r . K_k for k <= past + r (causal over the new tokens, model.py:97-104)
-#pragma unroll 8
-    for (int k0 = 0; k0 < nk; k0 += KG) {
-        const int k = k0 + kg;
-        float part[CACHED_MAXNEW];
+    for (int k0 = 0; k0 < nk; k0 += KG * CACHED_U) {
+        Vec kv[CACHED_U], vv[CACHED_U];
 #pragma unroll
-        for (int r = 0; r < CACHED_MAXNEW; ++r) part[r] = 0.f;
-        if (k < nk) {
-            const T* src = k < past ? kc + (long)k * HD + fc * E : qkv + (long)(k - past) * 3 * C + C + fc * E;
-            const Vec kv = *reinterpret_cast<const Vec*>(src);
+        for (int u = 0; u < CACHED_U; ++u) {
+            const int k = k0 + u * KG + kg;
+            const int kk = k < nk ? k : 0;                                   // out of range: a valid row, masked below
+            const T* ks = kk < past ? kc + (long)kk * HD : qkv + (long)(kk - past) * 3 * C + C;
+            const T* vs = kk < past ? vc + (long)kk * HD : qkv + (long)(kk - past) * 3 * C + 2 * C;
+            kv[u] = *reinterpret_cast<const Vec*>(ks);
+            vv[u] = *reinterpret_cast<const Vec*>(vs);
+        }
+        float s[CACHED_U][CACHED_MAXNEW];
 #pragma unroll
-            for (int r = 0; r < CACHED_MAXNEW; ++r)
-                if (r < p.n_new) {
+        for (int u = 0; u < CACHED_U; ++u) {
+            const int k = k0 + u * KG + kg;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) part[r] += sq[r][fc * E + e] * to_f(kv[e]);
-                }
+            for (int r = 0; r < CACHED_MAXNEW; ++r) {
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < E; ++e) part += q[r][e] * to_f(kv[u][e]);
+#pragma unroll
+                for (int off = 1; off < FC; off <<= 1) part += __shfl_xor(part, off, 64);
+                // causal over the new tokens (model.py:97-104): key k is visible to new row r iff k <= past + r
+                s[u][r] = (k < nk && k <= past + r) ? part : -3.0e38f;
+            }
         }
 #pragma unroll
         for (int r = 0; r < CACHED_MAXNEW; ++r) {
+            if (r >= p.n_new) break;
+            float mb = s[0][r];
 #pragma unroll
-            for (int o = 1; o < FC; o <<= 1) part[r] += __shfl_xor(part[r], o, 64);
-            if (fc == 0 && k < nk && r < p.n_new) sc[r][k] = k <= past + r ? part[r] : -3.0e38f;
-        }
-    }
-    __syncthreads();
-    // ---- softmax over the keys of each row (unnormalised probabilities stay in LDS)
-    for (int r = 0; r < p.n_new; ++r) {
-        float mx = -3.0e38f;
-        for (int k = lane; k < nk; k += 64) mx = fmaxf(mx, sc[r][k]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int k = lane; k < nk; k += 64) { const float e = __expf(sc[r][k] - mx); sc[r][k] = e; sum += e; }
-        sum = wave_sum(sum);
-        if (lane == 0) sinv[r] = 1.0f / sum;
-    }
-    __syncthreads();
-    // ---- O_r = sum_k p[r][k] V_k
-    float o[CACHED_MAXNEW][E];
+            for (int u = 1; u < CACHED_U; ++u) mb = fmaxf(mb, s[u][r]);
 #pragma unroll
-    for (int r = 0; r < CACHED_MAXNEW; ++r)
+            for (int off = FC; off < 64; off <<= 1) mb = fmaxf(mb, __shfl_xor(mb, off, 64));
+            const float mn = fmaxf(m[r], mb);
+            const float alpha = __expf(m[r] - mn);
+            m[r] = mn;
+            float ls = 0.f;
 #pragma unroll
-        for (int e = 0; e < E; ++e) o[r][e] = 0.f;
-#pragma unroll 8
-    for (int k0 = 0; k0 < nk; k0 += KG) {
-        const int k = k0 + kg;
-        if (k < nk) {
-            const T* src = k < past ? vc + (long)k * HD + fc * E : qkv + (long)(k - past) * 3 * C + 2 * C + fc * E;
-            const Vec vv = *reinterpret_cast<const Vec*>(src);
+            for (int e = 0; e < E; ++e) o[r][e] *= alpha;
 #pragma unroll
-            for (int r = 0; r < CACHED_MAXNEW; ++r)
-                if (r < p.n_new) {
-                    const float pr = sc[r][k];
+            for (int u = 0; u < CACHED_U; ++u) {
+                const float pr = __expf(s[u][r] - mn);                     // masked: exp(-3e38 - mn) = 0
+                ls += pr;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) o[r][e] += pr * to_f(vv[e]);
-                }
+                for (int e = 0; e < E; ++e) o[r][e] += pr * to_f(vv[u][e]);
+            }
+            l[r] = l[r] * alpha + ls;
         }
     }
 #pragma unroll
     for (int r = 0; r < CACHED_MAXNEW; ++r) {
         if (r >= p.n_new) break;
+        float lt = l[r];
+#pragma unroll
+        for (int off = FC; off < 64; off <<= 1) lt += __shfl_xor(lt, off, 64);
+        const float inv = 1.0f / lt;
+        Vec ov;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             float v = o[r][e];
 #pragma unroll
             for (int off = FC; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            o[r][e] = v * sinv[r];
+            ov[e] = from_f<T>(v * inv);
         }
-        if (kg == 0) {
-            Vec ov;
-#pragma unroll
-            for (int e = 0; e < E; ++e) ov[e] = from_f<T>(o[r][e]);
+        if (kg == 0)
             *reinterpret_cast<Vec*>(reinterpret_cast<T*>(p.out) + ((long)b * p.n_new + r) * C + h * HD + fc * E) = ov;
-        }
     }
 }
 
-// fallback (head_dim < 64, more than 4 new rows or more than 512 keys): one wave per (b, head, new row), keys serial
+// fallback (head_dim < 64 or more than 4 new rows): one wave per (b, head, new row), keys serial
 template <typename T>
 __global__ __launch_bounds__(64) void attn_cached_serial_kernel(const MvltAttnCached p) {
     // one wave = one (b, head, new row); hd = 64 -> lane owns one feature; keys streamed from the cache
@@ -712,7 +713,7 @@ extern "C" int mvlt_attn_cached(const MvltAttnCached* p, void* stream) {
     MVLT_CHECK(p->hd > 0 && p->hd <= 64 && p->B > 0 && p->nH > 0 && p->n_new > 0, MVLT_ERR_ARG);
     // with a device-side `past` the host cannot check the bound: the caller guarantees *past_dev + n_new <= cache_cap
     MVLT_CHECK(p->past_dev || p->past + p->n_new <= p->cache_cap, MVLT_ERR_ARG);
-    const bool fast = p->hd == 64 && p->n_new <= CACHED_MAXNEW && p->cache_cap <= CACHED_MAXK &&
+    const bool fast = p->hd == 64 && p->n_new <= CACHED_MAXNEW &&
                       aligned16(p->qkv_new) && aligned16(p->k_cache) && aligned16(p->v_cache) && aligned16(p->out);
     if (fast) {
         dim3 grid(p->B * p->nH);
