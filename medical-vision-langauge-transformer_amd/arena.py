@@ -16,12 +16,14 @@ MFMA kernels read.  Consequences:
 """
 from __future__ import annotations
 
+import operator
 from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
 
 ALIGN = 64  # elements (256 B for f32, 128 B for the bf16 copy)
+_VERSION = operator.attrgetter("_version")
 
 
 class Arena:
@@ -82,6 +84,14 @@ class Arena:
         self._ptr0 = self.params[0].data_ptr()
         self.shadow_fresh = False
         self._flat_version = -1
+        # In-place writes through the Parameters (load_state_dict, a stock torch optimizer) bump THEIR version
+        # counters, not ``flat``'s (``p.data = view`` does not share the counter), so staleness of the bf16 copy
+        # is detected by the sum of the parameter versions -- scanned once per pass (after every backward, after
+        # every load_state_dict; mark_parameters_changed() for anything else).
+        self._param_versions = -1
+        self._scan_ok = False
+        for m in root.modules():
+            m.register_load_state_dict_post_hook(lambda mod, keys, a=self: a.mark_parameters_changed())
         self._views: Dict[tuple, torch.Tensor] = {}
         self.has_grad = _EpochFlags(self.params)       # has_grad[id(p)] -> bool, reset in O(1) per backward pass
         self._marked: List[nn.Parameter] = []
@@ -166,6 +176,7 @@ class Arena:
 
     # ------------------------------------------------------------------ per-step state
     def begin_backward(self) -> None:
+        self._scan_ok = False          # an optimizer step usually follows: look at the parameter versions again
         self.has_grad.clear()
         self._marked = []
         self._watermark = self.total
@@ -180,7 +191,11 @@ class Arena:
         Only parameters whose status changed since the previous step are touched."""
         cur = frozenset(id(p) for p in self._marked)
         if cur == self._published:
-            return
+            # unchanged set: nothing to do -- unless somebody dropped the views (optimizer.zero_grad() sets
+            # p.grad = None every step in the reference loop): then all of them are handed out again
+            if not self._marked or (self._marked[0].grad is not None and self._marked[-1].grad is not None):
+                return
+            self._published = None
         prev = self._published or frozenset()
         byid = self.__dict__.get("_byid")
         if byid is None:
@@ -194,12 +209,24 @@ class Arena:
                 p.grad = None
         self._published = cur
 
+    def mark_parameters_changed(self) -> None:
+        """Call after writing parameter values by any route the arena cannot see."""
+        self._scan_ok = False
+
     def refresh_shadow(self) -> None:
-        """bf16 compute copy <- f32 master (one pass, 6 B/param) whenever the
-        master was modified through torch (load_state_dict, a torch optimizer:
-        in-place ops on the views bump ``flat._version``).  The fused AdamW
-        kernel refreshes the copy itself and leaves the version untouched."""
-        if self.shadow is not None and (not self.shadow_fresh or self.flat._version != self._flat_version):
+        """bf16 compute copy <- f32 master (one pass, 6 B/param) whenever the master was modified through
+        torch: in-place ops on ``flat`` itself bump ``flat._version``; writes through the Parameters
+        (load_state_dict, a stock torch optimizer) are seen through the parameter version scan.  The fused
+        AdamW kernel refreshes the copy itself and leaves all versions untouched."""
+        if self.shadow is None:
+            return
+        if not self._scan_ok:
+            pv = sum(map(_VERSION, self.params))
+            if pv != self._param_versions:
+                self._param_versions = pv
+                self.shadow_fresh = False
+            self._scan_ok = True
+        if not self.shadow_fresh or self.flat._version != self._flat_version:
             from . import ops
             ops.cast(self.flat, torch.bfloat16, out=self.shadow)
             self.shadow_fresh = True
