@@ -26,7 +26,27 @@ ALIGN = 64  # elements (256 B for f32, 128 B for the bf16 copy)
 _VERSION = operator.attrgetter("_version")
 
 
+def _nothing():
+    return None
+
+
+class _MarkChanged:
+    """load_state_dict post-hook (a picklable callable: whole-module torch.save must keep working)."""
+
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __call__(self, module, incompatible_keys):
+        if self.arena is not None:
+            self.arena.mark_parameters_changed()
+
+
 class Arena:
+    def __reduce__(self):
+        # whole-module pickling (torch.save(model)): the arena is derived state keyed by object identity; it
+        # unpickles as None and is rebuilt from the parameters on first use (Arena.of)
+        return (_nothing, ())
+
     def __init__(self, root: nn.Module, compute_dtype: torch.dtype, allow_cpu: bool = False):
         # allow_cpu: host-logic tests only (bucketing / DDP over gloo); no kernel ever runs on CPU tensors
         params: List[Tuple[str, nn.Parameter]] = []
@@ -90,8 +110,9 @@ class Arena:
         # every load_state_dict; mark_parameters_changed() for anything else).
         self._param_versions = -1
         self._scan_ok = False
+        hook = _MarkChanged(self)
         for m in root.modules():
-            m.register_load_state_dict_post_hook(lambda mod, keys, a=self: a.mark_parameters_changed())
+            m.register_load_state_dict_post_hook(hook)
         self._views: Dict[tuple, torch.Tensor] = {}
         self.has_grad = _EpochFlags(self.params)       # has_grad[id(p)] -> bool, reset in O(1) per backward pass
         self._marked: List[nn.Parameter] = []

@@ -95,6 +95,10 @@ def cached_forward(mv, text_idx, image_feature, past_key_values, seq2seq_mask):
     return EncoderOutput(h, tuple((kc[i], vc[i]) for i in range(nl))), None
 
 
+def _no_graph():
+    return None
+
+
 class _GreedyGraph:
     """The whole per-token work of greedy decoding -- last-row MLM head + argmax + [END]/PAD bookkeeping + the
     2-token cached forward -- captured ONCE as a HIP graph and replayed per token.  Everything a replay needs
@@ -102,6 +106,9 @@ class _GreedyGraph:
     through ``pos_offset_dev`` / ``past_dev``), the output column index, the ids fed to the next step, the
     unfinished flags, and the [B, max_length] output matrices.  The host only replays and, every 8 tokens, reads
     the all-finished flags back."""
+
+    def __reduce__(self):                 # captured graphs do not survive pickling: rebuilt on the next call
+        return (_no_graph, ())
 
     def __init__(self, model, B, n_img, max_length, cd, pad, eos, mask_id, key):
         mv, cfg = model.MVLBert, model.config

@@ -821,3 +821,40 @@ def test_stock_torch_adamw_equals_fused_adamw_in_bf16(M, specs, monkeypatch):
     # ill-conditioned formula weights that already moves the third loss by 2 %, so only the first update is compared
     assert la[0] == pytest.approx(lb[0], rel=1e-6) and abs(la[1] - lb[1]) < 1e-2 * abs(la[1]), (la, lb)
     assert la[1] < la[0] - 0.1 and len(set(la)) == len(la)         # every step moved the weights the kernels read
+
+
+class _PicklableTok:
+    mask_token_id, sep_token_id = 103, 102
+
+
+def test_whole_module_torch_save_and_load(M, specs, monkeypatch, tmp_path):
+    """The reference scripts also checkpoint with torch.save(model) / torch.load (whole-module pickling):
+    the derived state (arena, captured decode graph, hooks) must not get in the way and is rebuilt after loading."""
+    from mvlt_amd.train import PretrainStep
+    monkeypatch.setattr(random, "random", lambda: 0.9)
+    cfg = tiny_cfg(M, ITM_task=True)
+    cfg.ITM_task = True
+    model = M.MVLBertForPretraining(cfg)
+    load_formula(model, specs["tiny_pretrain"])
+    model = M.set_compute_dtype(model.cuda().eval(), BF16)
+    image, ids, labels, itm = (t.cuda() for t in synth_batch(3, 24, seed=41, vocab=3000))
+    step = PretrainStep(model, lr=1e-4)
+    step((image, ids, labels, itm))                      # arena, hooks, gradient views all exist now
+    with torch.no_grad():
+        want = model(image, ids, labels, itm).item()
+    f = str(tmp_path / "whole.pt")
+    torch.save(model, f)
+    again = torch.load(f, weights_only=False)
+    with torch.no_grad():
+        got = again(image, ids, labels, itm).item()
+    assert abs(got - want) < 1e-6 * abs(want), (got, want)
+    PretrainStep(again, lr=1e-4)((image, ids, labels, itm))     # and it trains on
+    cap, _ = _tiny_caption(M, specs, F32)
+    cap.tokenizer = _PicklableTok()
+    img2, _, _, _ = synth_batch(2, 24, seed=78, vocab=3000)
+    ids1, _ = cap(img2.cuda(), None, 1, 'unilm')          # captures the decode graph
+    f2 = str(tmp_path / "cap.pt")
+    torch.save(cap, f2)
+    cap2 = torch.load(f2, weights_only=False)
+    ids2, _ = cap2(img2.cuda(), None, 1, 'unilm')
+    assert torch.equal(ids1, ids2)
