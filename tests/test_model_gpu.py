@@ -858,3 +858,37 @@ def test_whole_module_torch_save_and_load(M, specs, monkeypatch, tmp_path):
     cap2 = torch.load(f2, weights_only=False)
     ids2, _ = cap2(img2.cuda(), None, 1, 'unilm')
     assert torch.equal(ids1, ids2)
+
+
+@pytest.mark.parametrize("cd", [F32, BF16])
+def test_mvlbert_optional_inputs_vs_oracle(M, specs, cd):
+    """MVLBert.forward corner inputs the reference allows (model.py:114,:125-128,:137-147): no text at all,
+    an image mask with masked-out regions, an explicit text_mask that differs from (ids > 0)."""
+    from oracle import mvlt_oracle as O
+    _, scfg, bcfg = _tiny_oracle_cfgs()
+    model = M.MVLBertForPretraining(tiny_cfg(M))
+    sd = load_formula(model, specs["tiny_pretrain"])
+    model = M.set_compute_dtype(model.cuda().eval(), cd)
+    mv = model.MVLBert
+    g = torch.Generator().manual_seed(9)
+    feat = torch.randn(3, 49, 256, generator=g)
+    _, ids, _, _ = synth_batch(3, 24, seed=90, vocab=3000)
+    imask = torch.ones(3, 49, dtype=torch.bool)
+    imask[0, 40:] = False
+    imask[2, ::3] = False
+    with torch.no_grad():
+        out, pooled = mv(None, None, feat.cuda(), None)                                   # image tokens only
+        ref = O.mvlbert_forward(sd, bcfg, None, feat, False)
+        assert out[0].shape == (3, 51, 256) and rel_err(out[0].float().cpu(), ref["hidden"]) < ACT[cd]
+        out, pooled = mv(ids.cuda(), (ids > 0).cuda(), feat.cuda(), imask.cuda())        # masked image regions
+        ref = O.mvlbert_forward(sd, bcfg, ids, feat, False, image_mask=imask)
+        keep = torch.cat([torch.ones(3, 1, dtype=torch.bool), imask, torch.ones(3, 1, dtype=torch.bool), ids > 0], 1)
+        assert rel_err(out[0].float().cpu()[keep], ref["hidden"][keep]) < ACT[cd]
+        assert rel_err(pooled.float().cpu(), ref["pooled"]) < ACT[cd]
+        tmask = (ids > 0) & (torch.arange(24)[None, :] % 5 != 2)                          # a text_mask with holes
+        out, _ = mv(ids.cuda(), tmask.cuda(), feat.cuda(), None)
+        ref = O.mvlbert_forward(sd, bcfg, torch.where(tmask, ids, torch.zeros_like(ids)), feat, False)
+        # same keys are masked; the embeddings of the masked-out *query* positions differ (ids vs 0), so compare
+        # the rows whose own embedding is unchanged and that see identical key sets
+        rows = torch.cat([torch.ones(3, 51, dtype=torch.bool), tmask], 1)
+        assert rel_err(out[0].float().cpu()[rows], ref["hidden"][rows]) < ACT[cd] * 3
