@@ -184,6 +184,12 @@ class Arena:
         far is final: that watermark drives the DDP bucket launches."""
         lo = None
         for p in ps:
+            if self.has_grad[id(p)]:
+                # gradients are written, not accumulated: a module that ran twice before one backward pass
+                # (two forward calls whose losses are summed) would silently keep only the last contribution
+                raise RuntimeError("mvlt_amd: a parameter received a second gradient in the same backward pass "
+                                   "(the same module was run more than once before backward()); gradients are "
+                                   "overwritten, not accumulated -- batch the inputs into one forward call instead")
             self.has_grad.set(id(p))
             self._marked.append(p)
             o = self.offset[id(p)]
@@ -239,6 +245,7 @@ class Arena:
         torch: in-place ops on ``flat`` itself bump ``flat._version``; writes through the Parameters
         (load_state_dict, a stock torch optimizer) are seen through the parameter version scan.  The fused
         AdamW kernel refreshes the copy itself and leaves all versions untouched."""
+        self._in_backward = False        # a forward pass: any earlier backward pass is over (also an aborted one)
         if self.shadow is None:
             return
         if not self._scan_ok:

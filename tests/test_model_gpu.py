@@ -892,3 +892,20 @@ def test_mvlbert_optional_inputs_vs_oracle(M, specs, cd):
         # the rows whose own embedding is unchanged and that see identical key sets
         rows = torch.cat([torch.ones(3, 51, dtype=torch.bool), tmask], 1)
         assert rel_err(out[0].float().cpu()[rows], ref["hidden"][rows]) < ACT[cd] * 3
+
+
+def test_two_forward_passes_before_one_backward_fail_loudly(M, specs, monkeypatch):
+    """Gradients are overwritten per backward pass; summing the losses of two forward calls would silently drop
+    one contribution, so the second write of a parameter's gradient in one pass raises."""
+    monkeypatch.setattr(random, "random", lambda: 0.9)
+    model = M.MVLBertForPretraining(tiny_cfg(M, ITM_task=True))
+    load_formula(model, specs["tiny_pretrain"])
+    model = M.set_compute_dtype(model.cuda().eval(), F32)
+    image, ids, labels, itm = (t.cuda() for t in synth_batch(3, 24, seed=41, vocab=3000))
+    l1 = model(image, ids, labels, itm)
+    l2 = model(image.flip(0), ids, labels, itm)
+    with pytest.raises(RuntimeError, match="second gradient"):
+        (l1 + l2).backward()
+    # the next ordinary step is unaffected
+    model(image, ids, labels, itm).backward()
+    assert model.ITM_mlp.weight.grad is not None
