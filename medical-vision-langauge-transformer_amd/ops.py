@@ -12,6 +12,7 @@ from . import _lib as L
 
 _DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
 _ws = {}
+_ws_need = {}     # (dtype, M, N, K, a_kmajor, b_kmajor, split_k) -> split-K workspace bytes
 GEMM_TIMER = None   # bench.py: callable(flops, key) -> (start_event, end_event) or None; .layout = (a_kmajor, b_kmajor) it watches
 
 
@@ -145,55 +146,67 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
          save_pre=None, dropout=None, rowscale=None, residual=None, rowmap=None, mul_gelu_grad=None,
          accumulate=False, split_k=0, ldc=None, a_colsum=None):
     """C = epilogue(A @ B); see MvltGemm.  A: [M,K] (or [K,M] if a_kmajor);
-    B: [N,K] torch-Linear layout (or [K,N] if b_kmajor)."""
-    _need_cuda(A, B)
-    assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
-    assert A.stride(1) == 1 and B.stride(1) == 1
-    K, M = (A.shape if a_kmajor else A.shape[::-1])
-    if b_kmajor:
-        Kb, N = B.shape
+    B: [N,K] torch-Linear layout (or [K,N] if b_kmajor).
+    (Written for a short host path: ~330 calls per training step; pointers go into the struct as plain ints.)"""
+    if not (A.is_cuda and B.is_cuda):
+        raise RuntimeError("mvlt_amd ops run on the GPU only (no CPU fallback)")
+    dtA = A.dtype
+    sa, sb = A.shape, B.shape
+    assert len(sa) == 2 and len(sb) == 2 and dtA == B.dtype and A.stride(1) == 1 and B.stride(1) == 1
+    if a_kmajor:
+        K, M = sa
     else:
-        N, Kb = B.shape
+        M, K = sa
+    if b_kmajor:
+        Kb, N = sb
+    else:
+        N, Kb = sb
     assert K == Kb, f"inner dims differ: {K} vs {Kb}"
-    odt = torch.float32 if out_f32 else A.dtype
+    odt = torch.float32 if out_f32 else dtA
     if out is None:
         rows = M if rowmap is None else int(rowmap.numel())
         out = torch.empty((rows, N if ldc is None else ldc), dtype=odt, device=A.device)
     assert out.dtype == odt and out.stride(-1) == 1
     p = L.MvltGemm()
-    p.dtype, p.M, p.N, p.K = _dt(A), M, N, K
-    p.A, p.lda, p.a_kmajor = _p(A), _ld(A), int(a_kmajor)
-    p.B, p.ldb, p.b_kmajor = _p(B), _ld(B), int(b_kmajor)
-    p.C, p.ldc = _p(out), _ld(out) if out.dim() == 2 else N
+    p.dtype = dti = _DT[dtA]
+    p.M, p.N, p.K = M, N, K
+    p.A, p.lda = A.data_ptr(), (A.stride(0) if sa[0] != 1 else sa[1])
+    p.B, p.ldb = B.data_ptr(), (B.stride(0) if sb[0] != 1 else sb[1])
+    if a_kmajor:
+        p.a_kmajor = 1
+    if b_kmajor:
+        p.b_kmajor = 1
+    p.C = out.data_ptr()
+    p.ldc = pldc = (_ld(out) if out.dim() == 2 else N)
     epi = 0
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N
         epi |= L.EPI_BIAS
-        p.bias = _p(bias)
+        p.bias = bias.data_ptr()
     if gelu:
         epi |= L.EPI_GELU
         if save_pre is not None:
-            assert save_pre.dtype == A.dtype and _ld(save_pre) == p.ldc
+            assert save_pre.dtype == dtA and _ld(save_pre) == pldc
             epi |= L.EPI_SAVE_PRE
-            p.pre = _p(save_pre)
+            p.pre = save_pre.data_ptr()
     if dropout is not None and dropout[0] > 0.0:
         epi |= L.EPI_DROPOUT
         p.dropout_p, p.seed, p.tag = float(dropout[0]), int(dropout[1]), int(dropout[2])
     if rowscale is not None:
         epi |= L.EPI_ROWSCALE
-        p.rowscale, p.rows_per_scale = _p(rowscale[0]), int(rowscale[1])
+        p.rowscale, p.rows_per_scale = rowscale[0].data_ptr(), int(rowscale[1])
     if residual is not None:
-        assert residual.dtype == A.dtype and residual.stride(-1) == 1
+        assert residual.dtype == dtA and residual.stride(-1) == 1
         epi |= L.EPI_RESIDUAL
-        p.residual, p.ldr = _p(residual), _ld(residual)
+        p.residual, p.ldr = residual.data_ptr(), _ld(residual)
     if rowmap is not None:
         assert rowmap.dtype == torch.int32
         epi |= L.EPI_ROWMAP
-        p.rowmap = _p(rowmap)
+        p.rowmap = rowmap.data_ptr()
     if mul_gelu_grad is not None:
-        assert mul_gelu_grad.dtype == A.dtype and _ld(mul_gelu_grad) == p.ldc
+        assert mul_gelu_grad.dtype == dtA and _ld(mul_gelu_grad) == pldc
         epi |= L.EPI_MUL_GELU_GRAD
-        p.aux = _p(mul_gelu_grad)
+        p.aux = mul_gelu_grad.data_ptr()
     if out_f32:
         epi |= L.EPI_OUT_F32
     if accumulate:
@@ -202,12 +215,15 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
     p.split_k = split_k
     if a_colsum is not None:
         assert a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M
-        p.a_colsum = _p(a_colsum)
+        p.a_colsum = a_colsum.data_ptr()
     lib = L.lib()
-    need = lib.mvlt_gemm_workspace_bytes(C.byref(p))
+    wkey = (dti, M, N, K, a_kmajor, b_kmajor, split_k)
+    need = _ws_need.get(wkey)
+    if need is None:
+        need = _ws_need[wkey] = lib.mvlt_gemm_workspace_bytes(C.byref(p))       # pure function of the key
     if need:
         ws = workspace("gemm", need, A.device)
-        p.workspace, p.workspace_bytes = _p(ws), ws.numel()
+        p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
     if GEMM_TIMER is not None and GEMM_TIMER.layout == (int(a_kmajor), int(b_kmajor)):
         # bench.py: bracket the launch with HIP events on the stream it is launched on
         bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
@@ -324,13 +340,13 @@ def layernorm_fwd(x, gamma, beta, eps, *, rows=None, C_=None, out=None, out_rowm
         oshape = (x.shape[0], (H // 2) * (W // 2), Cn)
     y = out if out is not None else torch.empty(oshape, dtype=x.dtype, device=x.device)
     p = L.MvltLayerNorm()
-    p.dtype, p.rows, p.C, p.eps = _dt(x), nrows, Cn, float(eps)
-    p.x, p.gamma, p.beta, p.y = _p(x), _p(gamma), _p(beta), _p(y)
+    p.dtype, p.rows, p.C, p.eps = _DT[x.dtype], nrows, Cn, eps
+    p.x, p.gamma, p.beta, p.y = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr()
     mean = rstd = ypre = None
     if save_stats:
-        stats = torch.empty((2, nrows), dtype=torch.float32, device=x.device)
-        mean, rstd = stats[0], stats[1]
-        p.mean, p.rstd = _p(mean), _p(rstd)
+        mean, rstd = torch.empty((2, nrows), dtype=torch.float32, device=x.device).unbind(0)
+        p.mean = pm = mean.data_ptr()
+        p.rstd = pm + 4 * nrows
     if gelu:
         p.gelu = 1
         if save_pre:
