@@ -28,6 +28,8 @@ PEAK_BF16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PER_GPU_BATCH, SEQ = 32, 80
 
 
+DOMINANT_NAME = ("gemm_group_kernel<bf16,{128|64},128,kmajor,kmajor> (grouped weight-gradient GEMMs dW_i = dY_i^T X_i "
+                 "of one layer per launch; side stream, overlapped with the dgrad chain)")
 DOMINANT = ("group", 1, 64, 128)   # gemm_group_kernel<bf16, BM=128|64, BN=128, A k-major, B k-major>: the grouped weight-
                                    # gradient GEMM (all dW of one BertLayer / Swin block per launch), the symbol with
                                    # the largest share of GPU time (profiles/r1_bench_kernel_stats.csv)
@@ -71,13 +73,13 @@ def _cpu_threads():
 
 def cpu_baseline_worker():
     """Child process: the CPU oracle (plain fp32 PyTorch restatement of the reference, train mode
-    with the reference dropouts) timed on this host's cores: fwd + bwd + AdamW."""
+    with the reference dropouts) timed on this host's cores: fwd + bwd + AdamW, B=8."""
     from oracle import mvlt_oracle as O
     from mvlt_amd.train import synthetic_batch
     import mvlt_amd as M
     threads = _cpu_threads()
     torch.set_num_threads(threads)
-    B = 2
+    B = int(os.environ.get("MVLT_CPU_BASELINE_B", "8"))
     model = M.MVLBertForPretraining(M.MVLBertPretrainConfig())        # parameter container only (CPU); math = oracle
     sd = {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point else v)
           for k, v in model.state_dict().items()}
@@ -95,7 +97,7 @@ def cpu_baseline_worker():
         opt.step()
         opt.zero_grad(set_to_none=True)
         times.append(time.time() - t)
-        if time.time() - t_start > 30.0:
+        if time.time() - t_start > 45.0:
             break
     timed = times[1:] if len(times) > 1 else times          # first step = warm-up when there is more than one
     print(json.dumps(dict(value=round(B * len(timed) / sum(timed), 3), unit="pairs/s", cores=threads, kind="port",
@@ -103,7 +105,7 @@ def cpu_baseline_worker():
                                  f"(oracle/mvlt_oracle.py, {len(times) - len(timed)} warm-up)")), flush=True)
 
 
-def cpu_baseline(timeout_s=150):
+def cpu_baseline(timeout_s=170):
     """Runs the worker as a CHILD process with a hard timeout so the benchmark always finishes."""
     import subprocess
     try:
@@ -117,6 +119,74 @@ def cpu_baseline(timeout_s=150):
         return dict(value=None, unit="pairs/s", cores=_cpu_threads(), kind="port", sample=f"timed out after {timeout_s}s")
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as CHILD processes (torch.distributed.run)
+    before this process has touched the GPU, relay rank 0's JSON line and exit with the children's code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith('{"metric"')), None)
+    if line is None:
+        sys.stderr.write(r.stdout[-4000:] + "\n" + r.stderr[-4000:] + "\n")
+        raise SystemExit(r.returncode or 1)
+    print(line, flush=True)
+    raise SystemExit(r.returncode)
+
+
+def packed_gflop_per_pair(batch):
+    """FLOPs actually executed per pair by the packed-rows / labelled-rows variant (SURVEY 8d formulas with the
+    BERT rows sum(51 + len_b) instead of B*131 and the MLM head on 10 rows per sample instead of 80)."""
+    lens = batch[4].float() + 51.0
+    B = lens.numel()
+    L = 51 + SEQ
+    bert_dense = 12 * (L * (4 * 768 ** 2 + 2 * 768 * 3072) + 2 * L * L * 768)
+    bert_packed = float(sum(12 * (l * (4 * 768 ** 2 + 2 * 768 * 3072) + 2 * l * l * 768) for l in lens.tolist())) / B
+    head_all = SEQ * (768 ** 2 + 768 * 30522)
+    head_lab = 10 * (768 ** 2 + 768 * 30522)
+    fwd_ref = GFLOP_PER_PAIR / 3 / 2 * 1e9           # MACs of the reference-equivalent forward
+    fwd = fwd_ref - bert_dense + bert_packed - head_all + head_lab
+    return fwd * 2 * 3 / 1e9
+
+
+def timed_run(step, batch, steps, use_dist, dist):
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(batch)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, loss
+
+
+def profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (cannot be collected
+    inside this process): profiles/r2_dominant_kernel_traffic.json, written by scripts/pmc_traffic.py."""
+    f = os.path.join(ROOT, "profiles", "r2_dominant_kernel_traffic.json")
+    try:
+        with open(f) as fh:
+            d = json.load(fh)
+        return d.get("traffic_bytes_per_launch"), "profiles/r2_dominant_kernel_traffic.json"
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,9 +194,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
-    ap.add_argument("--mlm-all-rows", action="store_true")
-    ap.add_argument("--dense-rows", action="store_true",
-                    help="materialise the zero-padded caption tails like the reference (default: packed rows)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the packed-rows / labelled-rows extra measurement")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         cpu_baseline_worker()
@@ -135,7 +203,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        self_launch(args)                           # never returns; this process has not touched the GPU
     import torch.distributed as dist
     torch.cuda.set_device(local)
     use_dist = world > 1 or os.environ.get("MVLT_FORCE_DDP") == "1"     # FORCE: exercise RCCL + reducer on 1 rank
@@ -152,10 +220,10 @@ def main():
     torch.manual_seed(1234)                         # same random-init replica on every rank
     cfg = M.MVLBertPretrainConfig()
     cfg.ITM_task = True                             # BASELINE config: Pretrain (MLM+ITM)
-    # the reference dataset masks at most 10 tokens per caption (run_pretrain_rgc_roco_medicat.py:188):
-    # the MLM head is evaluated on those rows only (loss and gradients identical to the all-rows head;
-    # --mlm-all-rows runs the reference-shaped head).  FLOP accounting stays reference-equivalent.
-    cfg.mlm_max_labels_per_sample = None if args.mlm_all_rows else 10
+    # PRIMARY number = the reference's own call: model(image, caption_masked, caption_label, ITM_label)
+    # (modules/model.py:372) -- every padded caption row is computed and all 80 text rows go through the MLM head
+    # (:399-410), exactly the work the reference does.
+    cfg.mlm_max_labels_per_sample = None
     model = M.MVLBertForPretraining(cfg).cuda().train()
     M.manual_seed(4321 + rank)                      # dropout stream differs per rank
     seed_coin_flip(5678)                            # seq2seq/bidir flip identical on all ranks
@@ -163,64 +231,71 @@ def main():
     comm = torch.bfloat16 if os.environ.get("MVLT_DDP_BF16") == "1" else torch.float32
     reducer = GradReducer(model, comm_dtype=comm) if use_dist else None
     step = PretrainStep(model, reducer=reducer, world_size=world)
-    # captions are zero-padded to seq80 (lengths U{16..79}).  The padded tail of a caption is a
-    # masked key (bidir) / above the causal diagonal (seq2seq) and carries no label, so nothing that reaches
-    # the loss reads it: by default the BERT tower runs on packed rows, given the tokeniser's lengths on the
-    # host (same loss and gradients, tests/test_model_gpu.py::test_packed_rows_*).  --dense-rows computes the
-    # padded positions too, as the reference does.  FLOP accounting stays reference-equivalent either way.
-    batch = synthetic_batch(PER_GPU_BATCH, SEQ, "cuda", 1234 + rank, with_lengths=not args.dense_rows)
+    batch_full = synthetic_batch(PER_GPU_BATCH, SEQ, "cuda", 1234 + rank, with_lengths=True)
+    batch = batch_full[:4]                          # the reference signature: no caption lengths
 
     for _ in range(args.warmup):
         step(batch)
     timer = KernelTimer(DOMINANT, every=int(os.environ.get("MVLT_BENCH_SAMPLE", "4")))
     ops.GEMM_TIMER = timer
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(batch)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, loss = timed_run(step, batch, args.steps, use_dist, dist)
     ops.GEMM_TIMER = None
-    if use_dist:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    loss_value = float(loss.item())
+
+    # EXTRA (opt-in API, not reachable from the reference's unchanged caller): packed BERT rows via the added
+    # text_lengths= argument + MLM head on the labelled rows only (config.mlm_max_labels_per_sample = 10)
+    extra = None
+    if not args.no_extra:
+        cfg.mlm_max_labels_per_sample = 10
+        for _ in range(max(2, args.warmup // 2)):
+            step(batch_full)
+        e2, l2 = timed_run(step, batch_full, args.steps, use_dist, dist)
+        gpp = packed_gflop_per_pair(batch_full)
+        extra = {"value_packed": round(PER_GPU_BATCH * world * args.steps / e2, 2),
+                 "ms_per_step_packed": round(1e3 * e2 / args.steps, 3),
+                 "packed_variant": "opt-in: forward(..., text_lengths=) packs away padded caption rows; "
+                                   "config.mlm_max_labels_per_sample=10 runs the MLM head on labelled rows only "
+                                   "(same loss and gradients; tests/test_model_gpu.py::test_packed_rows_*)",
+                 "packed_executed_gflop_per_pair": round(gpp, 1),
+                 "packed_step_tflops_per_gpu_executed": round(PER_GPU_BATCH * args.steps / e2 * gpp / 1e3, 2),
+                 "packed_loss": round(float(l2.item()), 4)}
+        cfg.mlm_max_labels_per_sample = None
     if rank == 0:
         pairs = PER_GPU_BATCH * world * args.steps
         value = pairs / elapsed
         kr = timer.result()
         roofline = None
         if kr is not None:
-            roofline = {"bound": "mfma", "kernel": "gemm_group_kernel<bf16,{128|64},128,kmajor,kmajor> (grouped weight-gradient "
-                                                   "GEMMs dW_i = dY_i^T X_i of one layer per launch: 128-row tiles for "
-                                                   "the BertLayer groups, 64-row tiles for the Swin stage-2 groups; side "
-                                                   "stream, overlapped with the dgrad chain)",
+            traffic, src = profiled_traffic()
+            roofline = {"bound": "mfma", "kernel": DOMINANT_NAME,
                         "achieved": round(kr["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(kr["tflops"] / PEAK_BF16_TFLOPS, 4),
-                        # HBM bytes per launch of this kernel from rocprofv3 PMC passes of the same step
-                        # (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_dominant_kernel_traffic.md), not measured live
-                        "traffic": 1.85e8,
+                        # HBM bytes per launch: rocprofv3 PMC passes of the same step (2*FETCH_SIZE + WRITE_SIZE),
+                        # read from the committed profile file named in traffic_source -- not measurable in-process
+                        "traffic": traffic, "traffic_source": src,
                         "launches": kr["launches"], "avg_launch_us": round(kr["avg_us"], 2),
-                        "sampling": f"1 in {timer.every} launches of the kernel inside the timed region"}
+                        "sampling": f"1 in {timer.every} launches of the kernel inside the timed region, HIP events "
+                                    "on the launch stream"}
         out = {"metric": "image-text pairs/sec pretrain step (Swin-S+BERT, 224px, seq80)", "value": round(value, 2),
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "Pretrain (MLM+ITM) Swin-S + BERT-base, batch=32/GPU, 224x224, seq80, bf16 "
-                                      "storage + f32 accumulate/master, fwd+bwd+allreduce+AdamW, random-init weights",
+                                      "storage + f32 accumulate/master, fwd+bwd+allreduce+AdamW, random-init weights; "
+                                      "reference call signature model(image, caption_masked, caption_label, ITM_label)",
                           "global_batch": PER_GPU_BATCH * world, "seq_len": SEQ, "parallelism": f"dp{world}",
-                          "mlm_head_rows": "all" if args.mlm_all_rows else "labelled (<=10/sample)",
-                          "bert_rows": "dense (padded)" if args.dense_rows else "packed (caption padding skipped)",
-                          "loss": round(float(loss.item()), 4)},
+                          "mlm_head_rows": "all (80 per sample, as the reference)",
+                          "bert_rows": "dense (padded caption rows computed, as the reference)",
+                          "grad_exchange": ("none (1 GPU)" if not use_dist else
+                                            f"RCCL all-reduce AVG, {'bf16' if comm == torch.bfloat16 else 'f32'}, 64 MiB "
+                                            "buckets overlapped with backward; per-rank MLM mean over labelled tokens"),
+                          "loss": round(loss_value, 4)},
+               # executed FLOPs == the reference-equivalent 132.7 GFLOP/pair on this path (nothing is skipped)
                "step_tflops_per_gpu": round(value / world * GFLOP_PER_PAIR / 1e3, 2),
                "step_mfma_frac": round(value / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS, 4),
                "roofline": roofline}
+        if extra is not None:
+            out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -30,15 +30,12 @@ def _nothing():
     return None
 
 
-class _MarkChanged:
-    """load_state_dict post-hook (a picklable callable: whole-module torch.save must keep working)."""
-
-    def __init__(self, arena):
-        self.arena = arena
-
-    def __call__(self, module, incompatible_keys):
-        if self.arena is not None:
-            self.arena.mark_parameters_changed()
+def _mark_changed_hook(module, incompatible_keys):
+    """load_state_dict post-hook, registered ONCE per module (a module-level function: picklable, and it holds
+    no reference to any arena -- a rebuilt arena is found through the module, the old one can be freed)."""
+    a = module.__dict__.get("_mvlt_arena")
+    if a is not None:
+        a.mark_parameters_changed()
 
 
 class Arena:
@@ -110,9 +107,10 @@ class Arena:
         # every load_state_dict; mark_parameters_changed() for anything else).
         self._param_versions = -1
         self._scan_ok = False
-        hook = _MarkChanged(self)
         for m in root.modules():
-            m.register_load_state_dict_post_hook(hook)
+            if not m.__dict__.get("_mvlt_sd_hooked", False):
+                m.register_load_state_dict_post_hook(_mark_changed_hook)
+                m.__dict__["_mvlt_sd_hooked"] = True
         self._views: Dict[tuple, torch.Tensor] = {}
         self.has_grad = _EpochFlags(self.params)       # has_grad[id(p)] -> bool, reset in O(1) per backward pass
         self._marked: List[nn.Parameter] = []
@@ -204,6 +202,7 @@ class Arena:
     # ------------------------------------------------------------------ per-step state
     def begin_backward(self) -> None:
         self._scan_ok = False          # an optimizer step usually follows: look at the parameter versions again
+        self._stash_live_grads()
         self.has_grad.clear()
         self._marked = []
         self._watermark = self.total
@@ -215,26 +214,83 @@ class Arena:
         """Expose gradients the torch way: p.grad is a view for parameters that
         received a gradient this step and None for the others (so a stock
         torch optimizer skips them exactly as it does for the reference).
-        Only parameters whose status changed since the previous step are touched."""
+        A stock optimizer's ``zero_grad()`` (set_to_none=True, the reference loop run_pretrain.py:182-184) drops
+        every view each step and the marked set changes with the seq2seq/bidir coin flip, so EVERY marked
+        parameter whose ``grad`` is None gets its (cached) view back -- not only the ones whose status changed."""
+        self._merge_stashed_grads()
         cur = frozenset(id(p) for p in self._marked)
-        if cur == self._published:
-            # unchanged set: nothing to do -- unless somebody dropped the views (optimizer.zero_grad() sets
-            # p.grad = None every step in the reference loop): then all of them are handed out again
-            if not self._marked or (self._marked[0].grad is not None and self._marked[-1].grad is not None):
-                return
-            self._published = None
         prev = self._published or frozenset()
-        byid = self.__dict__.get("_byid")
-        if byid is None:
-            byid = self._byid = {id(p): p for p in self.params}
-        for pid in cur ^ prev:
-            p = byid[pid]
-            if pid in cur:
-                o, n = self.offset[pid], p.numel()
-                p.grad = self.grad[o:o + n].view(p.shape)
-            else:
-                p.grad = None
+        gv = self.__dict__.get("_pgrad_views")
+        if gv is None:
+            gv = self._pgrad_views = {}
+        for p in self._marked:
+            if p.grad is None:
+                pid = id(p)
+                v = gv.get(pid)
+                if v is None:
+                    o = self.offset[pid]
+                    v = gv[pid] = self.grad[o:o + p.numel()].view(p.shape)
+                p.grad = v
+        if prev != cur:
+            byid = self.__dict__.get("_byid")
+            if byid is None:
+                byid = self._byid = {id(p): p for p in self.params}
+            for pid in prev - cur:
+                byid[pid].grad = None
         self._published = cur
+        self._consumed = False
+
+    def note_grads_consumed(self) -> None:
+        """FusedAdamW.step() / zero_grad(): the gradients of the last backward pass have been used."""
+        self._consumed = True
+
+    # ------------------------------------------------------------------ gradient accumulation (torch semantics)
+    # The kernels WRITE parameter gradients.  torch accumulates into p.grad until it is cleared, so when a
+    # backward pass starts while gradients of an earlier pass are still live (p.grad is not None and no
+    # FusedAdamW.step()/zero_grad() in between -- a gradient-accumulation loop, or two losses backpropagated one
+    # after the other) the live ranges are copied aside first and added back when the pass ends.  Two extra
+    # streaming passes over the live ranges, paid only by loops that accumulate; the reference loop
+    # (run_pretrain.py:181-184: backward, step, zero_grad) never does.
+    def _stash_live_grads(self) -> None:
+        self._acc_ranges, self._acc_params = [], []
+        prev = self._marked
+        if not prev or self.__dict__.get("_consumed", True):
+            return
+        live = [p for p in prev if p.grad is not None]
+        if not live:
+            return
+        live.sort(key=lambda p: self.offset[id(p)])
+        ranges: List[List[int]] = []
+        for p in live:
+            o = self.offset[id(p)]
+            e = o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            if ranges and ranges[-1][1] == o:
+                ranges[-1][1] = e
+            else:
+                ranges.append([o, e])
+        st = self.__dict__.get("_stash")
+        if st is None:
+            st = self._stash = torch.empty_like(self.grad)
+        for a, b in ranges:
+            st[a:b].copy_(self.grad[a:b])
+        self._acc_ranges, self._acc_params = ranges, live
+
+    def _merge_stashed_grads(self) -> None:
+        if not self.__dict__.get("_acc_ranges"):
+            return
+        if self.grad.is_cuda:                        # weight gradients of this pass come from the side stream
+            from . import ops
+            ops.join_side(self.grad.device)
+        for p in self._acc_params:                   # a parameter only the earlier pass touched keeps that gradient
+            pid = id(p)
+            if not self.has_grad[pid]:
+                o = self.offset[pid]
+                self.grad[o:o + p.numel()].zero_()
+                self.has_grad.set(pid)
+                self._marked.append(p)
+        for a, b in self._acc_ranges:
+            self.grad[a:b].add_(self._stash[a:b])
+        self._acc_ranges, self._acc_params = [], []
 
     def mark_parameters_changed(self) -> None:
         """Call after writing parameter values by any route the arena cannot see."""

@@ -59,19 +59,28 @@ def plan_ranges(arena: Arena, lo: int, hi: int, done: set) -> List[Tuple[int, in
 
 class GradReducer:
     def __init__(self, model, bucket_bytes: int = 64 << 20, process_group=None, allow_cpu: bool = False,
-                 comm_dtype: torch.dtype = torch.float32):
-        """comm_dtype=torch.bfloat16: buckets are cast to bf16 for the exchange and back afterwards (half the xGMI
+                 comm_dtype: torch.dtype = torch.float32, average: bool = True):
+        """average=True (default): p.grad ends up as the MEAN over ranks, like torch DDP, so a stock torch
+        optimizer / clip_grad_norm_ on the drop-in sees what it would see on one GPU (RCCL's AVG reduction: no
+        extra pass; other backends: SUM + one in-place scale).  average=False leaves the SUM (pair it with
+        FusedAdamW(grad_scale=1/world)).
+        comm_dtype=torch.bfloat16: buckets are cast to bf16 for the exchange and back afterwards (half the xGMI
         bytes; the cross-rank sum is then rounded to bf16 -- PyTorch DDP's bf16_compress_hook trade-off).  The
         default keeps the reference-equivalent f32 sum."""
         if comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("comm_dtype must be float32 or bfloat16")
         self.comm_dtype = comm_dtype
+        self.average = average
         self.comm_buf = None
         self.pending_casts = []
         self.model = model
         self.bucket_elems = bucket_bytes // 4
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
+        try:
+            self._avg_op = dist.get_backend(process_group) == "nccl"      # ncclAvg; gloo has no AVG
+        except Exception:
+            self._avg_op = False
         self.allow_cpu = allow_cpu
         self.arena = None
         self.handles = []
@@ -111,8 +120,9 @@ class GradReducer:
             ops.LnReduceQueue.flush_all()         # LayerNorm gamma/beta gradients are reduced in deferred batches
             ops.join_side(arena.flat.device)      # weight gradients are produced on the side stream
         ranges = plan_ranges(arena, lo, hi, self.done)
+        op = dist.ReduceOp.AVG if (self.average and self._avg_op) else dist.ReduceOp.SUM
         if self.comm_dtype == torch.float32:
-            hs = [dist.all_reduce(arena.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for a, b in ranges]
+            hs = [dist.all_reduce(arena.grad[a:b], op=op, group=self.pg, async_op=True) for a, b in ranges]
         else:
             if self.on_bucket is not None:
                 raise RuntimeError("compressed gradient exchange cannot feed the overlapped optimizer")
@@ -126,7 +136,7 @@ class GradReducer:
                     ops.cast(arena.grad[a:b], self.comm_dtype, out=buf)
                 else:
                     buf.copy_(arena.grad[a:b])
-                hs.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                hs.append(dist.all_reduce(buf, op=op, group=self.pg, async_op=True))
                 self.pending_casts.append((a, b))
         self.handles += hs
         self.launched += ranges
@@ -148,3 +158,6 @@ class GradReducer:
             else:
                 arena.grad[a:b].copy_(self.comm_buf[a:b])
         self.pending_casts = []
+        if self.average and not self._avg_op and self.world > 1:      # no AVG reduction on this backend (gloo)
+            for a, b in self.launched:
+                arena.grad[a:b].mul_(1.0 / self.world)

@@ -38,6 +38,18 @@ class FusedAdamW:
         if ar is not self._arena or ar.exp_avg is None:
             ar.exp_avg = torch.zeros_like(ar.flat)
             ar.exp_avg_sq = torch.zeros_like(ar.flat)
+            old = self._arena
+            if old is not None and old is not ar and old.exp_avg is not None:
+                # the arena was rebuilt (dtype switch, .cuda()/.to() after first use): carry the moments and step
+                # counts over, parameter by parameter, instead of silently restarting Adam
+                for p in ar.params:
+                    pid = id(p)
+                    if pid in old.offset and old.numel[pid] == p.numel():
+                        o, oo, n = ar.offset[pid], old.offset[pid], p.numel()
+                        ar.exp_avg[o:o + n].copy_(old.exp_avg[oo:oo + n])
+                        ar.exp_avg_sq[o:o + n].copy_(old.exp_avg_sq[oo:oo + n])
+                        ar.steps[pid] = old.steps[pid]
+                old.exp_avg = old.exp_avg_sq = None
             self._arena = ar
             if self._overlap is not None:
                 self._hook(ar)
@@ -45,7 +57,10 @@ class FusedAdamW:
 
     def zero_grad(self, set_to_none=True):
         """Gradients are overwritten (not accumulated) by every backward pass and
-        parameters without a gradient are tracked per step, so nothing to clear."""
+        parameters without a gradient are tracked per step, so nothing to clear; the call only tells the
+        arena that the caller is done with the last backward pass's gradients."""
+        if self._arena is not None:
+            self._arena.note_grads_consumed()
 
     # ------------------------------------------------------------------ checkpoint / resume (absent in the reference)
     def state_dict(self):
@@ -170,3 +185,4 @@ class FusedAdamW:
             self._stepped = set()
         ar.bump_steps()
         ar.note_params_written_by_kernel()
+        ar.note_grads_consumed()

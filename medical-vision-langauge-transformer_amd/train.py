@@ -38,8 +38,10 @@ class PretrainStep:
     def __init__(self, model, lr=None, reducer=None, world_size=1, overlap_optimizer=None):
         import os
         self.model = model
+        # the reducer hands out rank-averaged gradients by default (like torch DDP); a SUM reducer is rescaled here
+        gs = 1.0 if (reducer is None or getattr(reducer, "average", False)) else 1.0 / world_size
         self.opt = FusedAdamW(model, lr=lr if lr is not None else model.config.lr, betas=(0.9, 0.999), eps=1e-6,
-                              weight_decay=1e-4, grad_scale=1.0 / world_size)
+                              weight_decay=1e-4, grad_scale=gs)
         self.reducer = reducer
         if overlap_optimizer is None:
             overlap_optimizer = os.environ.get("MVLT_OPT_OVERLAP", "0") == "1"

@@ -19,6 +19,89 @@ class Toy(nn.Module):
         self.c = nn.Linear(100, 10)       # "late" layer (high offsets)
 
 
+def _real_model_marks(model):
+    """Parameter groups in the order the real engines mark them during a backward pass (model.py heads ->
+    bert.py layers N-1..0 -> embeddings -> swin.py final norm, stages 3..0, patch embed), for the seq2seq flip."""
+    order = []
+    h = model.MLM_head_seq2seq.predictions
+    order.append([h.decoder.weight, h.decoder.bias, h.transform.LayerNorm.weight, h.transform.LayerNorm.bias,
+                  h.transform.dense.weight, h.transform.dense.bias])
+    order.append([model.ITM_mlp.weight, model.ITM_mlp.bias])
+    bert = model.MVLBert
+    order.append([bert.pooler.dense.weight, bert.pooler.dense.bias])
+    for layer in reversed(list(bert.encoder.layer)):
+        order.append([p for p in layer.parameters()])
+    order.append([bert.word_embeddings.weight, bert.position_embeddings.weight, bert.token_type_embeddings.weight])
+    swin = model.conv.conv[0]
+    order.append([swin.norm.weight, swin.norm.bias])
+    for st in reversed(list(swin.layers)):
+        if st.downsample is not None:
+            order.append(list(st.downsample.parameters()))
+        for blk in reversed(list(st.blocks)):
+            order.append(list(blk.parameters()))
+    order.append(list(swin.patch_embed.parameters()))
+    return order
+
+
+def _worker_real(rank, world, port, q, average):
+    """The REAL model's arena (582 parameters, fused QKV groups, idle MLM head, never-used parameters) under the
+    reducer: one emulated backward pass per rank over gloo."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import mvlt_amd as M
+        from mvlt_amd.ddp import GradReducer
+        from mvlt_amd import runtime
+        torch.manual_seed(rank)
+        cfg = M.MVLBertPretrainConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                      intermediate_size=512, vocab_size=500)
+        cfg.swin.update(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8])
+        cfg.ITM_task = True
+        model = M.MVLBertForPretraining(cfg)
+        red = GradReducer(model, bucket_bytes=256 * 1024, allow_cpu=True, average=average)
+        ar = red.arena
+        flats = [torch.zeros_like(ar.flat) for _ in range(world)]
+        dist.all_gather(flats, ar.flat)
+        assert all(torch.equal(flats[0], t) for t in flats), "replicas differ after broadcast"
+        ar.begin_backward()
+        g = torch.Generator().manual_seed(100 + rank)
+        local = {}
+        for grp in _real_model_marks(model):
+            for p in grp:
+                v = ar.grad_view(p) if p.dim() > 1 else ar.grad[ar.offset[id(p)]:ar.offset[id(p)] + p.numel()]
+                v.copy_(torch.randn(v.shape, generator=g))
+                local[id(p)] = v.clone().reshape(-1)
+            ar.mark(*grp)
+        n_early = len(red.launched)
+        assert n_early >= 2, "buckets should leave while the backward pass is still running"
+        runtime.backward_end(ar)
+        covered = sorted(red.launched)
+        for (a0, b0), (a1, b1) in zip(covered, covered[1:]):
+            assert b0 <= a1, "overlapping all-reduce ranges"
+        named = dict(model.named_parameters())
+        for k in ("MLM_head_bidir.predictions.decoder.weight", "conv.conv.0.head.weight", "conv.resnet_fc.weight",
+                  "MVLBert.embedding_LayerNorm.weight"):
+            o = ar.offset[id(named[k])]
+            assert not any(a <= o < b for a, b in covered), f"{k} has no gradient but was communicated"
+            assert named[k].grad is None
+        scale = 1.0 / world if average else 1.0
+        for k, p in named.items():
+            if id(p) not in local:
+                continue
+            mine = [torch.zeros_like(local[id(p)]) for _ in range(world)]
+            dist.all_gather(mine, local[id(p)])
+            assert p.grad is not None, k
+            assert torch.allclose(p.grad.reshape(-1), sum(mine) * scale, atol=1e-6), k
+        q.put((rank, "ok", n_early, len(covered)))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc(), 0, 0))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q, bf16_comm=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,7 +113,7 @@ def _worker(rank, world, port, q, bf16_comm=False):
         from mvlt_amd import runtime
         torch.manual_seed(rank)             # different init per rank -> broadcast must equalise
         model = Toy()
-        red = GradReducer(model, bucket_bytes=64 * 1024, allow_cpu=True,
+        red = GradReducer(model, bucket_bytes=64 * 1024, allow_cpu=True, average=False,
                           comm_dtype=torch.bfloat16 if bf16_comm else torch.float32)
         ar = red.arena
         ref0 = [torch.zeros_like(ar.flat) for _ in range(world)]
@@ -89,6 +172,23 @@ def test_gradient_exchange_two_ranks_gloo(bf16_comm):
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("average", [True, False])
+def test_real_model_arena_two_ranks_gloo(average):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, q, average)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in res), res

@@ -83,3 +83,46 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "mvlt_oracle" not in src, f
+
+
+def _toy_arena():
+    import torch.nn as nn
+    from mvlt_amd.arena import Arena
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.common, self.b = nn.Linear(4, 4), nn.Linear(4, 4), nn.Linear(4, 4)
+    m = Toy()
+    return m, Arena(m, torch.float32, allow_cpu=True)
+
+
+def test_publish_grads_rehands_views_after_zero_grad_with_a_changing_marked_set():
+    """stock optimizer zero_grad() drops every p.grad view; when the marked set then changes
+    (seq2seq/bidir coin flip swaps the MLM head) the parameters common to both steps must get their view back."""
+    m, ar = _toy_arena()
+    ar.begin_backward(); ar.mark(m.a.weight, m.common.weight); ar.publish_grads()
+    assert m.a.weight.grad is not None and m.common.weight.grad is not None and m.b.weight.grad is None
+    m.zero_grad(set_to_none=True)
+    ar.begin_backward(); ar.mark(m.b.weight, m.common.weight); ar.publish_grads()
+    assert m.common.weight.grad is not None and m.b.weight.grad is not None and m.a.weight.grad is None
+    assert m.common.weight.grad.data_ptr() == ar.grad_view(m.common.weight).data_ptr()
+
+
+def test_unconsumed_gradients_accumulate_and_consumed_ones_do_not():
+    m, ar = _toy_arena()
+    ar.begin_backward(); ar.grad_view(m.a.weight).fill_(1.0); ar.grad_view(m.common.weight).fill_(2.0)
+    ar.mark(m.a.weight, m.common.weight); ar.publish_grads()
+    # second pass without clearing: a different set; common accumulates, a keeps its value, b is new
+    ar.begin_backward(); ar.grad_view(m.b.weight).fill_(5.0); ar.grad_view(m.common.weight).fill_(3.0)
+    ar.mark(m.b.weight, m.common.weight); ar.publish_grads()
+    assert float(m.common.weight.grad[0, 0]) == 5.0 and float(m.a.weight.grad[0, 0]) == 1.0
+    assert float(m.b.weight.grad[0, 0]) == 5.0 and ar.has_grad[id(m.a.weight)]
+    # cleared in between (zero_grad set_to_none) -> plain overwrite
+    m.zero_grad(set_to_none=True)
+    ar.begin_backward(); ar.grad_view(m.common.weight).fill_(7.0); ar.mark(m.common.weight); ar.publish_grads()
+    assert float(m.common.weight.grad[0, 0]) == 7.0 and m.a.weight.grad is None
+    # consumed by the fused optimizer -> overwrite although the views are still attached
+    ar.note_grads_consumed()
+    ar.begin_backward(); ar.grad_view(m.common.weight).fill_(1.5); ar.mark(m.common.weight); ar.publish_grads()
+    assert float(m.common.weight.grad[0, 0]) == 1.5

@@ -396,6 +396,7 @@ def test_ddp_buckets_carry_final_gradients(M, specs, monkeypatch):
         image, ids, labels, itm = synth_batch(3, 24, seed=41, vocab=3000)
         monkeypatch.setattr(random, "random", lambda: 0.9)
         for _ in range(2):       # second pass: stale values of the first one must not leak through
+            model.zero_grad()
             loss = model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda())
             loss.backward()
         torch.cuda.synchronize()
@@ -425,6 +426,7 @@ def test_image_pair_input_gradients_are_summed_over_both_views(M, specs):
     both = {k: p.grad.clone() for k, p in conv.named_parameters() if p.grad is not None}
     single = []
     for i in range(2):
+        conv.zero_grad()
         o = conv(pair[:, i].contiguous())
         assert torch.allclose(o, out[:, 49 * i:49 * (i + 1)], rtol=1e-4, atol=1e-5)
         (o.float() * w[:, 49 * i:49 * (i + 1)]).sum().backward()
@@ -499,6 +501,7 @@ def test_packed_rows_give_the_dense_loss_and_gradients(M, specs, monkeypatch, na
     monkeypatch.setattr(random, "random", lambda: 0.1 if name == "seq2seq" else 0.9)
     runs = []
     for tl in (None, lengths):
+        model.zero_grad()
         loss = model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda(), text_lengths=tl)
         loss.backward()
         torch.cuda.synchronize()
@@ -894,9 +897,73 @@ def test_mvlbert_optional_inputs_vs_oracle(M, specs, cd):
         assert rel_err(out[0].float().cpu()[rows], ref["hidden"][rows]) < ACT[cd] * 3
 
 
+def test_stock_adamw_with_alternating_mlm_heads_never_skips_a_parameter(M, specs, monkeypatch):
+    """The reference loop (run_pretrain.py:181-184): stock AdamW + zero_grad() (set_to_none) while the seq2seq/bidir
+    coin flip alternates the active MLM head.  Every parameter that received a gradient must have p.grad set on
+    every step (a parameter common to both steps used to keep p.grad = None and was silently skipped)."""
+    flips = iter([0.9, 0.1, 0.9, 0.1, 0.1, 0.9])
+    monkeypatch.setattr(random, "random", lambda: next(flips))
+    model = M.MVLBertForPretraining(tiny_cfg(M, ITM_task=True))
+    load_formula(model, specs["tiny_pretrain"])
+    model = M.set_compute_dtype(model.cuda().eval(), F32)
+    image, ids, labels, itm = (t.cuda() for t in synth_batch(3, 24, seed=41, vocab=3000))
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    params = dict(model.named_parameters())
+    for step in range(6):
+        loss = model(image, ids, labels, itm)
+        loss.backward()
+        active = "MLM_head_seq2seq" if model.last_seq2seq else "MLM_head_bidir"
+        idle = "MLM_head_bidir" if model.last_seq2seq else "MLM_head_seq2seq"
+        missing = [k for k, p in params.items() if p.grad is None and not k.startswith(idle)
+                   and not k.startswith(("conv.conv.0.head", "conv.resnet_fc", "MVLBert.embedding_LayerNorm"))
+                   and not k.endswith("predictions.bias")]
+        assert not missing, (step, missing[:8])
+        assert params[f"{active}.predictions.decoder.weight"].grad is not None
+        assert params[f"{idle}.predictions.decoder.weight"].grad is None
+        before = params["MVLBert.encoder.layer.0.output.dense.weight"].detach().clone()
+        opt.step()
+        opt.zero_grad()
+        assert not torch.equal(before, params["MVLBert.encoder.layer.0.output.dense.weight"])   # really updated
+
+
+def test_gradient_accumulation_matches_torch_semantics(M, specs, monkeypatch):
+    """Two backward passes without clearing the gradients accumulate, like autograd does (micro-batching);
+    clearing (zero_grad) or FusedAdamW.step() in between starts from zero."""
+    from mvlt_amd.optim import FusedAdamW
+    flips = iter([0.9, 0.1, 0.9, 0.1, 0.9, 0.1, 0.9])
+    monkeypatch.setattr(random, "random", lambda: next(flips))
+    model = M.MVLBertForPretraining(tiny_cfg(M, ITM_task=True))
+    load_formula(model, specs["tiny_pretrain"])
+    model = M.set_compute_dtype(model.cuda().eval(), F32)
+    b1 = tuple(t.cuda() for t in synth_batch(3, 24, seed=41, vocab=3000))
+    b2 = tuple(t.cuda() for t in synth_batch(3, 24, seed=42, vocab=3000))
+    single = []
+    for b in (b1, b2):                       # bidir head on b1, seq2seq head on b2
+        model.zero_grad()
+        model(*b).backward()
+        single.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    model.zero_grad()
+    model(*b1).backward()
+    model(*b2).backward()                    # not cleared in between: accumulates
+    both = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert both.keys() == single[0].keys() | single[1].keys()
+    bad = []
+    for k, g in both.items():
+        want = sum(s[k] for s in single if k in s)
+        if rel_err(g, want) > 1e-5 and want.abs().max() > 1e-9:
+            bad.append((k, rel_err(g, want)))
+    assert not bad, bad[:8]
+    # FusedAdamW.step() consumes the gradients: the next pass starts from zero again
+    opt = FusedAdamW(model, lr=0.0, weight_decay=0.0)
+    opt.step()
+    model(*b1).backward()
+    k = "MVLBert.encoder.layer.1.intermediate.dense.weight"
+    assert rel_err(dict(model.named_parameters())[k].grad, single[0][k]) < 1e-5
+
+
 def test_two_forward_passes_before_one_backward_fail_loudly(M, specs, monkeypatch):
-    """Gradients are overwritten per backward pass; summing the losses of two forward calls would silently drop
-    one contribution, so the second write of a parameter's gradient in one pass raises."""
+    """One backward pass that reaches the same module twice (the losses of two forward calls summed) would
+    overwrite the first contribution inside the pass, so the second write of a parameter's gradient raises."""
     monkeypatch.setattr(random, "random", lambda: 0.9)
     model = M.MVLBertForPretraining(tiny_cfg(M, ITM_task=True))
     load_formula(model, specs["tiny_pretrain"])
