@@ -188,6 +188,36 @@ typedef struct MvltAttn {
 int mvlt_attn_fwd(const MvltAttn* p, void* stream);
 int mvlt_attn_bwd(const MvltAttn* p, void* stream);   /* delta_ws: f32 [nseq,nH,L] */
 
+/* ------------------------------------------------------------------ fused Swin (S)W-MSA (SURVEY.md 8b `swin_wmsa`)
+ * The attention half of SwinTransformerBlock.forward in ONE launch (visual_feature_extractor.py:356-384 around
+ * WindowAttention.forward :224-254):
+ *   y = x + rowscale[b] * proj( softmax(q k^T * scale + rel_pos_bias + shift_mask) v ),  q,k,v = qkv(norm1(x))
+ * with roll(-shift) + window_partition on the way in and window_reverse + roll(+shift) on the way out expressed
+ * by the row map w2n (window-order row -> token row, the INT tables of SURVEY 8a2/8a3); window 7, head_dim 32.
+ * x, y: [B*res*res, C] token order (y may not alias x).  The qkv tensor and the attention output never make an
+ * HBM round trip.  Training: the optional pointers receive what the backward pass needs, as write-only outputs:
+ *   xn_win   [B*res*res, C]  norm1(x), window order (A operand of the qkv weight gradient)
+ *   attn_out [B*res*res, C]  attention output, window order (A operand of the proj weight gradient)
+ *   lse      f32 [B*nW, nH, 49], mean / rstd f32 [B*res*res] (token order)
+ * backward (mvlt_swin_wmsa_bwd): dy_win = gradient of the proj output in WINDOW order (rowscale already applied);
+ *   recomputes q,k,v from xn_win, writes dqkv [B*res*res, 3C] (window order, for the qkv weight gradient) and
+ *   dxn_win [B*res*res, C] = dqkv Wqkv (window order; LayerNorm backward consumes it through its dy_rowmap);
+ *   dbias_table f32 [169, nH] is ACCUMULATED (zero it first). */
+typedef struct MvltSwinWmsa {
+    int dtype, B, res, C, nH, shift;
+    const void* x; void* y; const int32_t* w2n;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const void* wqkv; const float* bqkv; const void* wproj; const float* bproj;
+    const float* bias_table; float scale;
+    const float* rowscale;             /* optional DropPath keep/(1-p), f32 [B] */
+    void* xn_win; void* attn_out; float* lse; float* mean; float* rstd;
+    /* backward only */
+    const void* dy_win; void* dqkv; void* dxn_win; float* dbias_table;
+} MvltSwinWmsa;
+int mvlt_swin_wmsa_supported(int dtype, int C, int nH);   /* 1 when the fused kernels cover this width */
+int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream);
+int mvlt_swin_wmsa_bwd(const MvltSwinWmsa* p, void* stream);
+
 /* ------------------------------------------------------------------ data movement / embeddings
  * PatchEmbed im2col (visual_feature_extractor.py:562): img f32 NCHW [B,3,S,S]
  * -> cols [B*(S/P)^2, 3*P*P] in (c,dy,dx) order = Conv2d weight.view(96,-1). */

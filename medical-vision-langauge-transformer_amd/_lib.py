@@ -67,6 +67,16 @@ class MvltAttn(C.Structure):
                 ("row_start", vp), ("seq_len", vp)]
 
 
+class MvltSwinWmsa(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("res", i32), ("C", i32), ("nH", i32), ("shift", i32),
+                ("x", vp), ("y", vp), ("w2n", vp),
+                ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32),
+                ("wqkv", vp), ("bqkv", vp), ("wproj", vp), ("bproj", vp),
+                ("bias_table", vp), ("scale", f32), ("rowscale", vp),
+                ("xn_win", vp), ("attn_out", vp), ("lse", vp), ("mean", vp), ("rstd", vp),
+                ("dy_win", vp), ("dqkv", vp), ("dxn_win", vp), ("dbias_table", vp)]
+
+
 class MvltEmbed(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("n_img", i32), ("T", i32), ("H", i32),
                 ("text_ids", vp), ("image_feature", vp),
@@ -110,6 +120,9 @@ SYMBOLS = {
     "mvlt_layernorm_param_reduce_batch": (i32, [C.POINTER(MvltLnReduceItem), i32, vp]),
     "mvlt_attn_fwd": (i32, [C.POINTER(MvltAttn), vp]),
     "mvlt_attn_bwd": (i32, [C.POINTER(MvltAttn), vp]),
+    "mvlt_swin_wmsa_supported": (i32, [i32, i32, i32]),
+    "mvlt_swin_wmsa_fwd": (i32, [C.POINTER(MvltSwinWmsa), vp]),
+    "mvlt_swin_wmsa_bwd": (i32, [C.POINTER(MvltSwinWmsa), vp]),
     "mvlt_im2col_patch": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "mvlt_embed_fwd": (i32, [C.POINTER(MvltEmbed), vp]),
     "mvlt_embed_bwd": (i32, [C.POINTER(MvltEmbed), vp]),

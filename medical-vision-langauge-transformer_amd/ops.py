@@ -498,6 +498,48 @@ def attn_bwd(dout, qkv, out, lse, mode, nseq, Lq, nH, hd, scale, dbias_table=Non
     return dqkv
 
 
+# ----------------------------------------------------------------------------- fused Swin W-MSA
+def swin_wmsa_supported(dtype, C_, nH):
+    return bool(L.lib().mvlt_swin_wmsa_supported(_DT[dtype], C_, nH))
+
+
+def _wmsa_struct(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj, bproj, table, scale, rowscale):
+    Cn = x.shape[1]
+    assert x.is_contiguous() and x.shape[0] == B * res * res and w2n.dtype == torch.int32 and w2n.numel() == x.shape[0]
+    assert wqkv.dtype == x.dtype and wproj.dtype == x.dtype and wqkv.shape == (3 * Cn, Cn) and wproj.shape == (Cn, Cn)
+    assert wqkv.is_contiguous() and wproj.is_contiguous() and table.dtype == torch.float32 and table.shape == (169, nH)
+    p = L.MvltSwinWmsa()
+    p.dtype, p.B, p.res, p.C, p.nH, p.shift = _DT[x.dtype], B, res, Cn, nH, shift
+    p.x, p.w2n = x.data_ptr(), w2n.data_ptr()
+    p.ln_gamma, p.ln_beta, p.ln_eps = gamma.data_ptr(), beta.data_ptr(), eps
+    p.wqkv, p.bqkv, p.wproj, p.bproj = wqkv.data_ptr(), bqkv.data_ptr(), wproj.data_ptr(), bproj.data_ptr()
+    p.bias_table, p.scale = table.data_ptr(), float(scale)
+    if rowscale is not None:
+        assert rowscale.dtype == torch.float32 and rowscale.numel() == B and rowscale.is_contiguous()
+        p.rowscale = rowscale.data_ptr()
+    return p
+
+
+def swin_wmsa_fwd(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj, bproj, table, scale,
+                  rowscale=None, save=False):
+    """y = x + rowscale * proj(window_attention(qkv(norm1(x))))  (MvltSwinWmsa): one launch.
+    save=True also returns (xn_win, attn_out, lse, mean, rstd) for the backward pass."""
+    _need_cuda(x)
+    p = _wmsa_struct(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj, bproj, table, scale, rowscale)
+    y = torch.empty_like(x)
+    p.y = y.data_ptr()
+    saved = None
+    if save:
+        rows = x.shape[0]
+        xn, ao = torch.empty_like(x), torch.empty_like(x)
+        lse = torch.empty((rows // 49, nH, 49), dtype=torch.float32, device=x.device)
+        mean, rstd = torch.empty((2, rows), dtype=torch.float32, device=x.device).unbind(0)
+        p.xn_win, p.attn_out, p.lse, p.mean, p.rstd = xn.data_ptr(), ao.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        saved = (xn, ao, lse, mean, rstd)
+    L.check(L.lib().mvlt_swin_wmsa_fwd(C.byref(p), _stream()), "mvlt_swin_wmsa_fwd")
+    return y, saved
+
+
 # ----------------------------------------------------------------------------- data movement
 def im2col_patch(img, dtype, patch):
     _need_cuda(img)

@@ -1,0 +1,51 @@
+"""Fused W-MSA (mvlt_swin_wmsa_fwd/bwd) vs the unfused kernel sequence at the pre-training step's shapes (B=32, bf16)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvlt_amd import ops, _lib as L
+from mvlt_amd.indexing import batched_window_maps
+torch.manual_seed(0)
+dt = torch.bfloat16
+B = int(os.environ.get("B", 32))
+ONLY = os.environ.get("ONLY")          # "fused" -> only the fused kernels (for rocprofv3 passes)
+
+
+def timeit(f, n=20):
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+for st, (res, C, nH) in enumerate([(56, 96, 3), (28, 192, 6), (14, 384, 12)]):
+    if os.environ.get("STAGE") and int(os.environ["STAGE"]) != st:
+        continue
+    nW = (res // 7) ** 2
+    rows = B * res * res
+    x = torch.randn(rows, C, device="cuda").to(dt)
+    g1, b1 = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    wqkv = (torch.randn(3 * C, C, device="cuda") * C ** -0.5).to(dt)
+    bqkv = torch.zeros(3 * C, device="cuda")
+    wproj = (torch.randn(C, C, device="cuda") * C ** -0.5).to(dt)
+    bproj = torch.zeros(C, device="cuda")
+    tbl = torch.randn(169, nH, device="cuda") * 0.02
+    rs = torch.full((B,), 1.1, device="cuda")
+    flop = 2.0 * B * nW * (49 * C * 3 * C + 2 * nH * 49 * 49 * 32 + 49 * C * C)
+    for shift in (0, 3):
+        w2n, n2w = batched_window_maps(B, res, res, 7, shift, x.device)
+        args = (x, w2n, B, res, nH, shift, g1, b1, 1e-5, wqkv, bqkv, wproj, bproj, tbl, 32 ** -0.5)
+        tf_eval = timeit(lambda: ops.swin_wmsa_fwd(*args, rowscale=rs))
+        tf_save = timeit(lambda: ops.swin_wmsa_fwd(*args, rowscale=rs, save=True))
+        line = f"s{st} res={res} C={C} shift={shift}: fused fwd {tf_eval:6.1f} us ({flop/tf_eval/1e6:6.1f} TFLOP/s), +saves {tf_save:6.1f} us"
+        if ONLY != "fused":
+            def unfused():
+                xn, m, r, _ = ops.layernorm_fwd(x, g1, b1, 1e-5, out_rowmap=n2w)
+                qkv = ops.gemm(xn, wqkv, bias=bqkv)
+                ao, lse = ops.attn_fwd(qkv, L.ATTN_SWIN, B * nW, 49, nH, 32, 32 ** -0.5, bias_table=tbl, nW=nW, win_res=res, shift=shift)
+                return ops.gemm(ao, wproj, bias=bproj, residual=x, rowmap=w2n, rowscale=(rs, res * res))
+            tu = timeit(unfused)
+            line += f" | unfused (4 launches) {tu:6.1f} us"
+        print(line, flush=True)

@@ -285,6 +285,66 @@ def test_swin_attention(ops, dt, res, nH, shift):
     assert rel(dtab, tr.grad) < (1e-4 if dt == torch.float32 else 2e-2)
 
 
+def wmsa_ref(x, w2n, nW, res, shift, nH, g1, b1, wqkv, bqkv, wproj, bproj, table, scale, rowscale):
+    """Attention half of SwinTransformerBlock.forward as plain fp32 torch (visual_feature_extractor.py:356-384)."""
+    C_ = x.shape[1]
+    xn = F.layer_norm(x, (C_,), g1, b1, 1e-5)
+    xw = xn[w2n.long()]                                   # roll(-shift) + window_partition
+    qkv = xw @ wqkv.t() + bqkv
+    ao = swin_ref(qkv, table, nW, res, shift, nH, scale)
+    pr = ao @ wproj.t() + bproj
+    y = torch.empty_like(pr)
+    y[w2n.long()] = pr                                    # window_reverse + roll(+shift)
+    if rowscale is not None:
+        y = y * rowscale.repeat_interleave(res * res)[:, None]
+    return x + y, xw, ao
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("res,C_,shift,B,dp", [(14, 384, 3, 3, True), (14, 384, 0, 2, False), (28, 192, 3, 2, True),
+                                              (56, 96, 3, 1, False), (56, 96, 0, 1, True), (14, 512, 3, 1, False),
+                                              (28, 256, 0, 1, False), (56, 128, 3, 1, True)])
+def test_swin_wmsa_fused_forward(ops, dt, res, C_, shift, B, dp):
+    """mvlt_swin_wmsa_fwd (norm1 + shift/partition + qkv + window attention + proj + reverse + DropPath + residual
+    in one launch) against the fp32 torch statement, and against the unfused kernel sequence it replaces."""
+    from mvlt_amd._lib import ATTN_SWIN
+    from mvlt_amd.indexing import batched_window_maps
+    nH = C_ // 32
+    if not ops.swin_wmsa_supported(dt, C_, nH) or (dt == torch.float32 and C_ == 512):
+        pytest.skip("width not covered by the fused kernel in this dtype (LDS)")
+    nW = (res // 7) ** 2
+    x = rnd((B * res * res, C_), dt, 60)
+    g1 = (1.0 + 0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(61))).cuda()
+    b1 = (0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(62))).cuda()
+    wqkv = rnd((3 * C_, C_), dt, 63, C_ ** -0.5)
+    bqkv = (0.1 * torch.randn(3 * C_, generator=torch.Generator().manual_seed(64))).cuda()
+    wproj = rnd((C_, C_), dt, 65, C_ ** -0.5)
+    bproj = (0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(66))).cuda()
+    table = (0.5 * torch.randn(169, nH, generator=torch.Generator().manual_seed(67))).cuda()
+    rs = torch.tensor([0.0, 1.25, 1.25][:B] if B > 1 else [1.25]).cuda() if dp else None
+    scale = 32 ** -0.5
+    w2n, n2w = batched_window_maps(B, res, res, 7, shift, x.device)
+    y, (xn, ao, lse, mean, rstd) = ops.swin_wmsa_fwd(x, w2n, B, res, nH, shift, g1, b1, 1e-5, wqkv, bqkv, wproj, bproj,
+                                                      table, scale, rowscale=rs, save=True)
+    ref, xw_ref, ao_ref = wmsa_ref(x.float(), w2n, nW, res, shift, nH, g1, b1, wqkv.float(), bqkv, wproj.float(), bproj,
+                                   table, scale, rs)
+    t = tol(dt)
+    assert rel(xn, xw_ref) < t
+    assert rel(ao, ao_ref) < t * 2
+    assert rel(y, ref) < t * 2
+    # eval-mode call (nothing saved) gives the same y
+    y2, none = ops.swin_wmsa_fwd(x, w2n, B, res, nH, shift, g1, b1, 1e-5, wqkv, bqkv, wproj, bproj, table, scale, rowscale=rs)
+    assert none is None and torch.equal(y2, y)
+    # the unfused kernel sequence (LN with row map, qkv GEMM, attention, proj GEMM with scatter + residual)
+    xn_u, mean_u, rstd_u, _ = ops.layernorm_fwd(x, g1, b1, 1e-5, out_rowmap=n2w)
+    qkv_u = ops.gemm(xn_u, wqkv, bias=bqkv)
+    ao_u, lse_u = ops.attn_fwd(qkv_u, ATTN_SWIN, B * nW, 49, nH, 32, scale, bias_table=table, nW=nW, win_res=res, shift=shift)
+    y_u = ops.gemm(ao_u, wproj, bias=bproj, residual=x, rowmap=w2n, rowscale=(rs, res * res) if rs is not None else None)
+    assert rel(xn, xn_u) < 1e-6 and rel(mean, mean_u) < 1e-6 and rel(rstd, rstd_u) < 1e-6
+    assert rel(lse, lse_u) < (1e-5 if dt == torch.float32 else 2e-3)
+    assert rel(ao, ao_u) < t and rel(y, y_u) < t
+
+
 def bert_ref(qkv, B, Lq, nH, mask_add, scale, keep=None, p=0.0):
     hd = qkv.shape[1] // (3 * nH)
     q, k, v = qkv.view(B, Lq, 3, nH, hd).permute(2, 0, 3, 1, 4)

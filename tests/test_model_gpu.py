@@ -192,6 +192,7 @@ def test_full_pretrain_loss_and_grad_slices(M, golden, specs, cd):
     model = M.set_compute_dtype(model.cuda().eval(), cd)
     image, ids, labels, itm = synth_batch(2, 80, seed=21)
     for name, flip in (("seq2seq", 0.1), ("bidir", 0.9)):
+        model.zero_grad()                    # gradients accumulate across backward passes, like autograd
         for itm_on in (False, True):
             cfg.ITM_task = itm_on
             random.random = (lambda v=flip: v)
