@@ -213,6 +213,9 @@ typedef struct MvltSwinWmsa {
     void* xn_win; void* attn_out; float* lse; float* mean; float* rstd;
     /* backward only */
     const void* dy_win; void* dqkv; void* dxn_win; float* dbias_table;
+    /* optional, training: q,k,v in the [B*res*res, 3C] window-order layout MvltAttn uses (forward: write-only
+     * output, so the unfused mvlt_attn_bwd can run on a fused forward; backward: read instead of recomputed) */
+    void* qkv_win;
 } MvltSwinWmsa;
 int mvlt_swin_wmsa_supported(int dtype, int C, int nH);   /* 1 when the fused kernels cover this width */
 int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream);

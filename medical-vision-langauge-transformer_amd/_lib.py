@@ -74,7 +74,7 @@ class MvltSwinWmsa(C.Structure):
                 ("wqkv", vp), ("bqkv", vp), ("wproj", vp), ("bproj", vp),
                 ("bias_table", vp), ("scale", f32), ("rowscale", vp),
                 ("xn_win", vp), ("attn_out", vp), ("lse", vp), ("mean", vp), ("rstd", vp),
-                ("dy_win", vp), ("dqkv", vp), ("dxn_win", vp), ("dbias_table", vp)]
+                ("dy_win", vp), ("dqkv", vp), ("dxn_win", vp), ("dbias_table", vp), ("qkv_win", vp)]
 
 
 class MvltEmbed(C.Structure):

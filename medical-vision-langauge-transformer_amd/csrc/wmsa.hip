@@ -2,25 +2,28 @@
 // SwinTransformerBlock -- norm1, cyclic shift + window partition, qkv projection, per-head window attention with
 // relative-position bias and shift mask, output projection, window reverse + un-shift, DropPath, residual
 // (visual_feature_extractor.py:224-254 and :356-384) -- in ONE launch.  The [tokens, 3C] qkv tensor and the
-// attention output never make an HBM round trip.
+// attention output never make an HBM round trip (training stores them once, write-only, for the backward pass).
 //
-// One workgroup (4 waves) owns one 7x7 window = 49 token rows, padded to 64 = four 16-row MFMA tiles:
+// One workgroup (NW = 4 or 8 waves) owns one 7x7 window = 49 token rows, padded to 64 = four 16-row MFMA tiles:
 //   * the window's rows are gathered from token order (row map), LayerNorm-ed with f32 statistics and kept in LDS
 //     as the A operand of every projection;
 //   * heads are walked in groups of G: the group's 96*G qkv columns are projected with the N tiles dealt to the
-//     four waves, so every weight element is loaded exactly once per workgroup, straight from L2 into MFMA
-//     B fragments (no LDS staging, no barrier inside the k-loop: the A tile is static);
-//   * q, k, v of the group go to a small LDS tile; wave w then runs query tile w of each head with the same
-//     in-register transposed-score softmax as attn.hip (bias values come from an LDS copy of the table through
+//     waves, so every weight element is loaded exactly once per workgroup, straight from L2 into MFMA B fragments
+//     (no LDS staging, no barrier inside the k-loop: the A tile is static).  The weight fragments run PD k-steps
+//     ahead of the MFMAs in a register ring, and the ring is primed across phases: the first k-steps of the next
+//     head group are requested before the output-projection slice of the current one, the output-projection
+//     fragments before the attention phase -- a workgroup streams 8 C^2 bytes of weights from L2 and is
+//     otherwise bound by that latency;
+//   * q, k, v of the group go to an LDS tile; each wave then runs (head, query tile) units with the same
+//     in-register transposed-score softmax as attn.hip (bias values from an LDS copy of the table through
 //     window-invariant per-lane indices);
 //   * the heads' output tile O[64, 32G] is multiplied into the output projection immediately
-//     (y += O_g Wproj[:, g]^T): the projection accumulators live in registers across the head loop, so there is
-//     no [64, C] attention-output tile at all;
+//     (y += O_g Wproj[:, g]^T): the projection accumulators live in registers across the head loop;
 //   * epilogue: + bias, DropPath scale, + shortcut, scattered back to token order.
-// Two barriers per head group.  Training additionally stores what the backward pass needs (window-ordered norm1
-// output, attention output, softmax log-sum-exp, LayerNorm statistics) as write-only side outputs.
+// Two barriers per head group.
 #include "common.h"
 #include "attn_frag.h"
+#include <stdlib.h>
 
 namespace {
 using namespace mvlt_attn;
@@ -32,7 +35,7 @@ struct WmsaDev {
     const void* wqkv; const float* bqkv; const void* wproj; const float* bproj;
     const float* bias_table; float scale;
     const float* rowscale;
-    void* xn; void* ao; float* lse; float* mean; float* rstd;
+    void* xn; void* ao; void* qkv; float* lse; float* mean; float* rstd;
 };
 
 template <typename T, int C, int G> struct WmsaGeom {
@@ -42,7 +45,7 @@ template <typename T, int C, int G> struct WmsaGeom {
     static constexpr size_t QB = (size_t)3 * G * 64 * LDH * sizeof(T);
     static constexpr size_t OB = (size_t)64 * LDO * sizeof(T);
     static constexpr int TBL = 176;                               // floats per head in the LDS bias table
-    static size_t bytes(int nH) { return XB + QB + OB + (size_t)nH * TBL * sizeof(float); }
+    static constexpr size_t bytes(int nH) { return XB + QB + OB + (size_t)nH * TBL * sizeof(float); }
 };
 
 // window-invariant, head-invariant facts about the 16 (key, query) pairs a lane's score registers hold
@@ -71,24 +74,28 @@ struct LanePairs {
     }
 };
 
-template <typename T, int C, int G>
-__global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const WmsaDev p) {
+template <typename T, int C, int G, int NW>
+__global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using GM = WmsaGeom<T, C, G>;
     using M = Mma<T>;
     using Frag = typename M::Frag;
     using Vec = typename TypeInfo<T>::Vec;
+    constexpr int NT = 64 * NW;
     constexpr int E = TypeInfo<T>::E, KB = M::KB;
     constexpr int LDX = GM::LDX, LDH = GM::LDH, LDO = GM::LDO;
     constexpr int KSTEPS = C / KB;               // k-steps of the qkv projection
     constexpr int KBD = 32 / KB;                 // k-steps over the head dim
     constexpr int TPB = Tok<T>::TPB;
     constexpr int KBT = 4 / TPB;                 // k-steps over the 64 (padded) keys
-    constexpr int NTQ = 6 * G, NTQW = (NTQ + 3) / 4;      // qkv N tiles of a head group, per wave
-    constexpr int NTP = C / 16, NTPW = (NTP + 3) / 4;      // proj N tiles, per wave
+    constexpr int NTQ = 6 * G, NTQW = (NTQ + NW - 1) / NW;     // qkv N tiles of a head group, per wave
+    constexpr int NTP = C / 16, NTPW = (NTP + NW - 1) / NW;     // proj N tiles, per wave
     constexpr int KSO = G * 32 / KB;             // k-steps of a head group's slice of the output projection
     constexpr int NHG = C / 32 / G;
+    constexpr int PD = KSTEPS < 4 ? KSTEPS : 4;  // k-steps the qkv weight fragments run ahead
+    constexpr int UPW = 4 * G / NW;              // (head, query tile) attention units per wave
     static_assert(C % 32 == 0 && (C / 32) % G == 0, "head groups");
+    static_assert((4 * G) % NW == 0, "attention units per wave");
 
     T* xln = reinterpret_cast<T*>(smem_raw);
     T* qkvt = reinterpret_cast<T*>(smem_raw + GM::XB);
@@ -98,19 +105,48 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
     const int win = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c15 = lane & 15;
     const T* xg = reinterpret_cast<const T*>(p.x);
+    const T* wq = reinterpret_cast<const T*>(p.wqkv);
+    const T* wp = reinterpret_cast<const T*>(p.wproj);
     const int nH = C / 32;
 
+    // k-slot permutation (bf16, C % 64 == 0): the contraction does not care which 8 inputs a lane's k-slots hold as
+    // long as both operands agree, so lane group g takes bytes [32 g, 32 g + 32) of every 128-byte line of a weight
+    // row -- first half at the even k-step, second half at the odd one.  Two back-to-back loads then consume whole
+    // cache lines (a plain [8 g, 8 g + 8) layout touches every line twice, PD k-steps apart, and the 32-KB L1 has
+    // long dropped it by then: twice the L2 traffic).  koff(kk) = element offset of a lane's 16 bytes at step kk.
+    constexpr bool PAIR = sizeof(T) == 2 && C % 64 == 0;
+    auto koff = [&](int kk) -> int { return PAIR ? (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 : kk * KB + g * E; };
+    // weight fragment of qkv tile t of head group hg at k-step kk: 16 output columns x KB inputs, 16 B per lane
+    auto wq_ptr = [&](int hg, int t) -> const T* {
+        const int tt = min(t, NTQ - 1);
+        const int part = tt / (2 * G), within = tt - part * 2 * G;
+        return wq + (long)(part * C + hg * G * 32 + within * 16 + c15) * C;
+    };
+    constexpr bool PPAIR = sizeof(T) == 2 && (G * 32) % 64 == 0;       // same for the projection's k-slices
+    auto poff = [&](int ks) -> int { return PPAIR ? (ks >> 1) * 64 + g * 16 + (ks & 1) * 8 : ks * KB + g * E; };
+    Frag fb[PD][NTQW];
+    // ---- the first weight fragments of head group 0 are requested before anything else
+    {
+#pragma unroll
+        for (int jj = 0; jj < NTQW; ++jj) {
+            const T* w = wq_ptr(0, wave + NW * jj);
+#pragma unroll
+            for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
+        }
+    }
+
     // ---- bias table -> LDS, [head][176] (entries 169.. = -1e30: padded keys / queries)
-    for (int i = threadIdx.x; i < nH * GM::TBL; i += 256) {
+    for (int i = threadIdx.x; i < nH * GM::TBL; i += NT) {
         const int h = i / GM::TBL, e = i - h * GM::TBL;
         tbl[i] = e < 169 ? p.bias_table[e * nH + h] : NEG_BIG;
     }
 
     // ---- gather the window's rows (token order -> window order), LayerNorm, normalised tile -> LDS
     {
-        constexpr int CPR = C / E, CPL = CPR / 4;         // 16-byte chunks per row / per lane (4 lanes per row)
-        static_assert(CPR % 4 == 0, "row chunks");
-        const int row = threadIdx.x >> 2, sub = threadIdx.x & 3;
+        constexpr int LPR = NW;                            // lanes per row (64 rows)
+        constexpr int CPR = C / E, CPL = CPR / LPR;        // 16-byte chunks per row / per lane
+        static_assert(CPR % LPR == 0, "row chunks");
+        const int row = threadIdx.x / LPR, sub = threadIdx.x % LPR;
         const bool rv = row < 49;
         const int tok = rv ? p.w2n[win * 49 + row] : 0;
         const T* src = xg + (long)tok * C;
@@ -118,24 +154,26 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            xv[i] = rv ? *reinterpret_cast<const Vec*>(src + (sub + 4 * i) * E) : zero_vec<T>();
+            xv[i] = rv ? *reinterpret_cast<const Vec*>(src + (sub + LPR * i) * E) : zero_vec<T>();
 #pragma unroll
             for (int e = 0; e < E; ++e) s += to_f(xv[i][e]);
         }
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
         const float mean = s / C;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < CPL; ++i)
 #pragma unroll
             for (int e = 0; e < E; ++e) { const float d = to_f(xv[i][e]) - mean; q += d * d; }
-        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o, 64);
         const float rstd = rsqrtf(q / C + p.eps);
         if (rv && sub == 0 && p.mean) { p.mean[tok] = mean; p.rstd[tok] = rstd; }
         T* xs = p.xn ? reinterpret_cast<T*>(p.xn) + ((long)win * 49 + row) * C : nullptr;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            const int c = (sub + 4 * i) * E;
+            const int c = (sub + LPR * i) * E;
             Vec o;
 #pragma unroll
             for (int e4 = 0; e4 < E; e4 += 4) {
@@ -150,15 +188,16 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
     }
 
     // ---- per-lane pair facts for this wave's query tile; shift-mask bits of this window
+    const int qt = wave & 3;                      // this wave's query tile in every attention unit it runs
     LanePairs lp;
-    lp.init(16 * wave + c15, g, p.shift);
+    lp.init(16 * qt + c15, g, p.shift);
     uint32_t mbits = 0;
     if (p.shift != 0) {
         const int w = win % p.nW, nwx = p.res / 7;
         const int wy = w / nwx, wx = w - wy * nwx;
         mbits = (wy == nwx - 1 ? lp.rowbits : 0u) | (wx == nwx - 1 ? lp.colbits : 0u);
     }
-    const int qrow = 16 * wave + c15;
+    const int qrow = 16 * qt + c15;
 
     f32x4 pacc[4][NTPW];
 #pragma unroll
@@ -166,8 +205,6 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
 #pragma unroll
         for (int jj = 0; jj < NTPW; ++jj) pacc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const T* wq = reinterpret_cast<const T*>(p.wqkv);
-    const T* wp = reinterpret_cast<const T*>(p.wproj);
     __syncthreads();
 
 #pragma unroll 1
@@ -181,30 +218,26 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
                 for (int jj = 0; jj < NTQW; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
             const T* wrow[NTQW];
 #pragma unroll
-            for (int jj = 0; jj < NTQW; ++jj) {
-                const int t = min(wave + 4 * jj, NTQ - 1);
-                const int part = t / (2 * G), within = t - part * 2 * G;
-                wrow[jj] = wq + (long)(part * C + hg * G * 32 + within * 16 + c15) * C + g * E;
-            }
-            const T* arow = xln + c15 * LDX + g * E;
+            for (int jj = 0; jj < NTQW; ++jj) wrow[jj] = wq_ptr(hg, wave + NW * jj);
+            const T* arow = xln + c15 * LDX;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 Frag fa[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const Frag*>(arow + 16 * i * LDX + kk * KB);
+                for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const Frag*>(arow + 16 * i * LDX + koff(kk));
 #pragma unroll
                 for (int jj = 0; jj < NTQW; ++jj) {
-                    if (wave + 4 * jj < NTQ) {
-                        const Frag fb = *reinterpret_cast<const Frag*>(wrow[jj] + kk * KB);
+                    if (wave + NW * jj < NTQ) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) M::mma(acc[i][jj], fb, fa[i]);
+                        for (int i = 0; i < 4; ++i) M::mma(acc[i][jj], fb[kk % PD][jj], fa[i]);
                     }
+                    if (kk + PD < KSTEPS) fb[kk % PD][jj] = *reinterpret_cast<const Frag*>(wrow[jj] + koff(kk + PD));
                 }
             }
             // + bias, to the q/k/v LDS tiles [part][head][row][32]
 #pragma unroll
             for (int jj = 0; jj < NTQW; ++jj) {
-                const int t = wave + 4 * jj;
+                const int t = wave + NW * jj;
                 if (t < NTQ) {
                     const int part = t / (2 * G), within = t - part * 2 * G;
                     const f32x4 b4 = load4f(p.bqkv + part * C + hg * G * 32 + within * 16 + 4 * g);
@@ -214,11 +247,33 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
                 }
             }
         }
+        // output-projection weight fragments of this head group: requested now, used after the attention phase
+        Frag fpj[KSO][NTPW];
+#pragma unroll
+        for (int jj = 0; jj < NTPW; ++jj) {
+            const int t = min(wave + NW * jj, NTP - 1);
+            const T* w = wp + (long)(16 * t + c15) * C + hg * G * 32;
+#pragma unroll
+            for (int ks = 0; ks < KSO; ++ks) fpj[ks][jj] = *reinterpret_cast<const Frag*>(w + poff(ks));
+        }
         __syncthreads();
 
-        // ================= window attention: wave w = query tile w of each head of the group
+        // ================= (training) q, k, v of the group -> HBM in the [row, 3C] layout of the unfused kernels
+        if (p.qkv) {
+            constexpr int CH = 32 / E;                   // 16-byte chunks per (row, part, head)
+            T* qg = reinterpret_cast<T*>(p.qkv) + (long)win * 49 * 3 * C + hg * G * 32;
+            for (int idx = threadIdx.x; idx < 49 * 3 * G * CH; idx += NT) {
+                const int ch = idx % CH, ph = (idx / CH) % (3 * G), r = idx / (CH * 3 * G);
+                const int part = ph / G, hl = ph - part * G;
+                *reinterpret_cast<Vec*>(qg + (long)r * 3 * C + part * C + hl * 32 + ch * E) =
+                    *reinterpret_cast<const Vec*>(qkvt + ((part * G + hl) * 64 + r) * LDH + ch * E);
+            }
+        }
+
+        // ================= window attention: (head, query tile) units; this wave always runs query tile qt
 #pragma unroll
-        for (int hl = 0; hl < G; ++hl) {
+        for (int u = 0; u < UPW; ++u) {
+            const int hl = NW == 4 ? u : (wave >> 2) + 2 * u;
             const int h = hg * G + hl;
             const T* Q = qkvt + ((0 * G + hl) * 64) * LDH;
             const T* K = qkvt + ((1 * G + hl) * 64) * LDH;
@@ -228,7 +283,7 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
             for (int t = 0; t < 4; ++t) sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             Frag fq[KBD];
 #pragma unroll
-            for (int kb = 0; kb < KBD; ++kb) fq[kb] = frag_rowmajor<T>(Q, LDH, 16 * wave, kb * KB);
+            for (int kb = 0; kb < KBD; ++kb) fq[kb] = frag_rowmajor<T>(Q, LDH, 16 * qt, kb * KB);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -270,13 +325,22 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
 #pragma unroll
             for (int td = 0; td < 2; ++td) store4f(ot + qrow * LDO + hl * 32 + 16 * td + 4 * g, o[td]);
         }
+        // the next head group's first qkv weight fragments: requested before the projection slice below
+        if (hg + 1 < NHG) {
+#pragma unroll
+            for (int jj = 0; jj < NTQW; ++jj) {
+                const T* w = wq_ptr(hg + 1, wave + NW * jj);
+#pragma unroll
+                for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
+            }
+        }
         __syncthreads();
 
         // ================= (training) attention output of the group -> HBM, whole rows, for the proj weight gradient
         if (p.ao) {
             constexpr int CH = G * 32 / E;               // 16-byte chunks per row of the group's tile
             T* aog = reinterpret_cast<T*>(p.ao) + (long)win * 49 * C + hg * G * 32;
-            for (int idx = threadIdx.x; idx < 49 * CH; idx += 256) {
+            for (int idx = threadIdx.x; idx < 49 * CH; idx += NT) {
                 const int r = idx / CH, ch = idx - r * CH;
                 *reinterpret_cast<Vec*>(aog + (long)r * C + ch * E) = *reinterpret_cast<const Vec*>(ot + r * LDO + ch * E);
             }
@@ -284,19 +348,17 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
 
         // ================= output projection, this group's k-slice: y[64, C] += O_g[64, 32 G] Wproj[:, 32 G hg ..]^T
         {
-            const T* arow = ot + c15 * LDO + g * E;
+            const T* arow = ot + c15 * LDO;
 #pragma unroll
             for (int ks = 0; ks < KSO; ++ks) {
                 Frag fa[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const Frag*>(arow + 16 * i * LDO + ks * KB);
+                for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const Frag*>(arow + 16 * i * LDO + poff(ks));
 #pragma unroll
                 for (int jj = 0; jj < NTPW; ++jj) {
-                    const int t = wave + 4 * jj;
-                    if (t < NTP) {
-                        const Frag fb = *reinterpret_cast<const Frag*>(wp + (long)(16 * t + c15) * C + hg * G * 32 + ks * KB + g * E);
+                    if (wave + NW * jj < NTP) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) M::mma(pacc[i][jj], fb, fa[i]);
+                        for (int i = 0; i < 4; ++i) M::mma(pacc[i][jj], fpj[ks][jj], fa[i]);
                     }
                 }
             }
@@ -312,7 +374,7 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
         for (int i = 0; i < 4; ++i) tokm[i] = (16 * i + c15 < 49) ? p.w2n[win * 49 + 16 * i + c15] : -1;
 #pragma unroll
         for (int jj = 0; jj < NTPW; ++jj) {
-            const int t = wave + 4 * jj;
+            const int t = wave + NW * jj;
             if (t < NTP) {
                 const int n = 16 * t + 4 * g;
                 const f32x4 b4 = load4f(p.bproj + n);
@@ -332,28 +394,57 @@ __global__ __launch_bounds__(256, (C <= 192 ? 2 : 1)) void wmsa_fwd_kernel(const
     }
 }
 
-template <typename T, int C, int G>
+template <typename T, int C, int G, int NW>
 int launch_fwd(const WmsaDev& d, hipStream_t s) {
     using GM = WmsaGeom<T, C, G>;
-    const size_t sh = GM::bytes(C / 32);
-    if (sh > 160 * 1024) return MVLT_ERR_UNSUPPORTED;
-    auto k = wmsa_fwd_kernel<T, C, G>;
+    constexpr size_t sh = GM::bytes(C / 32);
+    static_assert(sh <= 160 * 1024, "LDS");
+    auto k = wmsa_fwd_kernel<T, C, G, NW>;
     if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(k, dim3(d.nwin), dim3(256), sh, s, d);
+    hipLaunchKernelGGL(k, dim3(d.nwin), dim3(64 * NW), sh, s, d);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }
 
-template <typename T>
-int dispatch_fwd(const WmsaDev& d, int C, hipStream_t s) {
-    constexpr bool B16 = sizeof(T) == 2;
+// experiments: MVLT_WMSA_CFG=<G><NW> (e.g. "24" = heads in pairs, 4 waves) picks another instantiation where one exists
+int cfg_override() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MVLT_WMSA_CFG"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+int dispatch_fwd_bf16(const WmsaDev& d, int C, hipStream_t s) {
+    using T = bf16_t;
+    const int o = cfg_override();
     switch (C) {
-        case 96:  return launch_fwd<T, 96, 1>(d, s);                 // 3 heads
-        case 192: return launch_fwd<T, 192, (B16 ? 2 : 1)>(d, s);
-        case 384: return launch_fwd<T, 384, (B16 ? 2 : 1)>(d, s);
-        case 128: return launch_fwd<T, 128, (B16 ? 2 : 1)>(d, s);    // Swin-B
-        case 256: return launch_fwd<T, 256, (B16 ? 2 : 1)>(d, s);
-        case 512: return launch_fwd<T, 512, (B16 ? 2 : 1)>(d, s);
+        case 96:                                                      // 3 heads
+            if (o == 14) return launch_fwd<T, 96, 1, 4>(d, s);
+            return launch_fwd<T, 96, 3, 4>(d, s);
+        case 192:                                                     // 6 heads
+            if (o == 24) return launch_fwd<T, 192, 2, 4>(d, s);
+            if (o == 34) return launch_fwd<T, 192, 3, 4>(d, s);
+            if (o == 28) return launch_fwd<T, 192, 2, 8>(d, s);
+            return launch_fwd<T, 192, 6, 8>(d, s);
+        case 384:                                                     // 12 heads
+            if (o == 24) return launch_fwd<T, 384, 2, 4>(d, s);
+            if (o == 44) return launch_fwd<T, 384, 4, 4>(d, s);
+            if (o == 28) return launch_fwd<T, 384, 2, 8>(d, s);
+            return launch_fwd<T, 384, 4, 8>(d, s);
+        case 128: return launch_fwd<T, 128, 2, 4>(d, s);              // Swin-B
+        case 256: return launch_fwd<T, 256, 2, 4>(d, s);
+        case 512: return launch_fwd<T, 512, 4, 8>(d, s);
+        default: return MVLT_ERR_UNSUPPORTED;
+    }
+}
+
+int dispatch_fwd_f32(const WmsaDev& d, int C, hipStream_t s) {
+    using T = float;
+    switch (C) {
+        case 96:  return launch_fwd<T, 96, 1, 4>(d, s);
+        case 192: return launch_fwd<T, 192, 1, 4>(d, s);
+        case 384: return launch_fwd<T, 384, 1, 4>(d, s);
+        case 128: return launch_fwd<T, 128, 1, 4>(d, s);
+        case 256: return launch_fwd<T, 256, 1, 4>(d, s);
         default: return MVLT_ERR_UNSUPPORTED;
     }
 }
@@ -363,6 +454,7 @@ int dispatch_fwd(const WmsaDev& d, int C, hipStream_t s) {
 extern "C" int mvlt_swin_wmsa_supported(int dtype, int C, int nH) {
     if (dtype != MVLT_F32 && dtype != MVLT_BF16) return 0;
     if (nH * 32 != C) return 0;
+    if (dtype == MVLT_F32 && C == 512) return 0;                   // f32 tile does not fit the LDS
     return C == 96 || C == 192 || C == 384 || C == 128 || C == 256 || C == 512;
 }
 
@@ -375,6 +467,7 @@ extern "C" int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream) {
     MVLT_CHECK((p->mean == nullptr) == (p->rstd == nullptr), MVLT_ERR_ARG);
     if (p->xn_win) MVLT_CHECK(aligned16(p->xn_win), MVLT_ERR_ARG);
     if (p->attn_out) MVLT_CHECK(aligned16(p->attn_out), MVLT_ERR_ARG);
+    if (p->qkv_win) MVLT_CHECK(aligned16(p->qkv_win), MVLT_ERR_ARG);
     if (!mvlt_swin_wmsa_supported(p->dtype, p->C, p->nH)) return MVLT_ERR_UNSUPPORTED;
     WmsaDev d{};
     d.nW = (p->res / 7) * (p->res / 7);
@@ -383,10 +476,10 @@ extern "C" int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream) {
     d.gamma = p->ln_gamma; d.beta = p->ln_beta; d.eps = p->ln_eps;
     d.wqkv = p->wqkv; d.bqkv = p->bqkv; d.wproj = p->wproj; d.bproj = p->bproj;
     d.bias_table = p->bias_table; d.scale = p->scale; d.rowscale = p->rowscale;
-    d.xn = p->xn_win; d.ao = p->attn_out; d.lse = p->lse; d.mean = p->mean; d.rstd = p->rstd;
+    d.xn = p->xn_win; d.ao = p->attn_out; d.qkv = p->qkv_win; d.lse = p->lse; d.mean = p->mean; d.rstd = p->rstd;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (p->dtype == MVLT_F32) return dispatch_fwd<float>(d, p->C, s);
-    return dispatch_fwd<bf16_t>(d, p->C, s);
+    if (p->dtype == MVLT_F32) return dispatch_fwd_f32(d, p->C, s);
+    return dispatch_fwd_bf16(d, p->C, s);
 }
 
 extern "C" int mvlt_swin_wmsa_bwd(const MvltSwinWmsa* p, void* stream) {

@@ -523,19 +523,21 @@ def _wmsa_struct(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj,
 def swin_wmsa_fwd(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj, bproj, table, scale,
                   rowscale=None, save=False):
     """y = x + rowscale * proj(window_attention(qkv(norm1(x))))  (MvltSwinWmsa): one launch.
-    save=True also returns (xn_win, attn_out, lse, mean, rstd) for the backward pass."""
+    save=True also returns (xn_win, qkv_win, attn_out, lse, mean, rstd) for the backward pass."""
     _need_cuda(x)
     p = _wmsa_struct(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj, bproj, table, scale, rowscale)
     y = torch.empty_like(x)
     p.y = y.data_ptr()
     saved = None
     if save:
-        rows = x.shape[0]
+        rows, Cn = x.shape
         xn, ao = torch.empty_like(x), torch.empty_like(x)
+        qkv = torch.empty((rows, 3 * Cn), dtype=x.dtype, device=x.device)
         lse = torch.empty((rows // 49, nH, 49), dtype=torch.float32, device=x.device)
         mean, rstd = torch.empty((2, rows), dtype=torch.float32, device=x.device).unbind(0)
         p.xn_win, p.attn_out, p.lse, p.mean, p.rstd = xn.data_ptr(), ao.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr()
-        saved = (xn, ao, lse, mean, rstd)
+        p.qkv_win = qkv.data_ptr()
+        saved = (xn, qkv, ao, lse, mean, rstd)
     L.check(L.lib().mvlt_swin_wmsa_fwd(C.byref(p), _stream()), "mvlt_swin_wmsa_fwd")
     return y, saved
 

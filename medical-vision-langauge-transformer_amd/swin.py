@@ -17,6 +17,7 @@ reverse and writes parameter gradients straight into the arena.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -101,6 +102,18 @@ class PatchEmbed(nn.Module):
         self.in_chans, self.embed_dim = in_chans, embed_dim
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
         self.norm = nn.LayerNorm(embed_dim)
+
+
+_FUSED_WMSA = os.environ.get("MVLT_FUSED_WMSA", "auto")     # "0" never, "1" wherever supported, "auto" where it wins
+
+
+def _use_fused_wmsa(dtype, C, nH, nwin):
+    """One-launch W-MSA (mvlt_swin_wmsa_fwd) or the four-launch sequence.  A workgroup owns one window, so the
+    fused kernel needs enough windows to fill the 256 CUs; measured on MI355X (scripts/bench_wmsa.py, B=32):
+    2048 / 512 windows (stages 0 / 1) fused is 2x faster, 128 windows of C=384 (stage 2) it is not."""
+    if _FUSED_WMSA == "0" or not ops.swin_wmsa_supported(dtype, C, nH):
+        return False
+    return _FUSED_WMSA == "1" or nwin >= 512 or (nwin >= 256 and C <= 256)
 
 
 class _SwinFn(torch.autograd.Function):
@@ -267,14 +280,22 @@ class SwinTransformer(nn.Module):
         nW = (H // ws) * (W // ws)
         w2n, n2w = batched_window_maps(B, H, W, ws, blk.shift_size, x.device)
         at = blk.attn
-        xn1w, mean1, rstd1, _ = ops.layernorm_fwd(x, blk.norm1.weight.data, blk.norm1.bias.data, blk.norm1.eps,
-                                                  out_rowmap=n2w, save_stats=save)
-        qkv = ops.gemm(xn1w, ar.compute(at.qkv.weight), bias=at.qkv.bias.data)
-        ao, lse = ops.attn_fwd(qkv, L.ATTN_SWIN, B * nW, ws * ws, nH, C // nH, at.scale,
-                               bias_table=at.relative_position_bias_table.data, nW=nW, win_res=H,
-                               shift=blk.shift_size)
-        x1 = ops.gemm(ao, ar.compute(at.proj.weight), bias=at.proj.bias.data, residual=x, rowmap=w2n,
-                      rowscale=(s1, Lt) if s1 is not None else None)
+        if _use_fused_wmsa(x.dtype, C, nH, B * nW):
+            # norm1 + shift/partition + qkv + window attention + proj + reverse + DropPath + residual: one launch
+            x1, fs = ops.swin_wmsa_fwd(x, w2n, B, H, nH, blk.shift_size, blk.norm1.weight.data, blk.norm1.bias.data,
+                                       blk.norm1.eps, ar.compute(at.qkv.weight), at.qkv.bias.data,
+                                       ar.compute(at.proj.weight), at.proj.bias.data,
+                                       at.relative_position_bias_table.data, at.scale, rowscale=s1, save=save)
+            xn1w, qkv, ao, lse, mean1, rstd1 = fs if save else (None,) * 6
+        else:
+            xn1w, mean1, rstd1, _ = ops.layernorm_fwd(x, blk.norm1.weight.data, blk.norm1.bias.data, blk.norm1.eps,
+                                                      out_rowmap=n2w, save_stats=save)
+            qkv = ops.gemm(xn1w, ar.compute(at.qkv.weight), bias=at.qkv.bias.data)
+            ao, lse = ops.attn_fwd(qkv, L.ATTN_SWIN, B * nW, ws * ws, nH, C // nH, at.scale,
+                                   bias_table=at.relative_position_bias_table.data, nW=nW, win_res=H,
+                                   shift=blk.shift_size)
+            x1 = ops.gemm(ao, ar.compute(at.proj.weight), bias=at.proj.bias.data, residual=x, rowmap=w2n,
+                          rowscale=(s1, Lt) if s1 is not None else None)
         xn2, mean2, rstd2, _ = ops.layernorm_fwd(x1, blk.norm2.weight.data, blk.norm2.bias.data, blk.norm2.eps,
                                                  save_stats=save)
         h = torch.empty((B * Lt, blk.mlp.fc1.out_features), dtype=x.dtype, device=x.device)

@@ -8,6 +8,15 @@ torch.manual_seed(0)
 dt = torch.bfloat16
 B = int(os.environ.get("B", 32))
 ONLY = os.environ.get("ONLY")          # "fused" -> only the fused kernels (for rocprofv3 passes)
+if os.environ.get("SWEEP"):            # one child process per kernel instantiation (MVLT_WMSA_CFG is read once)
+    import subprocess
+    for st, cfgs in ((0, ("0", "14")), (1, ("0", "24", "34", "28")), (2, ("0", "24", "44", "28"))):
+        for c in cfgs:
+            env = dict(os.environ, STAGE=str(st), MVLT_WMSA_CFG=c, ONLY="fused")
+            env.pop("SWEEP")
+            out = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True).stdout
+            print(f"cfg={c}: " + out.strip().replace("\n", f"\ncfg={c}: "), flush=True)
+    sys.exit(0)
 
 
 def timeit(f, n=20):
@@ -37,8 +46,20 @@ for st, (res, C, nH) in enumerate([(56, 96, 3), (28, 192, 6), (14, 384, 12)]):
     for shift in (0, 3):
         w2n, n2w = batched_window_maps(B, res, res, 7, shift, x.device)
         args = (x, w2n, B, res, nH, shift, g1, b1, 1e-5, wqkv, bqkv, wproj, bproj, tbl, 32 ** -0.5)
-        tf_eval = timeit(lambda: ops.swin_wmsa_fwd(*args, rowscale=rs))
-        tf_save = timeit(lambda: ops.swin_wmsa_fwd(*args, rowscale=rs, save=True))
+        # prebuilt parameter structs, bare C calls: the Python wrapper (allocations, checks) costs more than the kernel
+        import ctypes
+        lib, st_ = L.lib(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        pe = ops._wmsa_struct(*args, rs)
+        y = torch.empty_like(x); pe.y = y.data_ptr()
+        ps = ops._wmsa_struct(*args, rs)
+        ps.y = y.data_ptr()
+        xn, ao = torch.empty_like(x), torch.empty_like(x)
+        qkv_s = torch.empty((rows, 3 * C), dtype=dt, device="cuda")
+        lse_s = torch.empty((rows // 49, nH, 49), device="cuda"); ms = torch.empty((2, rows), device="cuda")
+        ps.xn_win, ps.attn_out, ps.qkv_win, ps.lse = xn.data_ptr(), ao.data_ptr(), qkv_s.data_ptr(), lse_s.data_ptr()
+        ps.mean, ps.rstd = ms[0].data_ptr(), ms[1].data_ptr()
+        tf_eval = timeit(lambda: lib.mvlt_swin_wmsa_fwd(ctypes.byref(pe), st_), n=200)
+        tf_save = timeit(lambda: lib.mvlt_swin_wmsa_fwd(ctypes.byref(ps), st_), n=200)
         line = f"s{st} res={res} C={C} shift={shift}: fused fwd {tf_eval:6.1f} us ({flop/tf_eval/1e6:6.1f} TFLOP/s), +saves {tf_save:6.1f} us"
         if ONLY != "fused":
             def unfused():

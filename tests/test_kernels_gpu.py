@@ -324,7 +324,7 @@ def test_swin_wmsa_fused_forward(ops, dt, res, C_, shift, B, dp):
     rs = torch.tensor([0.0, 1.25, 1.25][:B] if B > 1 else [1.25]).cuda() if dp else None
     scale = 32 ** -0.5
     w2n, n2w = batched_window_maps(B, res, res, 7, shift, x.device)
-    y, (xn, ao, lse, mean, rstd) = ops.swin_wmsa_fwd(x, w2n, B, res, nH, shift, g1, b1, 1e-5, wqkv, bqkv, wproj, bproj,
+    y, (xn, qkv, ao, lse, mean, rstd) = ops.swin_wmsa_fwd(x, w2n, B, res, nH, shift, g1, b1, 1e-5, wqkv, bqkv, wproj, bproj,
                                                       table, scale, rowscale=rs, save=True)
     ref, xw_ref, ao_ref = wmsa_ref(x.float(), w2n, nW, res, shift, nH, g1, b1, wqkv.float(), bqkv, wproj.float(), bproj,
                                    table, scale, rs)
@@ -340,7 +340,9 @@ def test_swin_wmsa_fused_forward(ops, dt, res, C_, shift, B, dp):
     qkv_u = ops.gemm(xn_u, wqkv, bias=bqkv)
     ao_u, lse_u = ops.attn_fwd(qkv_u, ATTN_SWIN, B * nW, 49, nH, 32, scale, bias_table=table, nW=nW, win_res=res, shift=shift)
     y_u = ops.gemm(ao_u, wproj, bias=bproj, residual=x, rowmap=w2n, rowscale=(rs, res * res) if rs is not None else None)
-    assert rel(xn, xn_u) < 1e-6 and rel(mean, mean_u) < 1e-6 and rel(rstd, rstd_u) < 1e-6
+    # same arithmetic, another summation order: a bf16 element may round the other way once in a while
+    assert rel(xn, xn_u) < (1e-6 if dt == torch.float32 else 1e-4) and rel(mean, mean_u) < 1e-5 and rel(rstd, rstd_u) < 1e-5
+    assert rel(qkv, qkv_u) < t
     assert rel(lse, lse_u) < (1e-5 if dt == torch.float32 else 2e-3)
     assert rel(ao, ao_u) < t and rel(y, y_u) < t
 
