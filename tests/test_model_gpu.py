@@ -393,7 +393,7 @@ def test_ddp_buckets_carry_final_gradients(M, specs, monkeypatch):
         model = M.MVLBertForPretraining(cfg)
         load_formula(model, specs["tiny_pretrain"])
         model = M.set_compute_dtype(model.cuda().eval(), F32)
-        red = ddp.GradReducer(model, bucket_bytes=64 << 10) if use_ddp else None
+        red = ddp.GradReducer(model, bucket_bytes=64 << 10, average=False) if use_ddp else None   # keep the fake SUM visible
         image, ids, labels, itm = synth_batch(3, 24, seed=41, vocab=3000)
         monkeypatch.setattr(random, "random", lambda: 0.9)
         for _ in range(2):       # second pass: stale values of the first one must not leak through
