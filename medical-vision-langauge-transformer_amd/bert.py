@@ -231,7 +231,20 @@ class MVLBert(nn.Module):
         mode = L.ATTN_SEQ2SEQ if seq2seq else L.ATTN_BIDIR
         akw = dict(text_ids=mask_ids, image_mask=image_mask, obj_end=n_img + 1, pack=pack)
         layers = []
-        for i, layer in enumerate(self.encoder.layer):
+        native = ops.NATIVE
+        if native:
+            # one native call per BertLayer (csrc/host.cpp bert_layer_fwd): same launches, ~4 us of host time each
+            hx, st = ops.host(), ops.stream_int()
+            attn_desc = self._attn_desc(mode, B, Lq, nH, mask_ids, T, image_mask, n_img + 1, pack)
+            sd = ops.s64(seed)
+            for i, layer in enumerate(self.encoder.layer):
+                w, f, _ = self._layer_desc(ar, layer)
+                out = hx.bert_layer_fwd(x, w, f, H, cfg.intermediate_size, layer.output.LayerNorm.eps, attn_desc,
+                                        p_h, p_a, sd, i, save, st)
+                x = out[0]
+                if save:
+                    layers.append(out[1:])
+        for i, layer in enumerate(() if native else self.encoder.layer):
             sa, so = layer.attention.self, layer.attention.output
             qkv = ops.gemm(x, ar.compute(sa.query.weight, 3 * H), bias=ar.master_span(sa.query.bias, 3 * H))
             ctx, lse = ops.attn_fwd(qkv, mode, B, Lq, nH, H // nH, (H // nH) ** -0.5,
@@ -259,8 +272,34 @@ class MVLBert(nn.Module):
         saved = None
         if save:
             saved = dict(ar=ar, layers=layers, B=B, Lq=Lq, n_img=n_img, text_idx=text_idx, akw=akw, mode=mode,
-                         seed=seed, p_h=p_h, p_a=p_a, cls=cls, pooled=pooled, pack=pack, rows=rows)
+                         seed=seed, p_h=p_h, p_a=p_a, cls=cls, pooled=pooled, pack=pack, rows=rows, native=native, T=T)
         return hidden, pooled, saved
+
+    # ---- descriptors of the native host path: raw device pointers, built once per arena
+    @staticmethod
+    def _attn_desc(mode, B, Lq, nH, mask_ids, T, image_mask, obj_end, pack):
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        return [mode, B, Lq, nH, ptr(mask_ids), T, ptr(image_mask), obj_end,
+                ptr(pack[0]) if pack is not None else 0, ptr(pack[1]) if pack is not None else 0]
+
+    def _layer_desc(self, ar, layer):
+        key = ("bert_desc", id(layer))
+        d = ar._views.get(key)
+        if d is None:
+            sa, so, li, lo = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+            H3 = 3 * self.config.hidden_size
+            c, g = ar.compute, ar.grad_view
+            w = [c(sa.query.weight, H3).data_ptr(), c(so.dense.weight).data_ptr(), c(li.dense.weight).data_ptr(),
+                 c(lo.dense.weight).data_ptr()]
+            f = [ar.master_span(sa.query.bias, H3).data_ptr(), so.dense.bias.data.data_ptr(), li.dense.bias.data.data_ptr(),
+                 lo.dense.bias.data.data_ptr(), so.LayerNorm.weight.data.data_ptr(), so.LayerNorm.bias.data.data_ptr(),
+                 lo.LayerNorm.weight.data.data_ptr(), lo.LayerNorm.bias.data.data_ptr()]
+            gr = [g(sa.query.weight, H3).data_ptr(), g(sa.query.bias, H3).data_ptr(), g(so.dense.weight).data_ptr(),
+                  g(so.dense.bias).data_ptr(), g(li.dense.weight).data_ptr(), g(li.dense.bias).data_ptr(),
+                  g(lo.dense.weight).data_ptr(), g(lo.dense.bias).data_ptr(), g(so.LayerNorm.weight).data_ptr(),
+                  g(so.LayerNorm.bias).data_ptr(), g(lo.LayerNorm.weight).data_ptr(), g(lo.LayerNorm.bias).data_ptr()]
+            d = ar._views[key] = (w, f, gr)
+        return d
 
     def _backward(self, sv, dhidden, dpooled):
         ar: Arena = sv["ar"]
@@ -289,7 +328,24 @@ class MVLBert(nn.Module):
             else:
                 dx.index_add_(0, pack[3], ops.gemm(dpre, ar.compute(pd.weight), b_kmajor=True))
             ar.mark(pd.weight, pd.bias)
-        for i in range(len(self.encoder.layer) - 1, -1, -1):
+        native = sv.get("native", False)
+        if native:
+            hx, st, side = ops.host(), ops.stream_int(), ops.side_int(dx.device)
+            akw = sv["akw"]
+            attn_desc = self._attn_desc(sv["mode"], B, Lq, nH, akw["text_ids"], sv["T"], akw["image_mask"], akw["obj_end"], pack)
+            sd = ops.s64(seed)
+            for i in range(len(self.encoder.layer) - 1, -1, -1):
+                layer = self.encoder.layer[i]
+                sa, so, lo, li = layer.attention.self, layer.attention.output, layer.output, layer.intermediate
+                w, f, gr = self._layer_desc(ar, layer)
+                dx = hx.bert_layer_bwd(dx, sv["layers"][i], w, f, gr, H, cfg.intermediate_size, attn_desc, p_h, p_a, sd, i,
+                                       st, side)
+                sv["layers"][i] = None
+                ar.mark(lo.LayerNorm.weight, lo.LayerNorm.bias, lo.dense.weight, lo.dense.bias, li.dense.weight,
+                        li.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, so.dense.weight, so.dense.bias,
+                        sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias)
+            hx.lnq_flush(st)
+        for i in range(len(self.encoder.layer) - 1, -1, -1) if not native else ():
             layer = self.encoder.layer[i]
             sa, so = layer.attention.self, layer.attention.output
             (x, qkv, ctx, lse, y1, m1, r1, x1, h, a, y2, m2, r2) = sv["layers"][i]

@@ -1,0 +1,433 @@
+// Native host path (torch C++ extension `_mvlt_host`) over the C-ABI of include/mvlt_hip.h.
+//
+// The Python modules (swin.py / bert.py) keep the parameters and decide WHAT runs; this file issues the launch
+// sequence of one SwinTransformerBlock / BertLayer forward or backward pass in ONE native call: parameter-struct
+// fills, activation allocation (torch caching allocator through ATen), the side-stream fork for the weight
+// gradients and the deferred LayerNorm parameter reductions all happen here.  One step = ~800 kernel launches;
+// through Python + ctypes each launch costs ~16 us of host time (13 ms per step), here ~4 us.
+//
+// Reference arithmetic: SwinTransformerBlock.forward (visual_feature_extractor.py:350-387), WindowAttention.forward
+// (:224-254), Mlp.forward (:135-141); HF BertLayer (modeling_bert.py:111-136,164-203,282-293,325-351).
+// torch is plumbing only: device memory and stream handles.
+#include <torch/extension.h>
+#include <hip/hip_runtime_api.h>
+#include <vector>
+#include <string>
+#include "../../include/mvlt_hip.h"
+
+namespace {
+
+using at::Tensor;
+using Ptrs = std::vector<int64_t>;
+
+inline void ck(int rc, const char* what) { TORCH_CHECK(rc == MVLT_OK, "mvlt_amd: ", what, " failed with status ", rc); }
+inline int dtype_of(const Tensor& t) {
+    if (t.scalar_type() == at::kFloat) return MVLT_F32;
+    TORCH_CHECK(t.scalar_type() == at::kBFloat16, "mvlt_amd: float32 / bfloat16 only");
+    return MVLT_BF16;
+}
+template <typename T = void> inline T* P(int64_t v) { return reinterpret_cast<T*>(v); }
+inline void* dp(const Tensor& t) { return t.data_ptr(); }
+inline float* fp(const Tensor& t) { return static_cast<float*>(t.data_ptr()); }
+inline Tensor empty2(int64_t r, int64_t c, const Tensor& like) { return at::empty({r, c}, like.options()); }
+inline Tensor emptyf(at::IntArrayRef sz, const Tensor& like) { return at::empty(sz, like.options().dtype(at::kFloat)); }
+
+// ----------------------------------------------------------------------------------------------- streams
+struct Streams { void* main = nullptr; void* side = nullptr; };
+std::vector<hipEvent_t> g_events;
+size_t g_event_next = 0;
+std::vector<Tensor> g_side_keepalive;
+
+hipEvent_t next_event() {
+    if (g_events.empty()) {
+        g_events.resize(64);
+        for (auto& e : g_events) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate");
+    }
+    hipEvent_t e = g_events[g_event_next];
+    g_event_next = (g_event_next + 1) % g_events.size();
+    return e;
+}
+// side stream waits for everything queued on the main stream so far
+void fork_side(const Streams& s) {
+    hipEvent_t e = next_event();
+    TORCH_CHECK(hipEventRecord(e, static_cast<hipStream_t>(s.main)) == hipSuccess, "hipEventRecord");
+    TORCH_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(s.side), e, 0) == hipSuccess, "hipStreamWaitEvent");
+}
+
+// ----------------------------------------------------------------------------------------------- workspaces
+struct Scratch { Tensor buf; std::vector<Tensor> retired; };
+Scratch g_ws_main, g_ws_side;
+void* workspace(Scratch& s, size_t need, const Tensor& like) {
+    if (!s.buf.defined() || (size_t)s.buf.numel() < need) {
+        if (s.buf.defined()) s.retired.push_back(s.buf);          // queued kernels may still use it
+        s.buf = at::empty({(int64_t)std::max<size_t>(need, (size_t)64 << 20)}, like.options().dtype(at::kByte));
+    }
+    return s.buf.data_ptr();
+}
+
+// ----------------------------------------------------------------------------------------------- GEMM
+struct Epi {
+    const float* bias = nullptr; bool gelu = false; void* pre = nullptr;
+    float drop_p = 0.f; uint64_t seed = 0; uint32_t tag = 0;
+    const float* rowscale = nullptr; int rps = 1;
+    const void* residual = nullptr; int64_t ldr = 0;
+    const int32_t* rowmap = nullptr; const void* aux = nullptr;
+    bool out_f32 = false, accumulate = false; float* a_colsum = nullptr;
+};
+
+void fill_gemm(MvltGemm& p, int dtype, int M, int N, int K, const void* A, int64_t lda, bool ak, const void* B, int64_t ldb,
+               bool bk, void* C, int64_t ldc, const Epi& e) {
+    p = MvltGemm{};
+    p.dtype = dtype; p.M = M; p.N = N; p.K = K;
+    p.A = A; p.lda = lda; p.a_kmajor = ak; p.B = B; p.ldb = ldb; p.b_kmajor = bk; p.C = C; p.ldc = ldc;
+    int epi = 0;
+    if (e.bias) { epi |= MVLT_EPI_BIAS; p.bias = e.bias; }
+    if (e.gelu) { epi |= MVLT_EPI_GELU; if (e.pre) { epi |= MVLT_EPI_SAVE_PRE; p.pre = e.pre; } }
+    if (e.drop_p > 0.f) { epi |= MVLT_EPI_DROPOUT; p.dropout_p = e.drop_p; p.seed = e.seed; p.tag = e.tag; }
+    if (e.rowscale) { epi |= MVLT_EPI_ROWSCALE; p.rowscale = e.rowscale; p.rows_per_scale = e.rps; }
+    if (e.residual) { epi |= MVLT_EPI_RESIDUAL; p.residual = e.residual; p.ldr = e.ldr; }
+    if (e.rowmap) { epi |= MVLT_EPI_ROWMAP; p.rowmap = e.rowmap; }
+    if (e.aux) { epi |= MVLT_EPI_MUL_GELU_GRAD; p.aux = e.aux; }
+    if (e.out_f32) epi |= MVLT_EPI_OUT_F32;
+    if (e.accumulate) epi |= MVLT_EPI_ACCUM;
+    p.epilogue = epi;
+    p.a_colsum = e.a_colsum;
+}
+
+void gemm(int dtype, int M, int N, int K, const void* A, int64_t lda, bool ak, const void* B, int64_t ldb, bool bk,
+          void* C, int64_t ldc, const Epi& e, void* stream, Scratch& ws, const Tensor& like) {
+    MvltGemm p;
+    fill_gemm(p, dtype, M, N, K, A, lda, ak, B, ldb, bk, C, ldc, e);
+    const size_t need = mvlt_gemm_workspace_bytes(&p);
+    if (need) { p.workspace = workspace(ws, need, like); p.workspace_bytes = (size_t)ws.buf.numel(); }
+    ck(mvlt_gemm(&p, stream), "mvlt_gemm");
+}
+
+// y = x W^T (+ epilogue): x [rows, K] contiguous, W [N, K]
+inline void linear(const Tensor& x, int64_t W, int N, Tensor& out, const Epi& e, void* stream) {
+    gemm(dtype_of(x), (int)x.size(0), N, (int)x.size(1), dp(x), x.size(1), false, P(W), x.size(1), false, dp(out), out.size(1),
+         e, stream, g_ws_main, x);
+}
+// dx = dy W (+ epilogue): dy [rows, N], W [N, K] read k-major
+inline void dgrad(const Tensor& dy, int64_t W, int K, Tensor& out, const Epi& e, void* stream) {
+    gemm(dtype_of(dy), (int)dy.size(0), K, (int)dy.size(1), dp(dy), dy.size(1), false, P(W), K, true, dp(out), out.size(1),
+         e, stream, g_ws_main, dy);
+}
+
+// optional timing of the grouped weight-gradient launches (bench.py roofline): HIP events on the launch stream
+struct GroupTimer { bool on = false; int every = 4, count = 0; std::vector<hipEvent_t> ev; std::vector<double> flops; size_t used = 0; };
+GroupTimer g_timer;
+
+struct WItem { const Tensor* dy; const Tensor* x; int64_t dw; int64_t db; };
+// weight gradients of one layer: dW_i = dY_i^T X_i, db_i = colsum(dY_i)  (ops.wgrad_group)
+void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws) {
+    const int n = (int)items.size();
+    bool all128 = true, all96 = true;
+    for (auto& it : items) { all128 &= it.x->size(1) % 128 == 0; all96 &= it.x->size(1) % 96 == 0; }
+    const int bn = all128 ? 128 : (all96 ? 96 : 0);
+    long tiles = 0;
+    if (bn) for (auto& it : items) tiles += ((it.dy->size(1) + 63) / 64) * ((it.x->size(1) + bn - 1) / bn);
+    const int dtype = dtype_of(*items[0].dy);
+    if (!(n > 1 && n <= 8 && bn && tiles >= 200)) {
+        for (auto& it : items) {
+            Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db);
+            gemm(dtype, (int)it.dy->size(1), (int)it.x->size(1), (int)it.dy->size(0), dp(*it.dy), it.dy->size(1), true,
+                 dp(*it.x), it.x->size(1), true, P(it.dw), it.x->size(1), e, stream, ws, *it.dy);
+        }
+        return;
+    }
+    MvltGemm arr[8];
+    double flops = 0;
+    for (int i = 0; i < n; ++i) {
+        const auto& it = items[i];
+        Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db);
+        fill_gemm(arr[i], dtype, (int)it.dy->size(1), (int)it.x->size(1), (int)it.dy->size(0), dp(*it.dy), it.dy->size(1), true,
+                  dp(*it.x), it.x->size(1), true, P(it.dw), it.x->size(1), e);
+        arr[i].split_k = 1;
+        flops += 2.0 * arr[i].M * arr[i].N * arr[i].K;
+    }
+    bool timed = false;
+    if (g_timer.on && (g_timer.count++ % g_timer.every) == 0 && g_timer.used + 2 <= g_timer.ev.size()) {
+        timed = true;
+        (void)hipEventRecord(g_timer.ev[g_timer.used], static_cast<hipStream_t>(stream));
+    }
+    ck(mvlt_gemm_group(arr, n, stream), "mvlt_gemm_group");
+    if (timed) {
+        (void)hipEventRecord(g_timer.ev[g_timer.used + 1], static_cast<hipStream_t>(stream));
+        g_timer.used += 2;
+        g_timer.flops.push_back(flops);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- LayerNorm
+void ln_fwd(const Tensor& x, int rows, int C, int64_t gamma, int64_t beta, float eps, Tensor& y, float* mean, float* rstd,
+            const int32_t* out_rowmap, void* stream) {
+    MvltLayerNorm p{};
+    p.dtype = dtype_of(x); p.rows = rows; p.C = C; p.eps = eps;
+    p.x = dp(x); p.gamma = P<float>(gamma); p.beta = P<float>(beta); p.y = dp(y);
+    p.mean = mean; p.rstd = rstd; p.out_rowmap = out_rowmap;
+    ck(mvlt_layernorm_fwd(&p, stream), "mvlt_layernorm_fwd");
+}
+
+// deferred dgamma/dbeta reductions of one backward pass (ops.LnReduceQueue)
+struct LnQueue {
+    Tensor pool; std::vector<Tensor> retired; int64_t off = 0;
+    std::vector<MvltLnReduceItem> items;
+    float* take(int64_t nfloats, const Tensor& like) {
+        if (!pool.defined() || pool.numel() < off + nfloats) {
+            if (pool.defined()) retired.push_back(pool);
+            pool = at::empty({std::max<int64_t>(off + nfloats, (int64_t)48 << 20)}, like.options().dtype(at::kFloat));
+            off = 0;
+        }
+        float* w = fp(pool) + off;
+        off += nfloats;
+        return w;
+    }
+    void flush(void* stream) {
+        if (items.empty()) { off = 0; return; }
+        ck(mvlt_layernorm_param_reduce_batch(items.data(), (int)items.size(), stream), "mvlt_layernorm_param_reduce_batch");
+        items.clear(); off = 0; retired.clear();
+    }
+};
+LnQueue g_lnq;
+
+struct LnBranch { void* dz = nullptr; const int32_t* rowmap = nullptr; const float* rowscale = nullptr; int rps = 1;
+                  float drop_p = 0.f; uint64_t seed = 0; uint32_t tag = 0; };
+void ln_bwd(const Tensor& dy, const int32_t* dy_rowmap, const Tensor& x, const float* mean, const float* rstd, int rows, int C,
+            int64_t gamma, int64_t dgamma, int64_t dbeta, const void* dres, Tensor& dx, const LnBranch& br, void* stream) {
+    static const int ws_rows = mvlt_layernorm_bwd_workspace_rows();
+    MvltLayerNormBwd p{};
+    p.dtype = dtype_of(x); p.rows = rows; p.C = C;
+    p.dy = dp(dy); p.dy_rowmap = dy_rowmap; p.x = dp(x); p.mean = mean; p.rstd = rstd; p.gamma = P<float>(gamma);
+    p.dres = dres; p.dx = dp(dx);
+    p.dgamma = P<float>(dgamma); p.dbeta = P<float>(dbeta);
+    float* ws = g_lnq.take((int64_t)2 * ws_rows * C, x);
+    p.workspace = ws; p.defer_param_reduce = 1;
+    g_lnq.items.push_back(MvltLnReduceItem{ws, mvlt_layernorm_bwd_nparts(rows, C), C, p.dgamma, p.dbeta});
+    if (br.dz) {
+        p.dz = br.dz; p.dz_rowmap = br.rowmap; p.dz_rowscale = br.rowscale; p.dz_rows_per_scale = br.rps;
+        p.dz_dropout_p = br.drop_p; p.seed = br.seed; p.tag = br.tag;
+    }
+    ck(mvlt_layernorm_bwd(&p, stream), "mvlt_layernorm_bwd");
+}
+
+// ----------------------------------------------------------------------------------------------- BERT layer
+// w: compute-dtype weights [wqkv, wo, wi, wo2]; f: f32 [bqkv, bo, bi, bo2, g1, b1, g2, b2];
+// g: f32 gradients [dwqkv, dbqkv, dwo, dbo, dwi, dbi, dwo2, dbo2, dg1, db1, dg2, db2]
+struct AttnArgs { int mode, B, Lq, nH; int64_t text_ids; int T; int64_t image_mask; int obj_end; int64_t row_start, seq_len; };
+
+void fill_attn(MvltAttn& p, const Tensor& qkv, const AttnArgs& a, int H, void* out, float* lse, float drop_p, uint64_t seed, uint32_t tag) {
+    p = MvltAttn{};
+    p.dtype = dtype_of(qkv); p.mode = a.mode; p.nseq = a.B; p.L = a.Lq; p.nH = a.nH; p.hd = H / a.nH;
+    p.qkv = dp(qkv); p.out = out; p.lse = lse; p.scale = 1.0f / std::sqrt((float)p.hd);
+    p.text_ids = P<const int64_t>(a.text_ids); p.T = a.T; p.image_mask = P<const uint8_t>(a.image_mask); p.obj_end = a.obj_end;
+    p.row_start = P<const int32_t>(a.row_start); p.seq_len = P<const int32_t>(a.seq_len);
+    if (drop_p > 0.f) { p.dropout_p = drop_p; p.seed = seed; p.tag = tag; }
+}
+
+std::vector<Tensor> bert_layer_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f, int64_t H, int64_t I, double eps,
+                                   const Ptrs& attn, double p_h, double p_a, int64_t seed, int64_t layer, bool save,
+                                   int64_t stream_) {
+    void* st = P(stream_);
+    const int64_t rows = x.size(0);
+    AttnArgs a{(int)attn[0], (int)attn[1], (int)attn[2], (int)attn[3], attn[4], (int)attn[5], attn[6], (int)attn[7], attn[8], attn[9]};
+    const uint64_t sd = (uint64_t)seed;
+    Tensor qkv = empty2(rows, 3 * H, x);
+    { Epi e; e.bias = P<float>(f[0]); linear(x, w[0], (int)(3 * H), qkv, e, st); }
+    Tensor ctx = empty2(rows, H, x);
+    Tensor lse = emptyf({a.B, a.nH, a.Lq}, x);
+    { MvltAttn p; fill_attn(p, qkv, a, (int)H, dp(ctx), fp(lse), (float)p_a, sd, (uint32_t)(8 * layer + 0));
+      ck(mvlt_attn_fwd(&p, st), "mvlt_attn_fwd"); }
+    Tensor y1 = empty2(rows, H, x);
+    { Epi e; e.bias = P<float>(f[1]); e.drop_p = (float)p_h; e.seed = sd; e.tag = (uint32_t)(8 * layer + 1);
+      e.residual = dp(x); e.ldr = H; linear(ctx, w[1], (int)H, y1, e, st); }
+    Tensor x1 = empty2(rows, H, x), st1, st2;
+    float *m1 = nullptr, *r1 = nullptr, *m2 = nullptr, *r2 = nullptr;
+    if (save) { st1 = emptyf({2, rows}, x); m1 = fp(st1); r1 = m1 + rows; st2 = emptyf({2, rows}, x); m2 = fp(st2); r2 = m2 + rows; }
+    ln_fwd(y1, (int)rows, (int)H, f[4], f[5], (float)eps, x1, m1, r1, nullptr, st);
+    Tensor h = empty2(rows, I, x), act = empty2(rows, I, x);
+    { Epi e; e.bias = P<float>(f[2]); e.gelu = true; e.pre = dp(h); linear(x1, w[2], (int)I, act, e, st); }
+    Tensor y2 = empty2(rows, H, x);
+    { Epi e; e.bias = P<float>(f[3]); e.drop_p = (float)p_h; e.seed = sd; e.tag = (uint32_t)(8 * layer + 2);
+      e.residual = dp(x1); e.ldr = H; linear(act, w[3], (int)H, y2, e, st); }
+    Tensor x2 = empty2(rows, H, x);
+    ln_fwd(y2, (int)rows, (int)H, f[6], f[7], (float)eps, x2, m2, r2, nullptr, st);
+    if (!save) return {x2};
+    return {x2, x, qkv, ctx, lse, y1, st1, x1, h, act, y2, st2};
+}
+
+// saved = [x, qkv, ctx, lse, y1, st1, x1, h, act, y2, st2] (bert_layer_fwd output 1..)
+Tensor bert_layer_bwd(const Tensor& dx, const std::vector<Tensor>& sv, const Ptrs& w, const Ptrs& f, const Ptrs& g, int64_t H,
+                      int64_t I, const Ptrs& attn, double p_h, double p_a, int64_t seed, int64_t layer, int64_t stream_,
+                      int64_t side_) {
+    Streams ss{P(stream_), P(side_)};
+    void* st = ss.main;
+    const Tensor &x = sv[0], &qkv = sv[1], &ctx = sv[2], &lse = sv[3], &y1 = sv[4], &st1 = sv[5], &x1 = sv[6], &h = sv[7],
+                 &act = sv[8], &y2 = sv[9], &st2 = sv[10];
+    const int64_t rows = x.size(0);
+    AttnArgs a{(int)attn[0], (int)attn[1], (int)attn[2], (int)attn[3], attn[4], (int)attn[5], attn[6], (int)attn[7], attn[8], attn[9]};
+    const uint64_t sd = (uint64_t)seed;
+    // LN2 backward: dy2 = gradient of y2 (also the residual branch into x1); dz2 = hidden-dropout backward of it
+    Tensor dy2 = empty2(rows, H, x), dz2 = dy2;
+    { LnBranch br; if (p_h > 0) { dz2 = empty2(rows, H, x); br.dz = dp(dz2); br.drop_p = (float)p_h; br.seed = sd; br.tag = (uint32_t)(8 * layer + 2); }
+      ln_bwd(dx, nullptr, y2, fp(st2), fp(st2) + rows, (int)rows, (int)H, f[6], g[10], g[11], nullptr, dy2, br, st); }
+    Tensor dh = empty2(rows, I, x);
+    { Epi e; e.aux = dp(h); dgrad(dz2, w[3], (int)I, dh, e, st); }
+    Tensor dx1 = empty2(rows, H, x);
+    { Epi e; e.residual = dp(dy2); e.ldr = H; dgrad(dh, w[2], (int)H, dx1, e, st); }
+    Tensor dy1 = empty2(rows, H, x), dz1 = dy1;
+    { LnBranch br; if (p_h > 0) { dz1 = empty2(rows, H, x); br.dz = dp(dz1); br.drop_p = (float)p_h; br.seed = sd; br.tag = (uint32_t)(8 * layer + 1); }
+      ln_bwd(dx1, nullptr, y1, fp(st1), fp(st1) + rows, (int)rows, (int)H, f[4], g[8], g[9], nullptr, dy1, br, st); }
+    Tensor dctx = empty2(rows, H, x);
+    { Epi e; dgrad(dz1, w[1], (int)H, dctx, e, st); }
+    Tensor dqkv = empty2(rows, 3 * H, x);
+    { MvltAttn p; fill_attn(p, qkv, a, (int)H, dp(ctx), fp(lse), (float)p_a, sd, (uint32_t)(8 * layer + 0));
+      Tensor delta = at::empty_like(lse);
+      p.dout = dp(dctx); p.dqkv = dp(dqkv); p.delta_ws = fp(delta);
+      ck(mvlt_attn_bwd(&p, st), "mvlt_attn_bwd"); }
+    Tensor dxin = empty2(rows, H, x);
+    { Epi e; e.residual = dp(dy1); e.ldr = H; dgrad(dqkv, w[0], (int)H, dxin, e, st); }
+    // weight / bias gradients on the side stream (off the critical path)
+    fork_side(ss);
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&dz2, &act, &dh, &x1, &dz1, &ctx, &dqkv, &x}) g_side_keepalive.push_back(*t);
+    wgrad_group({{&dz2, &act, g[6], g[7]}, {&dh, &x1, g[4], g[5]}, {&dz1, &ctx, g[2], g[3]}, {&dqkv, &x, g[0], g[1]}},
+                ss.side, g_ws_side);
+    return dxin;
+}
+
+// ----------------------------------------------------------------------------------------------- Swin block
+// w: compute-dtype weights [wqkv, wproj, wfc1, wfc2]; f: f32 [n1g, n1b, bqkv, bproj, table, n2g, n2b, bfc1, bfc2];
+// g: f32 gradients [dn1g, dn1b, dwqkv, dbqkv, dwproj, dbproj, dtable, dn2g, dn2b, dwfc1, dbfc1, dwfc2, dbfc2]
+// geo: [B, H(res), C, nH, shift, fused]; maps: [w2n, n2w] int32 device pointers; s1/s2: DropPath scales f32 [B] or 0
+std::vector<Tensor> swin_block_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f, const Ptrs& geo, const Ptrs& maps, double scale,
+                                   double eps, int64_t s1, int64_t s2, bool save, int64_t stream_) {
+    void* st = P(stream_);
+    const int B = (int)geo[0], res = (int)geo[1], C = (int)geo[2], nH = (int)geo[3], shift = (int)geo[4];
+    const bool fused = geo[5] != 0;
+    const int64_t rows = x.size(0);
+    const int Lt = res * res, nW = (res / 7) * (res / 7);
+    const int dtype = dtype_of(x);
+    Tensor xn1w, qkv, ao, lse, stat1, x1 = empty2(rows, C, x);
+    float *m1 = nullptr, *r1 = nullptr;
+    if (save) { stat1 = emptyf({2, rows}, x); m1 = fp(stat1); r1 = m1 + rows; }
+    if (fused) {
+        MvltSwinWmsa p{};
+        p.dtype = dtype; p.B = B; p.res = res; p.C = C; p.nH = nH; p.shift = shift;
+        p.x = dp(x); p.y = dp(x1); p.w2n = P<const int32_t>(maps[0]);
+        p.ln_gamma = P<float>(f[0]); p.ln_beta = P<float>(f[1]); p.ln_eps = (float)eps;
+        p.wqkv = P(w[0]); p.bqkv = P<float>(f[2]); p.wproj = P(w[1]); p.bproj = P<float>(f[3]);
+        p.bias_table = P<float>(f[4]); p.scale = (float)scale; p.rowscale = P<float>(s1);
+        if (save) {
+            xn1w = empty2(rows, C, x); qkv = empty2(rows, 3 * C, x); ao = empty2(rows, C, x); lse = emptyf({rows / 49, nH, 49}, x);
+            p.xn_win = dp(xn1w); p.qkv_win = dp(qkv); p.attn_out = dp(ao); p.lse = fp(lse); p.mean = m1; p.rstd = r1;
+        }
+        ck(mvlt_swin_wmsa_fwd(&p, st), "mvlt_swin_wmsa_fwd");
+    } else {
+        xn1w = empty2(rows, C, x);
+        ln_fwd(x, (int)rows, C, f[0], f[1], (float)eps, xn1w, m1, r1, P<const int32_t>(maps[1]), st);
+        qkv = empty2(rows, 3 * C, x);
+        { Epi e; e.bias = P<float>(f[2]); linear(xn1w, w[0], 3 * C, qkv, e, st); }
+        ao = empty2(rows, C, x); lse = emptyf({rows / 49, nH, 49}, x);
+        { MvltAttn p{}; p.dtype = dtype; p.mode = MVLT_ATTN_SWIN; p.nseq = B * nW; p.L = 49; p.nH = nH; p.hd = C / nH;
+          p.qkv = dp(qkv); p.out = dp(ao); p.lse = fp(lse); p.scale = (float)scale;
+          p.bias_table = P<float>(f[4]); p.nW = nW; p.win_res = res; p.shift = shift;
+          ck(mvlt_attn_fwd(&p, st), "mvlt_attn_fwd"); }
+        { Epi e; e.bias = P<float>(f[3]); e.residual = dp(x); e.ldr = C; e.rowmap = P<const int32_t>(maps[0]);
+          if (s1) { e.rowscale = P<float>(s1); e.rps = Lt; }
+          linear(ao, w[1], C, x1, e, st); }
+    }
+    Tensor xn2 = empty2(rows, C, x), stat2;
+    float *m2 = nullptr, *r2 = nullptr;
+    if (save) { stat2 = emptyf({2, rows}, x); m2 = fp(stat2); r2 = m2 + rows; }
+    ln_fwd(x1, (int)rows, C, f[5], f[6], (float)eps, xn2, m2, r2, nullptr, st);
+    Tensor h = empty2(rows, 4 * C, x), act = empty2(rows, 4 * C, x);
+    { Epi e; e.bias = P<float>(f[7]); e.gelu = true; e.pre = dp(h); linear(xn2, w[2], 4 * C, act, e, st); }
+    Tensor x2 = empty2(rows, C, x);
+    { Epi e; e.bias = P<float>(f[8]); e.residual = dp(x1); e.ldr = C; if (s2) { e.rowscale = P<float>(s2); e.rps = Lt; }
+      linear(act, w[3], C, x2, e, st); }
+    if (!save) return {x2};
+    return {x2, x, stat1, xn1w, qkv, ao, lse, x1, stat2, xn2, h, act};
+}
+
+// sv = [x, stat1, xn1w, qkv, ao, lse, x1, stat2, xn2, h, act]
+Tensor swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>& sv, const Ptrs& w, const Ptrs& f, const Ptrs& g, const Ptrs& geo,
+                      const Ptrs& maps, double scale, int64_t s1, int64_t s2, int64_t stream_, int64_t side_) {
+    Streams ss{P(stream_), P(side_)};
+    void* st = ss.main;
+    const Tensor &x = sv[0], &stat1 = sv[1], &xn1w = sv[2], &qkv = sv[3], &ao = sv[4], &lse = sv[5], &x1 = sv[6], &stat2 = sv[7],
+                 &xn2 = sv[8], &h = sv[9], &act = sv[10];
+    const int B = (int)geo[0], res = (int)geo[1], C = (int)geo[2], nH = (int)geo[3], shift = (int)geo[4];
+    const int64_t rows = x.size(0);
+    const int Lt = res * res, nW = (res / 7) * (res / 7);
+    const int dtype = dtype_of(x);
+    const int32_t* w2n = P<const int32_t>(maps[0]); const int32_t* n2w = P<const int32_t>(maps[1]);
+    (void)w2n;
+    Tensor dy2 = dx2;
+    if (s2) {
+        dy2 = empty2(rows, C, x);
+        ck(mvlt_rows_transform(dtype, dp(dx2), dp(dy2), (int)rows, C, nullptr, P<float>(s2), Lt, 0.f, 0, 0, st), "mvlt_rows_transform");
+    }
+    Tensor dh = empty2(rows, 4 * C, x);
+    { Epi e; e.aux = dp(h); dgrad(dy2, w[3], 4 * C, dh, e, st); }
+    Tensor dxn2 = empty2(rows, C, x);
+    { Epi e; dgrad(dh, w[2], C, dxn2, e, st); }
+    Tensor dx1 = empty2(rows, C, x), dyw = empty2(rows, C, x);
+    { LnBranch br; br.dz = dp(dyw); br.rowmap = n2w; if (s1) { br.rowscale = P<float>(s1); br.rps = Lt; }
+      ln_bwd(dxn2, nullptr, x1, fp(stat2), fp(stat2) + rows, (int)rows, C, f[5], g[7], g[8], dp(dx2), dx1, br, st); }
+    Tensor dao = empty2(rows, C, x);
+    { Epi e; dgrad(dyw, w[1], C, dao, e, st); }
+    Tensor dqkv = empty2(rows, 3 * C, x);
+    { MvltAttn p{}; p.dtype = dtype; p.mode = MVLT_ATTN_SWIN; p.nseq = B * nW; p.L = 49; p.nH = nH; p.hd = C / nH;
+      p.qkv = dp(qkv); p.out = dp(ao); p.lse = fp(lse); p.scale = (float)scale;
+      p.bias_table = P<float>(f[4]); p.nW = nW; p.win_res = res; p.shift = shift;
+      p.dout = dp(dao); p.dqkv = dp(dqkv); p.dbias_table = P<float>(g[6]);
+      ck(mvlt_attn_bwd(&p, st), "mvlt_attn_bwd"); }
+    Tensor dxn1w = empty2(rows, C, x);
+    { Epi e; dgrad(dqkv, w[0], C, dxn1w, e, st); }
+    Tensor dx0 = empty2(rows, C, x);
+    { LnBranch br; ln_bwd(dxn1w, n2w, x, fp(stat1), fp(stat1) + rows, (int)rows, C, f[0], g[0], g[1], dp(dx1), dx0, br, st); }
+    fork_side(ss);
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&dy2, &act, &dh, &xn2, &dyw, &ao, &dqkv, &xn1w}) g_side_keepalive.push_back(*t);
+    wgrad_group({{&dy2, &act, g[11], g[12]}, {&dh, &xn2, g[9], g[10]}, {&dyw, &ao, g[4], g[5]}, {&dqkv, &xn1w, g[2], g[3]}},
+                ss.side, g_ws_side);
+    return dx0;
+}
+
+// ----------------------------------------------------------------------------------------------- housekeeping
+void lnq_flush(int64_t stream) { g_lnq.flush(P(stream)); }
+int64_t lnq_pending() { return (int64_t)g_lnq.items.size(); }
+void side_release() { g_side_keepalive.clear(); g_ws_side.retired.clear(); g_ws_main.retired.clear(); }
+
+void timer_begin(int64_t every, int64_t capacity) {
+    for (auto e : g_timer.ev) (void)hipEventDestroy(e);
+    g_timer = GroupTimer{};
+    g_timer.on = true; g_timer.every = (int)std::max<int64_t>(1, every);
+    g_timer.ev.resize((size_t)capacity * 2);
+    for (auto& e : g_timer.ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate");
+}
+// -> [(flops, milliseconds)] of the sampled grouped launches; call after a device synchronize
+std::vector<std::pair<double, double>> timer_collect() {
+    std::vector<std::pair<double, double>> out;
+    for (size_t i = 0; i + 1 < g_timer.used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_timer.ev[i], g_timer.ev[i + 1]) == hipSuccess) out.emplace_back(g_timer.flops[i / 2], (double)ms);
+    }
+    g_timer.on = false;
+    return out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "mvlt_amd native host path: per-layer launch sequences over the C-ABI of include/mvlt_hip.h";
+    m.def("bert_layer_fwd", &bert_layer_fwd);
+    m.def("bert_layer_bwd", &bert_layer_bwd);
+    m.def("swin_block_fwd", &swin_block_fwd);
+    m.def("swin_block_bwd", &swin_block_bwd);
+    m.def("lnq_flush", &lnq_flush);
+    m.def("lnq_pending", &lnq_pending);
+    m.def("side_release", &side_release);
+    m.def("timer_begin", &timer_begin);
+    m.def("timer_collect", &timer_collect);
+    m.def("abi_version", []() { return mvlt_version(); });
+}

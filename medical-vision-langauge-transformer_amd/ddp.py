@@ -141,7 +141,10 @@ class GradReducer:
         self.handles += hs
         self.launched += ranges
         if self.on_bucket is not None and ranges:
-            self.on_bucket(arena, ranges, hs)
+            # a backend without an AVG reduction (gloo) is rescaled in _finish, AFTER this consumer has used the
+            # bucket: tell it the factor that is still owed
+            owed = 1.0 / self.world if (self.average and not self._avg_op and self.world > 1) else 1.0
+            self.on_bucket(arena, ranges, hs, owed)
 
     def _finish(self, arena: Arena) -> None:
         # everything not yet communicated, including parameters whose gradient

@@ -5,6 +5,7 @@ stream and dtype bookkeeping.  Every function launches hand-written gfx950
 kernels on torch's current stream; nothing falls back to eager torch math.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -17,6 +18,44 @@ GEMM_TIMER = None   # bench.py: callable(flops, key) -> (start_event, end_event)
 
 
 _stream_cache = [None, None]
+
+# ----------------------------------------------------------------------------- native host path (csrc/host.cpp)
+# One native call per SwinTransformerBlock / BertLayer forward or backward pass (torch C++ extension over the same
+# C-ABI).  MVLT_NATIVE_HOST=0 keeps every launch on the Python + ctypes path below (same kernels, same results).
+NATIVE = os.environ.get("MVLT_NATIVE_HOST", "1") != "0"
+_host = None
+
+
+def host():
+    global _host
+    if _host is None:
+        import importlib.util
+        L.lib()                                   # same libmvlt_hip.so the extension binds by rpath
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_mvlt_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C medical-vision-langauge-transformer_amd/csrc` "
+                               "(python __graft_entry__.py); there is no fallback")
+        spec = importlib.util.spec_from_file_location("_mvlt_host", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if mod.abi_version() != L.lib().mvlt_version():
+            raise RuntimeError("_mvlt_host.so and libmvlt_hip.so disagree on the ABI version: rebuild both")
+        _host = mod
+    return _host
+
+
+def stream_int():
+    """Handle of the stream the current pass launches on, as a plain int (0 = the null stream)."""
+    return int(_stream().value or 0)
+
+
+def side_int(device):
+    return int(side_stream(device).cuda_stream)
+
+
+def s64(v):
+    """64-bit unsigned seed -> the int64 the extension takes (two's complement, cast back in C++)."""
+    return v - (1 << 64) if v >= (1 << 63) else v
 
 
 def _stream():
@@ -92,6 +131,8 @@ def join_side(device):
     if st is not None:
         torch.cuda.current_stream().wait_stream(st)
     _side_keepalive.clear()
+    if _host is not None:
+        _host.side_release()
 
 
 class pin_stream:
@@ -420,6 +461,8 @@ class LnReduceQueue:
         """Write every pending dgamma/dbeta now: a gradient bucket is about to be communicated."""
         for q in list(LnReduceQueue._active):
             q.flush()
+        if _host is not None and _host.lnq_pending():
+            _host.lnq_flush(stream_int())
 
     def take(self, nfloats, device):
         pool = LnReduceQueue._pool.get(device.index)

@@ -98,7 +98,7 @@ class FusedAdamW:
             ar.steps[id(p)] = int(st["step"])
 
     # ------------------------------------------------------------------ update of a set of element ranges
-    def _apply(self, ar: Arena, params) -> None:
+    def _apply(self, ar: Arena, params, extra_scale: float = 1.0) -> None:
         """AdamW over ``params`` (arena order): one launch per contiguous run with equal step count."""
         b1, b2 = self.betas
         run = None
@@ -116,7 +116,7 @@ class FusedAdamW:
         for lo, hi, st in runs:
             ops.adamw(ar.flat[lo:hi], ar.grad[lo:hi], ar.exp_avg[lo:hi], ar.exp_avg_sq[lo:hi],
                       ar.shadow[lo:hi] if ar.shadow is not None else None,
-                      self.lr, b1, b2, self.eps, self.weight_decay, st + 1, self.grad_scale)
+                      self.lr, b1, b2, self.eps, self.weight_decay, st + 1, self.grad_scale * extra_scale)
 
     # ------------------------------------------------------------------ overlap with the backward pass
     def overlap_with_backward(self, reducer=None, chunk_bytes: int = 64 << 20) -> "FusedAdamW":
@@ -158,7 +158,7 @@ class FusedAdamW:
             self._apply(ar, params)
         self._stepped.update(id(p) for p in params)
 
-    def _on_bucket(self, ar: Arena, ranges, handles) -> None:
+    def _on_bucket(self, ar: Arena, ranges, handles, owed_scale: float = 1.0) -> None:
         # DDP: the bucket's all-reduce has been issued; the update waits for it on the optimizer stream
         params = [p for a, b in ranges for p in ar.params_between(a, b)
                   if ar.has_grad[id(p)] and id(p) not in self._stepped]
@@ -170,7 +170,7 @@ class FusedAdamW:
             for h in handles:
                 h.wait()
         with ops.on_stream(st, "opt"):
-            self._apply(ar, params)
+            self._apply(ar, params, owed_scale)
         self._stepped.update(id(p) for p in params)
 
     # ------------------------------------------------------------------ the torch.optim-style entry point

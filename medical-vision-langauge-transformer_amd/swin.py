@@ -280,6 +280,14 @@ class SwinTransformer(nn.Module):
         nW = (H // ws) * (W // ws)
         w2n, n2w = batched_window_maps(B, H, W, ws, blk.shift_size, x.device)
         at = blk.attn
+        if ops.NATIVE:
+            # one native call per block (csrc/host.cpp swin_block_fwd)
+            w, f, _ = self._block_desc(ar, blk)
+            geo = [B, H, C, nH, blk.shift_size, int(_use_fused_wmsa(x.dtype, C, nH, B * nW))]
+            out = ops.host().swin_block_fwd(x, w, f, geo, [w2n.data_ptr(), n2w.data_ptr()], at.scale, blk.norm1.eps,
+                                            0 if s1 is None else s1.data_ptr(), 0 if s2 is None else s2.data_ptr(),
+                                            save, ops.stream_int())
+            return out[0], ((blk, out[1:], s1, s2, H, W) if save else None)
         if _use_fused_wmsa(x.dtype, C, nH, B * nW):
             # norm1 + shift/partition + qkv + window attention + proj + reverse + DropPath + residual: one launch
             x1, fs = ops.swin_wmsa_fwd(x, w2n, B, H, nH, blk.shift_size, blk.norm1.weight.data, blk.norm1.bias.data,
@@ -338,12 +346,46 @@ class SwinTransformer(nn.Module):
         pe = self.patch_embed
         dx0 = ops.layernorm_bwd(dx, x0, mean, rstd, pe.norm.weight.data, g(pe.norm.weight), g(pe.norm.bias), defer=lnq)
         lnq.flush()
+        if ops.NATIVE:
+            ops.host().lnq_flush(ops.stream_int())
         ops.gemm(dx0, cols, a_kmajor=True, b_kmajor=True, out=g(pe.proj.weight), out_f32=True,
                  a_colsum=g(pe.proj.bias))
         ops.join_side(dx0.device)                # all weight gradients are complete before anyone reads them
         ar.mark(pe.norm.weight, pe.norm.bias, pe.proj.weight, pe.proj.bias)
 
+    def _block_desc(self, ar, blk):
+        """Raw device pointers of one block for the native host path, built once per arena."""
+        key = ("swin_desc", id(blk))
+        d = ar._views.get(key)
+        if d is None:
+            at, mlp = blk.attn, blk.mlp
+            c, g = ar.compute, ar.grad_view
+            dd = lambda p: p.data.data_ptr()
+            w = [c(at.qkv.weight).data_ptr(), c(at.proj.weight).data_ptr(), c(mlp.fc1.weight).data_ptr(), c(mlp.fc2.weight).data_ptr()]
+            f = [dd(blk.norm1.weight), dd(blk.norm1.bias), dd(at.qkv.bias), dd(at.proj.bias), dd(at.relative_position_bias_table),
+                 dd(blk.norm2.weight), dd(blk.norm2.bias), dd(mlp.fc1.bias), dd(mlp.fc2.bias)]
+            gr = [g(p).data_ptr() for p in (blk.norm1.weight, blk.norm1.bias, at.qkv.weight, at.qkv.bias, at.proj.weight,
+                                            at.proj.bias, at.relative_position_bias_table, blk.norm2.weight, blk.norm2.bias,
+                                            mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias)]
+            d = ar._views[key] = (w, f, gr)
+        return d
+
+    def _block_bwd_native(self, ar, sv, dx2, B):
+        blk, saved, s1, s2, H, W = sv
+        w2n, n2w = batched_window_maps(B, H, W, blk.window_size, blk.shift_size, dx2.device)
+        w, f, gr = self._block_desc(ar, blk)
+        at, mlp = blk.attn, blk.mlp
+        dx0 = ops.host().swin_block_bwd(dx2, saved, w, f, gr, [B, H, blk.dim, blk.num_heads, blk.shift_size, 0],
+                                        [w2n.data_ptr(), n2w.data_ptr()], at.scale, 0 if s1 is None else s1.data_ptr(),
+                                        0 if s2 is None else s2.data_ptr(), ops.stream_int(), ops.side_int(dx2.device))
+        ar.mark(mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, blk.norm1.weight, blk.norm1.bias,
+                blk.norm2.weight, blk.norm2.bias, at.qkv.weight, at.qkv.bias, at.proj.weight, at.proj.bias,
+                at.relative_position_bias_table)
+        return dx0
+
     def _block_bwd(self, ar, sv, dx2, B):
+        if len(sv) == 6:
+            return self._block_bwd_native(ar, sv, dx2, B)
         (blk, x, mean1, rstd1, xn1w, qkv, ao, lse, x1, mean2, rstd2, xn2, h, a, s1, s2, H, W) = sv
         g = ar.grad_view
         C, nH, ws = blk.dim, blk.num_heads, blk.window_size
