@@ -140,7 +140,7 @@ def self_launch(args):
     raise SystemExit(r.returncode)
 
 
-def packed_gflop_per_pair(batch):
+def packed_gflop_per_pair(batch, all_mlm_rows=False):
     """FLOPs actually executed per pair by the packed-rows / labelled-rows variant (SURVEY 8d formulas with the
     BERT rows sum(51 + len_b) instead of B*131 and the MLM head on 10 rows per sample instead of 80)."""
     lens = batch[4].float() + 51.0
@@ -149,7 +149,7 @@ def packed_gflop_per_pair(batch):
     bert_dense = 12 * (L * (4 * 768 ** 2 + 2 * 768 * 3072) + 2 * L * L * 768)
     bert_packed = float(sum(12 * (l * (4 * 768 ** 2 + 2 * 768 * 3072) + 2 * l * l * 768) for l in lens.tolist())) / B
     head_all = SEQ * (768 ** 2 + 768 * 30522)
-    head_lab = 10 * (768 ** 2 + 768 * 30522)
+    head_lab = (SEQ if all_mlm_rows else 10) * (768 ** 2 + 768 * 30522)
     fwd_ref = GFLOP_PER_PAIR / 3 / 2 * 1e9           # MACs of the reference-equivalent forward
     fwd = fwd_ref - bert_dense + bert_packed - head_all + head_lab
     return fwd * 2 * 3 / 1e9
@@ -249,7 +249,22 @@ def main():
         native_samples = ops.host().timer_collect()          # [(flops, ms)] -- the stream is idle: timed_run synchronised
     loss_value = float(loss.item())
 
-    # EXTRA (opt-in API, not reachable from the reference's unchanged caller): packed BERT rows via the added
+    # EXTRA 1: the same call with config.auto_pack_rows = False -- every zero-padded caption row is computed, i.e.
+    # exactly the reference's work (the default plans the packing on the device from the ids themselves)
+    dense = None
+    if not args.no_extra:
+        cfg.auto_pack_rows = False
+        for _ in range(max(2, args.warmup // 2)):
+            step(batch)
+        e1, l1 = timed_run(step, batch, args.steps, use_dist, dist)
+        dense = {"value_dense_rows": round(PER_GPU_BATCH * world * args.steps / e1, 2),
+                 "ms_per_step_dense_rows": round(1e3 * e1 / args.steps, 3),
+                 "dense_rows_variant": "config.auto_pack_rows=False: every zero-padded caption row computed like the "
+                                       "reference (reference-equivalent 132.7 GFLOP/pair executed)",
+                 "dense_rows_step_tflops_per_gpu": round(PER_GPU_BATCH * args.steps / e1 * GFLOP_PER_PAIR / 1e3, 2),
+                 "dense_rows_loss": round(float(l1.item()), 4)}
+        cfg.auto_pack_rows = True
+    # EXTRA 2 (opt-in API, not reachable from the reference's unchanged caller): packed BERT rows via the added
     # text_lengths= argument + MLM head on the labelled rows only (config.mlm_max_labels_per_sample = 10)
     extra = None
     if not args.no_extra:
@@ -296,15 +311,23 @@ def main():
                                       "reference call signature model(image, caption_masked, caption_label, ITM_label)",
                           "global_batch": PER_GPU_BATCH * world, "seq_len": SEQ, "parallelism": f"dp{world}",
                           "mlm_head_rows": "all (80 per sample, as the reference)",
-                          "bert_rows": "dense (padded caption rows computed, as the reference)",
+                          "bert_rows": "module default: packing plan computed on the device from the ids/labels (no new "
+                                       "argument, no host sync); the zero-padded caption tails are not materialised, "
+                                       "loss and gradients equal the dense run (tests/test_model_gpu.py::"
+                                       "test_device_planned_packing_*); value_dense_rows = all padded rows computed",
                           "grad_exchange": ("none (1 GPU)" if not use_dist else
                                             f"RCCL all-reduce AVG, {'bf16' if comm == torch.bfloat16 else 'f32'}, 64 MiB "
                                             "buckets overlapped with backward; per-rank MLM mean over labelled tokens"),
                           "loss": round(loss_value, 4)},
-               # executed FLOPs == the reference-equivalent 132.7 GFLOP/pair on this path (nothing is skipped)
+               # reference-equivalent FLOPs (132.7 GFLOP/pair) over the step time; the FLOPs actually executed on the
+               # default path (padded caption rows skipped) are in executed_gflop_per_pair
                "step_tflops_per_gpu": round(value / world * GFLOP_PER_PAIR / 1e3, 2),
                "step_mfma_frac": round(value / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS, 4),
+               "executed_gflop_per_pair": round(packed_gflop_per_pair(batch_full, all_mlm_rows=True), 1),
+               "step_tflops_per_gpu_executed": round(value / world * packed_gflop_per_pair(batch_full, all_mlm_rows=True) / 1e3, 2),
                "roofline": roofline}
+        if dense is not None:
+            out.update(dense)
         if extra is not None:
             out.update(extra)
         if world == 1 and not args.no_cpu_baseline:

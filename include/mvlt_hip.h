@@ -78,6 +78,11 @@ typedef struct MvltGemm {
                                         gradient colsum(dY) fused into the wgrad GEMM dW = dY^T X */
     void* event_after_main;          /* optional hipEvent_t recorded on `stream` right after the main GEMM kernel
                                         (before the split-K reduce): lets a benchmark time that kernel alone */
+    const int32_t* m_dev;            /* optional, DEVICE int: the number of valid storage rows of A, read by the kernel
+                                        (ragged batches planned on the GPU, mvlt_pack_plan: no host sync).  a_kmajor=0:
+                                        rows of A / C beyond it are neither read nor written (M is the upper bound the
+                                        launch is sized for); a_kmajor=1 (weight gradients): the reduction stops there
+                                        (K is the upper bound) */
 } MvltGemm;
 int mvlt_gemm(const MvltGemm* p, void* stream);
 size_t mvlt_gemm_workspace_bytes(const MvltGemm* p);
@@ -119,6 +124,7 @@ typedef struct MvltLayerNorm {
     const void* x; const float* gamma; const float* beta;
     void* y; void* y_pre; float* mean; float* rstd;
     const int32_t* out_rowmap; int merge_H, merge_W; int gelu;
+    const int32_t* rows_dev;         /* optional, DEVICE int: valid rows (<= rows); see MvltGemm.m_dev */
 } MvltLayerNorm;
 int mvlt_layernorm_fwd(const MvltLayerNorm* p, void* stream);
 
@@ -142,6 +148,7 @@ typedef struct MvltLayerNormBwd {
     void* dz; const int32_t* dz_rowmap; const float* dz_rowscale; int dz_rows_per_scale;
     float dz_dropout_p; uint64_t seed; uint32_t tag;
     int defer_param_reduce;          /* 1: leave the partial rows in `workspace`; reduce them later, batched */
+    const int32_t* rows_dev;         /* optional, DEVICE int: valid rows (<= rows); see MvltGemm.m_dev */
 } MvltLayerNormBwd;
 int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream);
 int mvlt_layernorm_bwd_workspace_rows(void);
@@ -242,6 +249,17 @@ typedef struct MvltEmbed {
     const int32_t* row_start; const int32_t* seq_len;
     const int32_t* pos_offset_dev;      /* optional (forward): added to pos_offset, read on the device (replayed decode step) */
 } MvltEmbed;
+/* Packing plan of a ragged caption batch, computed ON THE DEVICE (no host sync): sample b keeps the sequence
+ * positions [0, n_img + 2 + len_b) where len_b = 1 + the last caption position t with text_ids[b,t] != 0 or
+ * (labels != NULL and labels[b,t] >= 0); the zero-padded tail beyond it is a masked key in the bidirectional mode
+ * (model.py:125-128), lies above the causal diagonal in the seq2seq mode (:118-123) and carries no label, so no
+ * kept row ever reads it.  Outputs: seq_len[b] = n_img + 2 + len_b, row_start[b] = exclusive prefix sum,
+ * total_rows[0] = sum (feeds MvltGemm.m_dev / MvltLayerNorm.rows_dev), row_start64 = the same as int64 (index
+ * tensors), text_row[b*T + t] = int64 packed row of caption position t (row_start[b] -- the [CLS] row, finite
+ * data -- for positions beyond len_b: their label is -100 by construction).  B <= 65536. */
+int mvlt_pack_plan(const int64_t* text_ids, const int64_t* labels, int B, int T, int n_img,
+                   int32_t* row_start, int32_t* seq_len, int32_t* total_rows, int64_t* row_start64, int64_t* text_row,
+                   void* stream);
 int mvlt_embed_fwd(const MvltEmbed* p, void* stream);
 int mvlt_embed_bwd(const MvltEmbed* p, void* stream);  /* dword/dpos/dtype_emb are ACCUMULATED (zero them first) */
 

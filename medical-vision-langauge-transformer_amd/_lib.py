@@ -29,14 +29,14 @@ class MvltGemm(C.Structure):
                 ("bias", vp), ("pre", vp), ("residual", vp), ("ldr", i64), ("aux", vp),
                 ("rowscale", vp), ("rows_per_scale", i32), ("rowmap", vp),
                 ("dropout_p", f32), ("seed", u64), ("tag", u32),
-                ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("a_colsum", vp), ("event_after_main", vp)]
+                ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("a_colsum", vp), ("event_after_main", vp), ("m_dev", vp)]
 
 
 class MvltLayerNorm(C.Structure):
     _fields_ = [("dtype", i32), ("rows", i32), ("C", i32), ("eps", f32),
                 ("x", vp), ("gamma", vp), ("beta", vp),
                 ("y", vp), ("y_pre", vp), ("mean", vp), ("rstd", vp),
-                ("out_rowmap", vp), ("merge_H", i32), ("merge_W", i32), ("gelu", i32)]
+                ("out_rowmap", vp), ("merge_H", i32), ("merge_W", i32), ("gelu", i32), ("rows_dev", vp)]
 
 
 class MvltLayerNormBwd(C.Structure):
@@ -49,7 +49,7 @@ class MvltLayerNormBwd(C.Structure):
                 ("dgamma", vp), ("dbeta", vp), ("accumulate", i32),
                 ("workspace", vp),
                 ("dz", vp), ("dz_rowmap", vp), ("dz_rowscale", vp), ("dz_rows_per_scale", i32),
-                ("dz_dropout_p", f32), ("seed", u64), ("tag", u32), ("defer_param_reduce", i32)]
+                ("dz_dropout_p", f32), ("seed", u64), ("tag", u32), ("defer_param_reduce", i32), ("rows_dev", vp)]
 
 
 class MvltLnReduceItem(C.Structure):
@@ -124,6 +124,7 @@ SYMBOLS = {
     "mvlt_swin_wmsa_fwd": (i32, [C.POINTER(MvltSwinWmsa), vp]),
     "mvlt_swin_wmsa_bwd": (i32, [C.POINTER(MvltSwinWmsa), vp]),
     "mvlt_im2col_patch": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
+    "mvlt_pack_plan": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "mvlt_embed_fwd": (i32, [C.POINTER(MvltEmbed), vp]),
     "mvlt_embed_bwd": (i32, [C.POINTER(MvltEmbed), vp]),
     "mvlt_rows_transform": (i32, [i32, vp, vp, i32, i32, vp, vp, i32, f32, u64, u32, vp]),

@@ -207,6 +207,30 @@ class MVLBert(nn.Module):
                                       torch.is_grad_enabled(), pack)
         return hidden, (pooled if self.pooler is not None else None), pack[3], pack[1]
 
+    def forward_autopack(self, text_idx, image_feature, labels=None, seq2seq_mask=False):
+        """forward_packed with the plan computed ON THE DEVICE from the ids themselves (mvlt_pack_plan): no extra
+        argument, no host sync.  Sample b keeps [CLS] img [SEP] and its caption up to the last position that holds a
+        non-zero id (or a label); the launch geometry is sized for the dense upper bound B * L and every kernel
+        reads the real row count from device memory (MvltGemm.m_dev / MvltLayerNorm.rows_dev).
+        Returns (hidden [B*L, H] -- rows beyond the packed total are never written --, pooled [B, H],
+        text_row int64 [B*T]: the packed row of every caption position, the sample's [CLS] row for dropped ones)."""
+        cd = compute_dtype_of(self)
+        B, n_img, _ = image_feature.shape
+        dev = image_feature.device
+        text_idx = text_idx.contiguous()
+        lab = None if labels is None else labels.reshape(text_idx.shape).to(torch.int64).contiguous()
+        with ops.pin_stream():
+            rs, sl, tot, rs64, trow = ops.pack_plan(text_idx, lab, n_img)
+        pack = (rs, sl, B * (n_img + 2 + text_idx.shape[1]), rs64, tot)
+        tok = self.__dict__.get("_mvlt_token")
+        if tok is None or tok.device != dev:
+            tok = torch.zeros(1, device=dev, requires_grad=True)
+            self.__dict__["_mvlt_token"] = tok
+        feat = image_feature if image_feature.dtype == cd else image_feature.to(cd)
+        hidden, pooled = _EncFn.apply(tok, feat.contiguous(), self, text_idx, text_idx, None, bool(seq2seq_mask),
+                                      torch.is_grad_enabled(), pack)
+        return hidden, (pooled if self.pooler is not None else None), trow
+
     # ------------------------------------------------------------------ engine
     def _forward(self, feat, text_idx, mask_ids, image_mask, seq2seq, save, pack=None):
         cfg = self.config
@@ -225,6 +249,7 @@ class MVLBert(nn.Module):
         # pack = (row_start, seq_len, R): activations are [R, H] with the trailing zero-padded caption positions
         # of every sample left out (forward_packed); otherwise dense [B*Lq, H]
         rows = B * Lq if pack is None else pack[2]
+        rd = pack[4] if (pack is not None and len(pack) > 4) else None     # row count on the device (auto-packed batch)
         x = ops.embed_fwd(text_idx, feat, self.word_embeddings.weight.data, self.position_embeddings.weight.data,
                           self.token_type_embeddings.weight.data, cfg.cls_token_id, cfg.sep_token_id,
                           pack=pack).view(rows, H)
@@ -246,20 +271,20 @@ class MVLBert(nn.Module):
                     layers.append(out[1:])
         for i, layer in enumerate(() if native else self.encoder.layer):
             sa, so = layer.attention.self, layer.attention.output
-            qkv = ops.gemm(x, ar.compute(sa.query.weight, 3 * H), bias=ar.master_span(sa.query.bias, 3 * H))
+            qkv = ops.gemm(x, ar.compute(sa.query.weight, 3 * H), bias=ar.master_span(sa.query.bias, 3 * H), m_dev=rd)
             ctx, lse = ops.attn_fwd(qkv, mode, B, Lq, nH, H // nH, (H // nH) ** -0.5,
                                     dropout=(p_a, seed, 8 * i + 0), **akw)
             y1 = ops.gemm(ctx, ar.compute(so.dense.weight), bias=so.dense.bias.data, dropout=(p_h, seed, 8 * i + 1),
-                          residual=x)
+                          residual=x, m_dev=rd)
             x1, m1, r1, _ = ops.layernorm_fwd(y1, so.LayerNorm.weight.data, so.LayerNorm.bias.data, so.LayerNorm.eps,
-                                              save_stats=save)
+                                              save_stats=save, rows_dev=rd)
             h = torch.empty((rows, cfg.intermediate_size), dtype=cd, device=x.device)
             a = ops.gemm(x1, ar.compute(layer.intermediate.dense.weight), bias=layer.intermediate.dense.bias.data,
-                         gelu=True, save_pre=h)
+                         gelu=True, save_pre=h, m_dev=rd)
             y2 = ops.gemm(a, ar.compute(layer.output.dense.weight), bias=layer.output.dense.bias.data,
-                          dropout=(p_h, seed, 8 * i + 2), residual=x1)
+                          dropout=(p_h, seed, 8 * i + 2), residual=x1, m_dev=rd)
             x2, m2, r2, _ = ops.layernorm_fwd(y2, layer.output.LayerNorm.weight.data, layer.output.LayerNorm.bias.data,
-                                              layer.output.LayerNorm.eps, save_stats=save)
+                                              layer.output.LayerNorm.eps, save_stats=save, rows_dev=rd)
             if save:
                 layers.append((x, qkv, ctx, lse, y1, m1, r1, x1, h, a, y2, m2, r2))
             x = x2
@@ -280,7 +305,8 @@ class MVLBert(nn.Module):
     def _attn_desc(mode, B, Lq, nH, mask_ids, T, image_mask, obj_end, pack):
         ptr = lambda t: 0 if t is None else t.data_ptr()
         return [mode, B, Lq, nH, ptr(mask_ids), T, ptr(image_mask), obj_end,
-                ptr(pack[0]) if pack is not None else 0, ptr(pack[1]) if pack is not None else 0]
+                ptr(pack[0]) if pack is not None else 0, ptr(pack[1]) if pack is not None else 0,
+                ptr(pack[4]) if (pack is not None and len(pack) > 4) else 0]
 
     def _layer_desc(self, ar, layer):
         key = ("bert_desc", id(layer))
@@ -311,6 +337,7 @@ class MVLBert(nn.Module):
         nH = cfg.num_attention_heads
         seed, p_h, p_a = sv["seed"], sv["p_h"], sv["p_a"]
         pack, rows = sv["pack"], sv["rows"]
+        rd = pack[4] if (pack is not None and len(pack) > 4) else None
         if dhidden is None:                      # only the pooled output was used (VQA / retrieval heads)
             dx = torch.zeros((rows, H), dtype=sv["layers"][0][0].dtype, device=sv["layers"][0][0].device)
             dhidden = dx.new_empty(0)
@@ -352,26 +379,31 @@ class MVLBert(nn.Module):
             lo, li = layer.output, layer.intermediate
             if p_h > 0:
                 dy2, dz2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight),
-                                             g(lo.LayerNorm.bias), branch=dict(dropout=(p_h, seed, 8 * i + 2)), defer=lnq)
+                                             g(lo.LayerNorm.bias), branch=dict(dropout=(p_h, seed, 8 * i + 2)), defer=lnq,
+                                             rows_dev=rd)
             else:
-                dy2 = dz2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight), g(lo.LayerNorm.bias), defer=lnq)
-            dh = ops.gemm(dz2, ar.compute(lo.dense.weight), b_kmajor=True, mul_gelu_grad=h)
-            dx1 = ops.gemm(dh, ar.compute(li.dense.weight), b_kmajor=True, residual=dy2)
+                dy2 = dz2 = ops.layernorm_bwd(dx, y2, m2, r2, lo.LayerNorm.weight.data, g(lo.LayerNorm.weight),
+                                              g(lo.LayerNorm.bias), defer=lnq, rows_dev=rd)
+            dh = ops.gemm(dz2, ar.compute(lo.dense.weight), b_kmajor=True, mul_gelu_grad=h, m_dev=rd)
+            dx1 = ops.gemm(dh, ar.compute(li.dense.weight), b_kmajor=True, residual=dy2, m_dev=rd)
             if p_h > 0:
                 dy1, dz1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight),
-                                             g(so.LayerNorm.bias), branch=dict(dropout=(p_h, seed, 8 * i + 1)), defer=lnq)
+                                             g(so.LayerNorm.bias), branch=dict(dropout=(p_h, seed, 8 * i + 1)), defer=lnq,
+                                             rows_dev=rd)
             else:
-                dy1 = dz1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight), g(so.LayerNorm.bias), defer=lnq)
-            dctx = ops.gemm(dz1, ar.compute(so.dense.weight), b_kmajor=True)
+                dy1 = dz1 = ops.layernorm_bwd(dx1, y1, m1, r1, so.LayerNorm.weight.data, g(so.LayerNorm.weight),
+                                              g(so.LayerNorm.bias), defer=lnq, rows_dev=rd)
+            dctx = ops.gemm(dz1, ar.compute(so.dense.weight), b_kmajor=True, m_dev=rd)
             dqkv = ops.attn_bwd(dctx, qkv, ctx, lse, sv["mode"], B, Lq, nH, H // nH, (H // nH) ** -0.5,
                                 dropout=(p_a, seed, 8 * i + 0), **sv["akw"])
-            dx_in = ops.gemm(dqkv, ar.compute(sa.query.weight, 3 * H), b_kmajor=True, residual=dy1)
+            dx_in = ops.gemm(dqkv, ar.compute(sa.query.weight, 3 * H), b_kmajor=True, residual=dy1, m_dev=rd)
             # weight / bias gradients on the side stream (off the critical path)
+            xtra = () if rd is None else (rd,)
             with ops.on_side(dx.device, dz2, a, dh, x1, dz1, ctx, dqkv, x):
-                ops.wgrad_group([(dz2, a, g(lo.dense.weight), g(lo.dense.bias)),
-                                 (dh, x1, g(li.dense.weight), g(li.dense.bias)),
-                                 (dz1, ctx, g(so.dense.weight), g(so.dense.bias)),
-                                 (dqkv, x, g(sa.query.weight, 3 * H), g(sa.query.bias, 3 * H))])
+                ops.wgrad_group([(dz2, a, g(lo.dense.weight), g(lo.dense.bias)) + xtra,
+                                 (dh, x1, g(li.dense.weight), g(li.dense.bias)) + xtra,
+                                 (dz1, ctx, g(so.dense.weight), g(so.dense.bias)) + xtra,
+                                 (dqkv, x, g(sa.query.weight, 3 * H), g(sa.query.bias, 3 * H)) + xtra])
             dx = dx_in
             ar.mark(lo.LayerNorm.weight, lo.LayerNorm.bias, lo.dense.weight, lo.dense.bias, li.dense.weight,
                     li.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, so.dense.weight, so.dense.bias,

@@ -27,7 +27,20 @@ struct GemmDev {
     int split_k; int k_per_split; float* ws;
     int a_vec, b_vec, epi_vec;
     float* a_colsum; float* ws_colsum;   // optional: column sums of a k-major A (bias gradient), fused
+    const int* m_dev;                    // optional: valid storage rows of A on the device (MvltGemm.m_dev)
 };
+
+// Ragged batches planned on the GPU: the launch is sized for the upper bound, the kernel reads the real count.
+// k-contiguous A: M shrinks (tiles beyond it leave at once); k-major A (weight gradients): the reduction shrinks.
+template <bool AK>
+MVLT_DEV GemmDev effective(const GemmDev& p) {
+    GemmDev q = p;
+    if (p.m_dev) {
+        const int r = __builtin_amdgcn_readfirstlane(*p.m_dev);
+        if (AK) q.K = min(q.K, max(r, 0)); else q.M = min(q.M, max(r, 0));
+    }
+    return q;
+}
 
 template <typename T>
 MVLT_DEV typename TypeInfo<T>::Vec load_chunk(const T* base, long ld, int outer, int inner,
@@ -192,12 +205,14 @@ MVLT_DEV int xcd_remap(int orig, int nwg) {
 
 // one output tile (bx, by) of one k-split bz
 template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2>
-MVLT_DEV void gemm_body(const GemmDev& p, const int bx, const int by, const int bz, T* sA, T* sB) {
+MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const int bz, T* sA, T* sB) {
     using GA = TileGeom<T, BM, AK>;
     using GB = TileGeom<T, BN, BK_>;
     using Vec = typename TypeInfo<T>::Vec;
     constexpr int FM = BM / 32, FN = BN / 32;
+    const GemmDev p = effective<AK>(p_in);
     const int m0 = by * BM, n0 = bx * BN;
+    if (m0 >= p.M) return;                       // (uniform per workgroup; only with m_dev)
     const int ks = bz * p.k_per_split;
     const int ke = min(p.K, ks + p.k_per_split);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -474,8 +489,10 @@ __global__ __launch_bounds__(256, 3) void gemm_group_kernel(const GemmGroupDev g
 
 // slabs -> output: 64 output quads per block, the slabs are shared out over 4 waves and combined in LDS
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDev p) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDev p_in) {
     __shared__ f32x4 red[4][64];
+    GemmDev p = p_in;
+    if (p.m_dev && p.rowmap == nullptr && !p_in.a_colsum) p.M = min(p.M, max(*p.m_dev, 0));   // (never for weight gradients)
     const int nq = (p.N + 3) / 4;
     const long total = (long)p.M * nq;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -616,6 +633,7 @@ static int fill_dev(const MvltGemm* p, const Plan& pl, GemmDev& d) {
     }
     d.ws = reinterpret_cast<float*>(p->workspace);
     d.a_colsum = p->a_colsum;
+    d.m_dev = p->m_dev;
     d.ws_colsum = d.ws ? d.ws + (size_t)d.split_k * p->M * p->N : nullptr;
     d.a_vec = (p->lda % E == 0) && aligned16(p->A);
     d.b_vec = (p->ldb % E == 0) && aligned16(p->B);

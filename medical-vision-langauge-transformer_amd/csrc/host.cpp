@@ -73,6 +73,7 @@ struct Epi {
     const void* residual = nullptr; int64_t ldr = 0;
     const int32_t* rowmap = nullptr; const void* aux = nullptr;
     bool out_f32 = false, accumulate = false; float* a_colsum = nullptr;
+    const int32_t* m_dev = nullptr;          // valid storage rows of A on the device (ragged batches)
 };
 
 void fill_gemm(MvltGemm& p, int dtype, int M, int N, int K, const void* A, int64_t lda, bool ak, const void* B, int64_t ldb,
@@ -92,6 +93,7 @@ void fill_gemm(MvltGemm& p, int dtype, int M, int N, int K, const void* A, int64
     if (e.accumulate) epi |= MVLT_EPI_ACCUM;
     p.epilogue = epi;
     p.a_colsum = e.a_colsum;
+    p.m_dev = e.m_dev;
 }
 
 void gemm(int dtype, int M, int N, int K, const void* A, int64_t lda, bool ak, const void* B, int64_t ldb, bool bk,
@@ -120,7 +122,7 @@ GroupTimer g_timer;
 
 struct WItem { const Tensor* dy; const Tensor* x; int64_t dw; int64_t db; };
 // weight gradients of one layer: dW_i = dY_i^T X_i, db_i = colsum(dY_i)  (ops.wgrad_group)
-void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws) {
+void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws, const int32_t* k_dev = nullptr) {
     const int n = (int)items.size();
     bool all128 = true, all96 = true;
     for (auto& it : items) { all128 &= it.x->size(1) % 128 == 0; all96 &= it.x->size(1) % 96 == 0; }
@@ -130,7 +132,7 @@ void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws) {
     const int dtype = dtype_of(*items[0].dy);
     if (!(n > 1 && n <= 8 && bn && tiles >= 200)) {
         for (auto& it : items) {
-            Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db);
+            Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db); e.m_dev = k_dev;
             gemm(dtype, (int)it.dy->size(1), (int)it.x->size(1), (int)it.dy->size(0), dp(*it.dy), it.dy->size(1), true,
                  dp(*it.x), it.x->size(1), true, P(it.dw), it.x->size(1), e, stream, ws, *it.dy);
         }
@@ -140,7 +142,7 @@ void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws) {
     double flops = 0;
     for (int i = 0; i < n; ++i) {
         const auto& it = items[i];
-        Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db);
+        Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db); e.m_dev = k_dev;
         fill_gemm(arr[i], dtype, (int)it.dy->size(1), (int)it.x->size(1), (int)it.dy->size(0), dp(*it.dy), it.dy->size(1), true,
                   dp(*it.x), it.x->size(1), true, P(it.dw), it.x->size(1), e);
         arr[i].split_k = 1;
@@ -161,11 +163,11 @@ void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws) {
 
 // ----------------------------------------------------------------------------------------------- LayerNorm
 void ln_fwd(const Tensor& x, int rows, int C, int64_t gamma, int64_t beta, float eps, Tensor& y, float* mean, float* rstd,
-            const int32_t* out_rowmap, void* stream) {
+            const int32_t* out_rowmap, void* stream, const int32_t* rows_dev = nullptr) {
     MvltLayerNorm p{};
     p.dtype = dtype_of(x); p.rows = rows; p.C = C; p.eps = eps;
     p.x = dp(x); p.gamma = P<float>(gamma); p.beta = P<float>(beta); p.y = dp(y);
-    p.mean = mean; p.rstd = rstd; p.out_rowmap = out_rowmap;
+    p.mean = mean; p.rstd = rstd; p.out_rowmap = out_rowmap; p.rows_dev = rows_dev;
     ck(mvlt_layernorm_fwd(&p, stream), "mvlt_layernorm_fwd");
 }
 
@@ -194,7 +196,8 @@ LnQueue g_lnq;
 struct LnBranch { void* dz = nullptr; const int32_t* rowmap = nullptr; const float* rowscale = nullptr; int rps = 1;
                   float drop_p = 0.f; uint64_t seed = 0; uint32_t tag = 0; };
 void ln_bwd(const Tensor& dy, const int32_t* dy_rowmap, const Tensor& x, const float* mean, const float* rstd, int rows, int C,
-            int64_t gamma, int64_t dgamma, int64_t dbeta, const void* dres, Tensor& dx, const LnBranch& br, void* stream) {
+            int64_t gamma, int64_t dgamma, int64_t dbeta, const void* dres, Tensor& dx, const LnBranch& br, void* stream,
+            const int32_t* rows_dev = nullptr) {
     static const int ws_rows = mvlt_layernorm_bwd_workspace_rows();
     MvltLayerNormBwd p{};
     p.dtype = dtype_of(x); p.rows = rows; p.C = C;
@@ -202,7 +205,7 @@ void ln_bwd(const Tensor& dy, const int32_t* dy_rowmap, const Tensor& x, const f
     p.dres = dres; p.dx = dp(dx);
     p.dgamma = P<float>(dgamma); p.dbeta = P<float>(dbeta);
     float* ws = g_lnq.take((int64_t)2 * ws_rows * C, x);
-    p.workspace = ws; p.defer_param_reduce = 1;
+    p.workspace = ws; p.defer_param_reduce = 1; p.rows_dev = rows_dev;
     g_lnq.items.push_back(MvltLnReduceItem{ws, mvlt_layernorm_bwd_nparts(rows, C), C, p.dgamma, p.dbeta});
     if (br.dz) {
         p.dz = br.dz; p.dz_rowmap = br.rowmap; p.dz_rowscale = br.rowscale; p.dz_rows_per_scale = br.rps;
@@ -232,26 +235,27 @@ std::vector<Tensor> bert_layer_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f
     const int64_t rows = x.size(0);
     AttnArgs a{(int)attn[0], (int)attn[1], (int)attn[2], (int)attn[3], attn[4], (int)attn[5], attn[6], (int)attn[7], attn[8], attn[9]};
     const uint64_t sd = (uint64_t)seed;
+    const int32_t* rd = attn.size() > 10 ? P<const int32_t>(attn[10]) : nullptr;      // valid rows on the device (auto-packed batch)
     Tensor qkv = empty2(rows, 3 * H, x);
-    { Epi e; e.bias = P<float>(f[0]); linear(x, w[0], (int)(3 * H), qkv, e, st); }
+    { Epi e; e.m_dev = rd; e.bias = P<float>(f[0]); linear(x, w[0], (int)(3 * H), qkv, e, st); }
     Tensor ctx = empty2(rows, H, x);
     Tensor lse = emptyf({a.B, a.nH, a.Lq}, x);
     { MvltAttn p; fill_attn(p, qkv, a, (int)H, dp(ctx), fp(lse), (float)p_a, sd, (uint32_t)(8 * layer + 0));
       ck(mvlt_attn_fwd(&p, st), "mvlt_attn_fwd"); }
     Tensor y1 = empty2(rows, H, x);
-    { Epi e; e.bias = P<float>(f[1]); e.drop_p = (float)p_h; e.seed = sd; e.tag = (uint32_t)(8 * layer + 1);
+    { Epi e; e.m_dev = rd; e.bias = P<float>(f[1]); e.drop_p = (float)p_h; e.seed = sd; e.tag = (uint32_t)(8 * layer + 1);
       e.residual = dp(x); e.ldr = H; linear(ctx, w[1], (int)H, y1, e, st); }
     Tensor x1 = empty2(rows, H, x), st1, st2;
     float *m1 = nullptr, *r1 = nullptr, *m2 = nullptr, *r2 = nullptr;
     if (save) { st1 = emptyf({2, rows}, x); m1 = fp(st1); r1 = m1 + rows; st2 = emptyf({2, rows}, x); m2 = fp(st2); r2 = m2 + rows; }
-    ln_fwd(y1, (int)rows, (int)H, f[4], f[5], (float)eps, x1, m1, r1, nullptr, st);
+    ln_fwd(y1, (int)rows, (int)H, f[4], f[5], (float)eps, x1, m1, r1, nullptr, st, rd);
     Tensor h = empty2(rows, I, x), act = empty2(rows, I, x);
-    { Epi e; e.bias = P<float>(f[2]); e.gelu = true; e.pre = dp(h); linear(x1, w[2], (int)I, act, e, st); }
+    { Epi e; e.m_dev = rd; e.bias = P<float>(f[2]); e.gelu = true; e.pre = dp(h); linear(x1, w[2], (int)I, act, e, st); }
     Tensor y2 = empty2(rows, H, x);
-    { Epi e; e.bias = P<float>(f[3]); e.drop_p = (float)p_h; e.seed = sd; e.tag = (uint32_t)(8 * layer + 2);
+    { Epi e; e.m_dev = rd; e.bias = P<float>(f[3]); e.drop_p = (float)p_h; e.seed = sd; e.tag = (uint32_t)(8 * layer + 2);
       e.residual = dp(x1); e.ldr = H; linear(act, w[3], (int)H, y2, e, st); }
     Tensor x2 = empty2(rows, H, x);
-    ln_fwd(y2, (int)rows, (int)H, f[6], f[7], (float)eps, x2, m2, r2, nullptr, st);
+    ln_fwd(y2, (int)rows, (int)H, f[6], f[7], (float)eps, x2, m2, r2, nullptr, st, rd);
     if (!save) return {x2};
     return {x2, x, qkv, ctx, lse, y1, st1, x1, h, act, y2, st2};
 }
@@ -267,31 +271,32 @@ Tensor bert_layer_bwd(const Tensor& dx, const std::vector<Tensor>& sv, const Ptr
     const int64_t rows = x.size(0);
     AttnArgs a{(int)attn[0], (int)attn[1], (int)attn[2], (int)attn[3], attn[4], (int)attn[5], attn[6], (int)attn[7], attn[8], attn[9]};
     const uint64_t sd = (uint64_t)seed;
+    const int32_t* rd = attn.size() > 10 ? P<const int32_t>(attn[10]) : nullptr;
     // LN2 backward: dy2 = gradient of y2 (also the residual branch into x1); dz2 = hidden-dropout backward of it
     Tensor dy2 = empty2(rows, H, x), dz2 = dy2;
     { LnBranch br; if (p_h > 0) { dz2 = empty2(rows, H, x); br.dz = dp(dz2); br.drop_p = (float)p_h; br.seed = sd; br.tag = (uint32_t)(8 * layer + 2); }
-      ln_bwd(dx, nullptr, y2, fp(st2), fp(st2) + rows, (int)rows, (int)H, f[6], g[10], g[11], nullptr, dy2, br, st); }
+      ln_bwd(dx, nullptr, y2, fp(st2), fp(st2) + rows, (int)rows, (int)H, f[6], g[10], g[11], nullptr, dy2, br, st, rd); }
     Tensor dh = empty2(rows, I, x);
-    { Epi e; e.aux = dp(h); dgrad(dz2, w[3], (int)I, dh, e, st); }
+    { Epi e; e.m_dev = rd; e.aux = dp(h); dgrad(dz2, w[3], (int)I, dh, e, st); }
     Tensor dx1 = empty2(rows, H, x);
-    { Epi e; e.residual = dp(dy2); e.ldr = H; dgrad(dh, w[2], (int)H, dx1, e, st); }
+    { Epi e; e.m_dev = rd; e.residual = dp(dy2); e.ldr = H; dgrad(dh, w[2], (int)H, dx1, e, st); }
     Tensor dy1 = empty2(rows, H, x), dz1 = dy1;
     { LnBranch br; if (p_h > 0) { dz1 = empty2(rows, H, x); br.dz = dp(dz1); br.drop_p = (float)p_h; br.seed = sd; br.tag = (uint32_t)(8 * layer + 1); }
-      ln_bwd(dx1, nullptr, y1, fp(st1), fp(st1) + rows, (int)rows, (int)H, f[4], g[8], g[9], nullptr, dy1, br, st); }
+      ln_bwd(dx1, nullptr, y1, fp(st1), fp(st1) + rows, (int)rows, (int)H, f[4], g[8], g[9], nullptr, dy1, br, st, rd); }
     Tensor dctx = empty2(rows, H, x);
-    { Epi e; dgrad(dz1, w[1], (int)H, dctx, e, st); }
+    { Epi e; e.m_dev = rd; dgrad(dz1, w[1], (int)H, dctx, e, st); }
     Tensor dqkv = empty2(rows, 3 * H, x);
     { MvltAttn p; fill_attn(p, qkv, a, (int)H, dp(ctx), fp(lse), (float)p_a, sd, (uint32_t)(8 * layer + 0));
       Tensor delta = at::empty_like(lse);
       p.dout = dp(dctx); p.dqkv = dp(dqkv); p.delta_ws = fp(delta);
       ck(mvlt_attn_bwd(&p, st), "mvlt_attn_bwd"); }
     Tensor dxin = empty2(rows, H, x);
-    { Epi e; e.residual = dp(dy1); e.ldr = H; dgrad(dqkv, w[0], (int)H, dxin, e, st); }
+    { Epi e; e.m_dev = rd; e.residual = dp(dy1); e.ldr = H; dgrad(dqkv, w[0], (int)H, dxin, e, st); }
     // weight / bias gradients on the side stream (off the critical path)
     fork_side(ss);
     for (const Tensor* t : std::initializer_list<const Tensor*>{&dz2, &act, &dh, &x1, &dz1, &ctx, &dqkv, &x}) g_side_keepalive.push_back(*t);
     wgrad_group({{&dz2, &act, g[6], g[7]}, {&dh, &x1, g[4], g[5]}, {&dz1, &ctx, g[2], g[3]}, {&dqkv, &x, g[0], g[1]}},
-                ss.side, g_ws_side);
+                ss.side, g_ws_side, rd);
     return dxin;
 }
 

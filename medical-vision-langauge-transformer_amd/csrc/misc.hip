@@ -53,6 +53,34 @@ MVLT_DEV int emb_word_id(const EmbDev& p, int b, int posi) {
     return (int)p.text[(long)b * p.T + (posi - p.n_img - 2)];
 }
 
+// Packing plan of a ragged caption batch (mvlt_pack_plan): one workgroup, no host involvement.
+__global__ __launch_bounds__(256) void pack_plan_kernel(const int64_t* text, const int64_t* labels, int B, int T, int n_img,
+                                                        int* row_start, int* seq_len, int* total, int64_t* row_start64,
+                                                        int64_t* text_row) {
+    for (int b = threadIdx.x; b < B; b += 256) {
+        int len = 0;
+        for (int t = T - 1; t >= 0; --t) {
+            const long i = (long)b * T + t;
+            if (text[i] != 0 || (labels && labels[i] >= 0)) { len = t + 1; break; }
+        }
+        seq_len[b] = n_img + 2 + len;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < B; ++b) { row_start[b] = acc; if (row_start64) row_start64[b] = acc; acc += seq_len[b]; }
+        total[0] = acc;
+    }
+    __syncthreads();
+    if (text_row) {
+        for (long i = threadIdx.x; i < (long)B * T; i += 256) {
+            const int b = (int)(i / T), t = (int)(i - (long)b * T);
+            const int len = seq_len[b] - (n_img + 2);
+            text_row[i] = t < len ? (int64_t)row_start[b] + n_img + 2 + t : (int64_t)row_start[b];
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbDev p) {
     const int HV = p.H / 4;
@@ -565,6 +593,17 @@ static int fill_emb(const MvltEmbed* p, EmbDev& d) {
     if (p->n_img >= 0) MVLT_CHECK(p->image_feature || p->dout, MVLT_ERR_ARG);
     return MVLT_OK;
 }
+extern "C" int mvlt_pack_plan(const int64_t* text_ids, const int64_t* labels, int B, int T, int n_img,
+                              int32_t* row_start, int32_t* seq_len, int32_t* total_rows, int64_t* row_start64,
+                              int64_t* text_row, void* stream) {
+    MVLT_CHECK(text_ids && row_start && seq_len && total_rows, MVLT_ERR_ARG);
+    MVLT_CHECK(B > 0 && B <= 65536 && T > 0 && n_img >= 0, MVLT_ERR_ARG);
+    hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(256), 0, STREAM(stream), text_ids, labels, B, T, n_img, row_start, seq_len,
+                       total_rows, row_start64, text_row);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
 extern "C" int mvlt_embed_fwd(const MvltEmbed* p, void* stream) {
     EmbDev d{}; int rc = fill_emb(p, d); if (rc) return rc;
     MVLT_CHECK(p->out && (p->n_img < 0 || p->image_feature), MVLT_ERR_ARG);

@@ -20,7 +20,9 @@ struct LnDev {
     float* part_g; float* part_b; int nparts;
     // optional second output: dz[zmap ? zmap[r] : r] = dropmask(dx[r]) * zscale[r / zrps]
     void* dz; const int* zmap; const float* zscale; int zrps; uint32_t zthresh; float zdscale; uint64_t seed; uint32_t tag;
+    const int* rows_dev;     // optional: valid rows on the device (ragged batches planned on the GPU)
 };
+MVLT_DEV int ln_rows(const LnDev& p) { return p.rows_dev ? min(p.rows, max(*p.rows_dev, 0)) : p.rows; }
 
 template <int LPR> MVLT_DEV float group_sum(float v) {
 #pragma unroll
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnDev p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sl = lane % LPR;
     const int r = (blockIdx.x * 4 + wave) * RPW + lane / LPR;
-    const bool rv = r < p.rows;
+    const bool rv = r < ln_rows(p);
     const T* x = reinterpret_cast<const T*>(p.x);
     f32x4 v[NV];
     float s = 0.f;
@@ -109,9 +111,10 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnDev p) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) { ag[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[j] = ag[j]; }
     const float invC = 1.0f / p.C;
-    for (int r0 = (blockIdx.x * nwave + wave) * RPW; r0 < p.rows; r0 += gridDim.x * nwave * RPW) {
+    const int nrows = ln_rows(p);
+    for (int r0 = (blockIdx.x * nwave + wave) * RPW; r0 < nrows; r0 += gridDim.x * nwave * RPW) {
         const int r = r0 + lane / LPR;
-        const bool rv = r < p.rows;
+        const bool rv = r < nrows;
         const float mean = rv ? p.mean[r] : 0.f, rstd = rv ? p.rstd[r] : 0.f;
         const int rd = (rv && p.rowmap) ? p.rowmap[r] : r;
         f32x4 xh[NV], g[NV];
@@ -301,7 +304,7 @@ extern "C" int mvlt_layernorm_fwd(const MvltLayerNorm* p, void* stream) {
     LnDev d{};
     d.rows = p->rows; d.C = p->C; d.eps = p->eps; d.x = p->x; d.gamma = p->gamma; d.beta = p->beta;
     d.y = p->y; d.y_pre = p->y_pre; d.mean = p->mean; d.rstd = p->rstd; d.rowmap = p->out_rowmap;
-    d.mH = p->merge_H; d.mW = p->merge_W; d.gelu = p->gelu;
+    d.mH = p->merge_H; d.mW = p->merge_W; d.gelu = p->gelu; d.rows_dev = p->rows_dev;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p->dtype == MVLT_F32) return dispatch<float, false>(d, merge, s);
     if (p->dtype == MVLT_BF16) return dispatch<bf16_t, false>(d, merge, s);
@@ -323,7 +326,7 @@ extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
     d.part_g = p->workspace; d.part_b = p->workspace + (size_t)LN_BWD_PARTS * p->C;
     d.dz = p->dz; d.zmap = p->dz_rowmap; d.zscale = p->dz_rowscale; d.zrps = p->dz_rows_per_scale > 0 ? p->dz_rows_per_scale : 1;
     d.zthresh = (uint32_t)((double)p->dz_dropout_p * 4294967296.0); d.zdscale = 1.0f / (1.0f - p->dz_dropout_p);
-    d.seed = p->seed; d.tag = p->tag;
+    d.seed = p->seed; d.tag = p->tag; d.rows_dev = p->rows_dev;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (p->dtype == MVLT_F32) rc = dispatch<float, true>(d, merge, s);

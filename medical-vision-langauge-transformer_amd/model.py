@@ -394,6 +394,9 @@ class MVLBertPretrainedModel(nn.Module):
 
 
 # ----------------------------------------------------------------------------- heads
+_AUTO_PACK = os.environ.get("MVLT_AUTO_PACK", "1") != "0"
+
+
 class MVLBertForPretraining(MVLBertPretrainedModel):
     """model.py:352-420.  The seq2seq/bidirectional coin flip (model.py:390-394)
     uses Python's ``random`` like the reference; under DDP every rank must draw
@@ -421,9 +424,18 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
         seq2seq_mask = random.random() < 0.5
         self.last_seq2seq = seq2seq_mask
         packed = text_lengths is not None and image_mask is None
+        # default: the packing plan is derived ON THE DEVICE from the ids and labels themselves (no new argument, no
+        # host sync; config.auto_pack_rows = False or MVLT_AUTO_PACK=0 computes every padded row like the reference)
+        auto = (not packed and image_mask is None and getattr(self.config, "auto_pack_rows", True) and _AUTO_PACK
+                and text_idx.dtype == torch.int64)
         B, T = text_idx.shape
         n_img = image_feature.shape[1]
-        if packed:
+        text_row = None
+        if auto:
+            hidden, pooled, text_row = self.MVLBert.forward_autopack(
+                text_idx, image_feature, labels=caption_label if self.config.MLM_task else None, seq2seq_mask=seq2seq_mask)
+            H = hidden.shape[1]
+        elif packed:
             hidden, pooled, row_start, seq_len = self.MVLBert.forward_packed(text_idx, image_feature, text_lengths,
                                                                              seq2seq_mask=seq2seq_mask)
             H = hidden.shape[1]
@@ -450,7 +462,10 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
                 valid = labels >= 0
                 order = torch.argsort((~valid).to(torch.int8), stable=True)[: cap * B]
                 sel_labels = labels[order].contiguous()
-            if packed:
+            if auto:
+                # packed row of every caption position (dropped positions: the sample's [CLS] row; label -100)
+                x = hidden[text_row[order] if compact else text_row]
+            elif packed:
                 # flat (b, t) -> packed row of caption position t; rows of unlabelled picks are clamped into
                 # range (their label is -100, whatever they gather is ignored)
                 flat = order if compact else torch.arange(B * T, device=dev)

@@ -185,7 +185,7 @@ def _ld(t):
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=None, gelu=False,
          save_pre=None, dropout=None, rowscale=None, residual=None, rowmap=None, mul_gelu_grad=None,
-         accumulate=False, split_k=0, ldc=None, a_colsum=None):
+         accumulate=False, split_k=0, ldc=None, a_colsum=None, m_dev=None):
     """C = epilogue(A @ B); see MvltGemm.  A: [M,K] (or [K,M] if a_kmajor);
     B: [N,K] torch-Linear layout (or [K,N] if b_kmajor).
     (Written for a short host path: ~330 calls per training step; pointers go into the struct as plain ints.)"""
@@ -254,6 +254,8 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
         epi |= L.EPI_ACCUM
     p.epilogue = epi
     p.split_k = split_k
+    if m_dev is not None:          # valid storage rows of A on the device (ragged batch planned on the GPU)
+        p.m_dev = m_dev.data_ptr()
     if a_colsum is not None:
         assert a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M
         p.a_colsum = a_colsum.data_ptr()
@@ -311,11 +313,15 @@ def wgrad_group(items):
     len(items) split-K launches plus their reduce kernels; otherwise one gemm() each."""
     lib = L.lib()
     n = len(items)
+    m_dev = None
+    if items and len(items[0]) == 5:          # (dy, x, dw, db, m_dev): the reduction length lives on the device
+        m_dev = items[0][4]
+        items = [it[:4] for it in items]
     bn = 128 if all(x.shape[1] % 128 == 0 for _, x, _, _ in items) else (96 if all(x.shape[1] % 96 == 0 for _, x, _, _ in items) else 0)
     tiles = sum(((dy.shape[1] + 63) // 64) * ((x.shape[1] + bn - 1) // bn) for dy, x, _, _ in items) if bn else 0
     if not (1 < n <= 8 and bn and tiles >= 200):
         for dy, x, dw, db in items:
-            gemm(dy, x, a_kmajor=True, b_kmajor=True, out=dw, out_f32=True, a_colsum=db)
+            gemm(dy, x, a_kmajor=True, b_kmajor=True, out=dw, out_f32=True, a_colsum=db, m_dev=m_dev)
         return
     arr = (L.MvltGemm * n)()
     flops = 0.0
@@ -329,6 +335,8 @@ def wgrad_group(items):
         p.B, p.ldb, p.b_kmajor = _p(x), x.stride(0), 1
         p.C, p.ldc = _p(dw), dw.stride(0)
         p.epilogue, p.split_k = L.EPI_OUT_F32, 1
+        if m_dev is not None:
+            p.m_dev = m_dev.data_ptr()
         if db is not None:
             assert db.dtype == torch.float32 and db.numel() == dy.shape[1]
             p.a_colsum = _p(db)
@@ -367,7 +375,7 @@ def colsum(x, out=None, accumulate=False):
 
 # ----------------------------------------------------------------------------- LayerNorm
 def layernorm_fwd(x, gamma, beta, eps, *, rows=None, C_=None, out=None, out_rowmap=None, merge=None, gelu=False,
-                  save_pre=False, save_stats=True):
+                  save_pre=False, save_stats=True, rows_dev=None):
     """x: [..., C] contiguous (or the un-merged [B,H*W,C/4] tensor when merge=(H,W))."""
     _need_cuda(x)
     assert x.is_contiguous() and gamma.dtype == torch.float32
@@ -398,12 +406,14 @@ def layernorm_fwd(x, gamma, beta, eps, *, rows=None, C_=None, out=None, out_rowm
         p.out_rowmap = _p(out_rowmap)
     if merge is not None:
         p.merge_H, p.merge_W = merge
+    if rows_dev is not None:
+        p.rows_dev = rows_dev.data_ptr()
     L.check(L.lib().mvlt_layernorm_fwd(C.byref(p), _stream()), "mvlt_layernorm_fwd")
     return y, mean, rstd, ypre
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_pre=None, dres=None, merge=None,
-                  accumulate=False, dx=None, branch=None, defer=None):
+                  accumulate=False, dx=None, branch=None, defer=None, rows_dev=None):
     """branch=dict(rowmap=, rowscale=(t, rps), dropout=(p, seed, tag)) also returns the branch gradient dz.
     defer=LnReduceQueue: the dgamma/dbeta partial rows are reduced later in one batched launch."""
     _need_cuda(dy, x)
@@ -433,6 +443,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_
         p.merge_H, p.merge_W = merge
     p.dgamma, p.dbeta, p.accumulate, p.workspace = _p(dgamma), _p(dbeta), int(accumulate), _p(ws)
     p.defer_param_reduce = int(defer is not None)
+    if rows_dev is not None:
+        p.rows_dev = rows_dev.data_ptr()
     dz = None
     if branch is not None:
         dz = torch.empty((nrows, Cn), dtype=x.dtype, device=x.device)
@@ -594,6 +606,24 @@ def im2col_patch(img, dtype, patch):
     cols = torch.empty((B * G * G, Cin * patch * patch), dtype=dtype, device=img.device)
     L.check(L.lib().mvlt_im2col_patch(_DT[dtype], _p(img), _p(cols), B, Cin, S, patch, _stream()), "mvlt_im2col_patch")
     return cols
+
+
+def pack_plan(text_ids, labels, n_img):
+    """Packing plan of a ragged caption batch, computed on the device (mvlt_pack_plan, no host sync).
+    -> (row_start i32 [B], seq_len i32 [B], total i32 [1], row_start i64 [B], text_row i64 [B*T])"""
+    _need_cuda(text_ids)
+    assert text_ids.dtype == torch.int64 and text_ids.is_contiguous() and text_ids.dim() == 2
+    B, T = text_ids.shape
+    if labels is not None:
+        assert labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == B * T
+    dev = text_ids.device
+    i32buf = torch.empty(2 * B + 1, dtype=torch.int32, device=dev)
+    i64buf = torch.empty(B + B * T, dtype=torch.int64, device=dev)
+    rs, sl, tot = i32buf[:B], i32buf[B:2 * B], i32buf[2 * B:]
+    rs64, trow = i64buf[:B], i64buf[B:]
+    L.check(L.lib().mvlt_pack_plan(_p(text_ids), _p(labels), B, T, n_img, _p(rs), _p(sl), _p(tot), _p(rs64), _p(trow),
+                                   _stream()), "mvlt_pack_plan")
+    return rs, sl, tot, rs64, trow
 
 
 def _embed_struct(dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_id, pos_offset, type_override):

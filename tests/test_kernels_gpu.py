@@ -610,3 +610,75 @@ def test_gemm_plan_introspection(ops):
     bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
     assert L.lib().mvlt_gemm_plan(C.byref(p), C.byref(bm), C.byref(bn), C.byref(sp)) == 0
     assert (bm.value, bn.value) in ((64, 128), (128, 128)) and sp.value >= 1
+
+
+# ------------------------------------------------------------------ ragged batches planned on the device
+def test_pack_plan_matches_host_statement(ops):
+    """mvlt_pack_plan against the plain statement of its contract (INT: bit-exact)."""
+    torch.manual_seed(5)
+    B, T, n_img = 7, 19, 49
+    ids = torch.randint(1, 50, (B, T))
+    lab = torch.full((B, T), -100)
+    for b, ln in enumerate((0, 19, 5, 1, 18, 7, 3)):
+        ids[b, ln:] = 0
+    ids[2, 1] = 0
+    lab[5, 9] = 3                                   # label beyond the last non-zero id
+    rs, sl, tot, rs64, trow = ops.pack_plan(ids.cuda(), lab.cuda(), n_img)
+    keep = (ids != 0) | (lab >= 0)
+    lens = torch.tensor([int(keep[b].nonzero().max()) + 1 if keep[b].any() else 0 for b in range(B)])
+    want_sl = lens + n_img + 2
+    want_rs = torch.cumsum(want_sl, 0) - want_sl
+    assert torch.equal(sl.cpu().long(), want_sl) and torch.equal(rs.cpu().long(), want_rs)
+    assert int(tot.item()) == int(want_sl.sum()) and torch.equal(rs64.cpu(), want_rs)
+    t = torch.arange(T)[None, :]
+    want_row = torch.where(t < lens[:, None], want_rs[:, None] + n_img + 2 + t, want_rs[:, None].expand(B, T))
+    assert torch.equal(trow.cpu().view(B, T), want_row)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_device_row_count_gemm_and_layernorm(ops, dt):
+    """MvltGemm.m_dev / MvltLayerNorm.rows_dev: the launch is sized for the upper bound, the kernels read the real row
+    count from device memory.  Rows beyond it are poisoned with NaN (never read) and the outputs beyond it keep their
+    sentinel (never written)."""
+    Mx, N, K, R = 333, 192, 256, 200
+    rd = torch.tensor([R], dtype=torch.int32).cuda()
+    a = rnd((Mx, K), dt, 1); w = rnd((N, K), dt, 2, K ** -0.5); bias = torch.randn(N).cuda()
+    a[R:] = float("nan")
+    out = torch.full((Mx, N), 7.0, dtype=dt, device="cuda")
+    ops.gemm(a, w, bias=bias, out=out, m_dev=rd)
+    ref = a[:R].float() @ w.float().t() + bias
+    assert rel(out[:R], ref) < tol(dt) and bool((out[R:] == 7.0).all())
+    # dgrad layout (B k-major)
+    wk = rnd((K, N), dt, 3, K ** -0.5)
+    out.fill_(7.0)
+    ops.gemm(a, wk, b_kmajor=True, out=out, m_dev=rd)
+    assert rel(out[:R], a[:R].float() @ wk.float()) < tol(dt) and bool((out[R:] == 7.0).all())
+    # weight gradient: the reduction stops at the device count (single product and grouped launch)
+    dy = rnd((Mx, N), dt, 4); dy[R:] = float("nan")
+    dw = torch.empty((N, K), device="cuda"); db = torch.empty(N, device="cuda")
+    ops.gemm(dy, a, a_kmajor=True, b_kmajor=True, out=dw, out_f32=True, a_colsum=db, m_dev=rd)
+    assert rel(dw, dy[:R].float().t() @ a[:R].float()) < tol(dt) and rel(db, dy[:R].float().sum(0)) < tol(dt)
+    big_dy = rnd((Mx, 768), dt, 5); big_dy[R:] = float("nan")
+    big_x = rnd((Mx, 768), dt, 6); big_x[R:] = float("nan")
+    items = [(big_dy, big_x, torch.empty((768, 768), device="cuda"), torch.empty(768, device="cuda"), rd) for _ in range(3)]
+    ops.wgrad_group(items)
+    for it in items:
+        assert rel(it[2], big_dy[:R].float().t() @ big_x[:R].float()) < tol(dt)
+        assert rel(it[3], big_dy[:R].float().sum(0)) < tol(dt)
+    # LayerNorm forward / backward
+    C_ = 256
+    x = rnd((Mx, C_), dt, 7); x[R:] = float("nan")
+    g = (1.0 + 0.1 * torch.randn(C_)).cuda(); b = (0.1 * torch.randn(C_)).cuda()
+    y = torch.full((Mx, C_), 7.0, dtype=dt, device="cuda")
+    _, mean, rstd, _ = ops.layernorm_fwd(x, g, b, 1e-5, out=y, rows_dev=rd)
+    yr = torch.nn.functional.layer_norm(x[:R].float(), (C_,), g, b, 1e-5)
+    assert rel(y[:R], yr) < tol(dt) and bool((y[R:] == 7.0).all())
+    dyl = rnd((Mx, C_), dt, 8); dyl[R:] = float("nan")
+    dg, dbt = torch.empty(C_, device="cuda"), torch.empty(C_, device="cuda")
+    dx = torch.full((Mx, C_), 7.0, dtype=dt, device="cuda")
+    ops.layernorm_bwd(dyl, x, mean, rstd, g, dg, dbt, dx=dx, rows_dev=rd)
+    xr = x[:R].float().requires_grad_(True)
+    gr = g.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (C_,), gr, br, 1e-5).backward(dyl[:R].float())
+    t = tol(dt) * 2
+    assert rel(dx[:R], xr.grad) < t and rel(dg, gr.grad) < t and rel(dbt, br.grad) < t and bool((dx[R:] == 7.0).all())

@@ -503,6 +503,7 @@ def test_packed_rows_give_the_dense_loss_and_gradients(M, specs, monkeypatch, na
     runs = []
     for tl in (None, lengths):
         model.zero_grad()
+        model.config.auto_pack_rows = False           # tl=None: every padded row computed, like the reference
         loss = model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda(), text_lengths=tl)
         loss.backward()
         torch.cuda.synchronize()
@@ -519,6 +520,43 @@ def test_packed_rows_give_the_dense_loss_and_gradients(M, specs, monkeypatch, na
     assert torch.isnan(model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda(), text_lengths=short))
 
 
+@pytest.mark.parametrize("name", ["seq2seq", "bidir"])
+@pytest.mark.parametrize("cap", [None, 6])
+def test_device_planned_packing_is_the_default_and_equals_the_dense_run(M, specs, monkeypatch, name, cap):
+    """model(image, ids, labels, itm) -- the reference signature, nothing else -- packs the batch with a plan computed
+    on the device (mvlt_pack_plan; kernels read the row count from device memory).  Loss and every gradient must
+    equal the run that computes all padded rows (config.auto_pack_rows = False).  Ragged edge cases: an empty
+    caption, a full-length one, a zero id INSIDE a caption, and a label sitting on a zero id in the padding."""
+    cfg = tiny_cfg(M, ITM_task=True)
+    cfg.ITM_task = True
+    cfg.mlm_max_labels_per_sample = cap
+    model = M.MVLBertForPretraining(cfg)
+    load_formula(model, specs["tiny_pretrain"])
+    model = M.set_compute_dtype(model.cuda().eval(), F32)
+    image, ids, labels, itm = synth_batch(6, 24, seed=47, vocab=3000)
+    ids[0] = 0; labels[0] = -100                                   # empty caption
+    ids[1] = torch.randint(1000, 3000, (24,)); ids[1, -1] = 104      # full length
+    ids[2, 2] = 0                                                  # a zero id inside the caption
+    n3 = int((ids[3] != 0).sum())
+    assert n3 < 22
+    labels[3, n3 + 1] = 1234                                       # a label on a padded (zero-id) position
+    monkeypatch.setattr(random, "random", lambda: 0.1 if name == "seq2seq" else 0.9)
+    runs = []
+    for auto in (False, True):
+        model.zero_grad()
+        model.config.auto_pack_rows = auto
+        loss = model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = runs
+    assert l0 == l0 and abs(l0 - l1) < 2e-6 * abs(l0), (l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 150
+    bad = [(k, rel_err(g1[k], g0[k])) for k in g0
+           if rel_err(g1[k], g0[k]) > 2e-4 and not k.endswith("key.bias") and g0[k].abs().max() > 1e-9]
+    assert not bad, bad[:10]
+
+
 def test_packed_rows_full_size_bf16(M, monkeypatch):
     """Swin-S + BERT-base, B=8, bf16, eval mode: packed vs dense loss."""
     from mvlt_amd.train import synthetic_batch
@@ -530,9 +568,13 @@ def test_packed_rows_full_size_bf16(M, monkeypatch):
     batch = synthetic_batch(8, 80, "cuda", 77, with_lengths=True)
     monkeypatch.setattr(random, "random", lambda: 0.9)
     with torch.no_grad():
+        model.config.auto_pack_rows = False
         dense = model(*batch[:4]).item()
         packed = model(*batch[:4], text_lengths=batch[4]).item()
+        model.config.auto_pack_rows = True
+        auto = model(*batch[:4]).item()                # the default: plan computed on the device
     assert abs(dense - packed) < 3e-3 * abs(dense), (dense, packed)
+    assert abs(dense - auto) < 3e-3 * abs(dense), (dense, auto)
 
 
 @pytest.mark.parametrize("graph", ["1", "0"])
