@@ -137,6 +137,7 @@ def test_tiny_train_mode_matches_oracle_with_same_masks(M, specs):
     from mvlt_amd import ops
     cfg = tiny_cfg(M, ITM_task=True)
     cfg.ITM_task = True
+    cfg.auto_pack_rows = False      # the oracle is fed the dropout masks of the DENSE row layout (mask index = row * N + col)
     model = M.MVLBertForPretraining(cfg)
     sd = load_formula(model, specs["tiny_pretrain"])
     model = M.set_compute_dtype(model.cuda().train(), F32)
