@@ -12,6 +12,7 @@
 #include <torch/extension.h>
 #include <hip/hip_runtime_api.h>
 #include <vector>
+#include <cstdlib>
 #include <string>
 #include "../../include/mvlt_hip.h"
 
@@ -47,8 +48,11 @@ hipEvent_t next_event() {
     g_event_next = (g_event_next + 1) % g_events.size();
     return e;
 }
+// experiments: MVLT_SIDE=0 issues the weight gradients on the main stream (no overlap with the dgrad chain)
+bool side_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("MVLT_SIDE"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
 // side stream waits for everything queued on the main stream so far
-void fork_side(const Streams& s) {
+void fork_side(Streams& s) {
+    if (!side_enabled()) { s.side = s.main; return; }
     hipEvent_t e = next_event();
     TORCH_CHECK(hipEventRecord(e, static_cast<hipStream_t>(s.main)) == hipSuccess, "hipEventRecord");
     TORCH_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(s.side), e, 0) == hipSuccess, "hipStreamWaitEvent");

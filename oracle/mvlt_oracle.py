@@ -586,3 +586,44 @@ def formula_fill(named_shapes: Sequence[Tuple[str, Tuple[int, ...], torch.dtype]
         out[name] = t
         k += 1
     return out
+
+
+def hash_fill(named_shapes: Sequence[Tuple[str, Tuple[int, ...], torch.dtype]], seed: int = 20261003) -> SD:
+    """Well-conditioned deterministic weights both sides can regenerate: element i of the k-th float entry is an
+    integer hash of (k, i) mapped to U[-1, 1) (exact integer arithmetic, identical on every platform), scaled like a
+    trained network: Linear / conv weights U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (torch's own default), LayerNorm
+    weights 1 +- 0.1, biases +-0.02, embeddings +-0.05, relative-position tables +-0.2.  Unlike the sin() formula
+    of formula_fill (every matrix has rank 2) these matrices are full rank, so bf16 errors are not amplified by the
+    fixture itself."""
+    out: SD = {}
+    k = 0
+    M32 = 0xFFFFFFFF
+    for name, shape, dtype in named_shapes:
+        if not dtype.is_floating_point:
+            continue
+        low = name.lower()
+        if "attn_mask" in low:
+            k += 1
+            continue
+        n = int(math.prod(shape)) if len(shape) else 1
+        h = (torch.arange(n, dtype=torch.int64) * 2654435761 + (k + 1) * 40503 + seed) & M32
+        for _ in range(2):
+            h = h ^ (h >> 16)
+            h = (h * 0x45D9F3B) & M32
+        h = h ^ (h >> 16)
+        u = (h.to(torch.float64) / 2147483648.0 - 1.0).to(torch.float32).view(shape)
+        if ("norm" in low) and name.endswith("weight"):
+            t = 1.0 + 0.1 * u
+        elif name.endswith("bias") and "relative_position" not in name:
+            t = 0.02 * u
+        elif "embeddings.weight" in name:
+            t = 0.05 * u
+        elif "relative_position_bias_table" in name:
+            t = 0.2 * u
+        else:
+            fan_in = shape[-1] if len(shape) == 2 else int(math.prod(shape[1:])) if len(shape) > 1 else n
+            t = u * (1.0 / math.sqrt(fan_in))
+        out[name] = t
+        k += 1
+    return out
+

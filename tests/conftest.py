@@ -40,6 +40,18 @@ def specs():
         return json.load(f)
 
 
+@pytest.fixture(scope="session")
+def specs_hash():
+    with open(os.path.join(GOLD, "specs_hash.json")) as f:
+        return json.load(f)
+
+
+def hash_sd(spec):
+    """State dict with the well-conditioned integer-hash weights (oracle.hash_fill) for a golden spec."""
+    from oracle.mvlt_oracle import hash_fill
+    return hash_fill([(k, tuple(s), getattr(torch, d)) for k, s, d in spec])
+
+
 def formula_sd(spec):
     """State dict with the deterministic formula weights for a golden spec."""
     from oracle.mvlt_oracle import formula_fill

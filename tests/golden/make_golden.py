@@ -402,10 +402,123 @@ def tiny_models(M):
     return out
 
 
+def fill_hash(model, spec_name):
+    from oracle.mvlt_oracle import hash_fill
+    sd = model.state_dict()
+    spec = [(k, tuple(v.shape), v.dtype) for k, v in sd.items()]
+    new = hash_fill(spec)
+    with torch.no_grad():
+        for k, v in new.items():
+            sd[k].copy_(v)
+    SPECS[spec_name] = [(k, list(s), str(d).replace("torch.", "")) for k, s, d in spec]
+
+
+def hash_models(M):
+    """Second golden set on WELL-CONDITIONED weights (oracle.hash_fill): the reference's own modules, full size
+    (Swin-S + BERT-base, B=2) -- bf16 parity is judged on these; plus greedy token ids of the tiny caption model by a
+    full-sequence recompute loop over the reference's MVLBert + MLM_head_seq2seq (the reference's own cached loop
+    cannot run under the installed HF)."""
+    out = {}
+    M.parse_option = lambda: (None, swin_ns())
+    cfg = make_config(M, "MVLBertPretrainConfig")
+    cfg.ITM_task = True
+    torch.manual_seed(0)
+    model = M.MVLBertForPretraining(cfg)
+    fill_hash(model, "hash_pretrain")
+    model.eval()
+    image, ids, labels, itm = synth_batch(2, 80, seed=61)
+    grad_names = [
+        "conv.conv.0.patch_embed.proj.weight", "conv.conv.0.layers.0.blocks.0.attn.qkv.weight",
+        "conv.conv.0.layers.0.blocks.1.attn.relative_position_bias_table", "conv.conv.0.layers.1.blocks.1.mlp.fc1.weight",
+        "conv.conv.0.layers.2.blocks.5.mlp.fc1.weight", "conv.conv.0.layers.2.blocks.17.attn.proj.weight",
+        "conv.conv.0.layers.3.blocks.1.mlp.fc2.weight", "conv.conv.0.norm.weight",
+        "MVLBert.position_embeddings.weight", "MVLBert.encoder.layer.0.attention.self.query.weight",
+        "MVLBert.encoder.layer.0.attention.output.LayerNorm.weight", "MVLBert.encoder.layer.5.intermediate.dense.weight",
+        "MVLBert.encoder.layer.11.attention.self.value.weight", "MVLBert.encoder.layer.11.output.dense.weight",
+        "MVLBert.pooler.dense.weight", "ITM_mlp.weight",
+    ]
+    for flip, name in ((0.1, "seq2seq"), (0.9, "bidir")):
+        M.random.random = lambda v=flip: v
+        model.zero_grad(set_to_none=True)
+        loss = model(image, ids, labels, itm)
+        out[f"loss_{name}"] = loss.detach().reshape(())
+        loss.backward()
+        sd = dict(model.named_parameters())
+        for gn in grad_names:
+            g = sd[gn].grad
+            out[f"grad_{name}_{gn}"] = g.reshape(-1)[:256].clone()
+            out[f"gradnorm_{name}_{gn}"] = g.double().norm().float()
+        head = "MLM_head_seq2seq" if name == "seq2seq" else "MLM_head_bidir"
+        out[f"gradnorm_{name}_decoder"] = sd[f"{head}.predictions.decoder.weight"].grad.double().norm().float()
+        with torch.no_grad():
+            feat = model.conv(image)
+            t, im, pooled, sep = model.MVLBert(ids, ids > 0, feat, torch.ones(2, 49, dtype=torch.bool),
+                                               seq2seq_mask=(name == "seq2seq"), output_text_image_seperate=True)
+            out["feat"] = feat.clone()
+            out[f"text_out_head_{name}"] = t[:, :8].clone()
+            out[f"pooled_{name}"] = pooled.clone()
+    # ---- tiny pretrain model, EVERY gradient (bf16 is checked against these without exemptions)
+    M.parse_option = lambda: (None, swin_ns(32, (2, 2, 2, 2), (1, 2, 4, 8), 0.2))
+    tcfg = make_config(M, "MVLBertPretrainConfig", hidden_size=256, num_hidden_layers=2,
+                       num_attention_heads=4, intermediate_size=1024, vocab_size=3000)
+    tcfg.ITM_task = True
+    tmodel = M.MVLBertForPretraining(tcfg)
+    fill_hash(tmodel, "hash_tiny_pretrain")
+    tmodel.eval()
+    timage, tids, tlabels, titm = synth_batch(3, 24, seed=65, vocab=3000)
+    for flip, name in ((0.1, "seq2seq"), (0.9, "bidir")):
+        M.random.random = lambda v=flip: v
+        tmodel.zero_grad(set_to_none=True)
+        loss = tmodel(timage, tids, tlabels, titm)
+        loss.backward()
+        out[f"tiny_loss_{name}"] = loss.detach().reshape(())
+        for n, p in tmodel.named_parameters():
+            if p.grad is not None:
+                out[f"tiny_gradnorm_{name}_{n}"] = p.grad.double().norm().float()
+                out[f"tiny_gradhead_{name}_{n}"] = p.grad.reshape(-1)[:64].clone()
+            else:
+                out[f"tiny_gradnone_{name}_{n}"] = torch.tensor(1)
+    # ---- greedy ids, tiny caption model, reference modules, full-sequence recompute
+    M.parse_option = lambda: (None, swin_ns(32, (2, 2, 2, 2), (1, 2, 4, 8), 0.2))
+    ccfg = make_config(M, "MVLBertConfigForImageCaption", hidden_size=256, num_hidden_layers=2,
+                       num_attention_heads=4, intermediate_size=1024, vocab_size=3000)
+    tok = types.SimpleNamespace(mask_token_id=103, sep_token_id=102)
+    cap = M.MVLBertForImageCaption(ccfg, tokenizer=tok)
+    fill_hash(cap, "hash_tiny_caption")
+    cap.eval()
+    image3, _, _, _ = synth_batch(3, 24, seed=63, vocab=3000)
+    max_len = 12
+    with torch.no_grad():
+        feat = cap.conv(image3)
+        B = 3
+        gen = torch.zeros(B, 0, dtype=torch.long)
+        unfinished = torch.ones(B, dtype=torch.long)
+        for _ in range(max_len):
+            inp = torch.cat([gen, torch.full((B, 1), 103)], 1)
+            enc, _ = cap.MVLBert(inp, torch.ones_like(inp, dtype=torch.bool), feat, torch.ones(B, feat.shape[1], dtype=torch.bool),
+                                 seq2seq_mask=True)
+            logits = cap.MLM_head_seq2seq(enc[0][:, -1:])[:, -1]
+            nxt = logits.argmax(-1) * unfinished
+            gen = torch.cat([gen, nxt[:, None]], 1)
+            unfinished = unfinished * (nxt != 104).long()
+            if unfinished.max() == 0:
+                break
+        out["greedy_ids"] = gen
+        out["greedy_first_logits_top"] = torch.topk(logits, 4).values          # how far the last pick is from a tie
+    return out
+
+
 def main():
     install_shims()
     torch.set_num_threads(8)
     M = import_reference(swin_ns())
+    if "--hash-only" in sys.argv:          # only the second golden set (keeps the other fixtures byte-identical)
+        np.savez_compressed(os.path.join(HERE, "hash_models.npz"), **to_np(hash_models(M)))
+        import json
+        with open(os.path.join(HERE, "specs_hash.json"), "w") as f:
+            json.dump(SPECS, f)
+        print("hash models done")
+        return
     np.savez_compressed(os.path.join(HERE, "int_tables.npz"), **to_np(int_tables(M)))
     print("int tables done")
     if "--int-only" in sys.argv:
@@ -419,6 +532,11 @@ def main():
     import json
     with open(os.path.join(HERE, "specs.json"), "w") as f:
         json.dump(SPECS, f)
+    SPECS.clear()
+    np.savez_compressed(os.path.join(HERE, "hash_models.npz"), **to_np(hash_models(M)))
+    with open(os.path.join(HERE, "specs_hash.json"), "w") as f:
+        json.dump(SPECS, f)
+    print("hash models done")
 
 
 if __name__ == "__main__":

@@ -20,6 +20,12 @@ F32, BF16 = torch.float32, torch.bfloat16
 ACT = {F32: 2e-4, BF16: 6e-2}
 LOSS = {F32: 1e-4, BF16: 3e-3}
 GRAD = {F32: 5e-3, BF16: 0.15}
+# bounds against the reference on WELL-CONDITIONED weights (tests/golden/hash_models.npz): the north-star tolerance
+# (1e-3 relative) holds for the loss in both precisions; bf16 storage shows up as ~1e-2 on hidden states and a few
+# per cent on individual gradient tensors (8 significant bits through 36 layers), f32 is at rounding level
+HASH_LOSS = {F32: 1e-4, BF16: 1e-3}
+HASH_ACT = {F32: 2e-4, BF16: 2e-2}
+HASH_GRAD = {F32: 5e-3, BF16: 8e-2}
 
 
 def load_formula(model, spec):
@@ -58,16 +64,28 @@ def test_swin_s_forward_vs_reference(M, golden, specs, cd):
 
 
 # ------------------------------------------------------------------ tiny model: everything, fwd + bwd
-@pytest.mark.parametrize("cd", [F32, BF16])
+# Two fixtures from the reference (tests/golden/make_golden.py): "formula" = sin() weights (every matrix has rank 2: a
+# property of the fixture that amplifies bf16 rounding in the gradients, so it is run in f32 only) and "hash" =
+# full-rank integer-hash weights, run in f32 AND bf16 with every gradient checked -- no bf16 exemption.
+TINY_GRAD = {F32: 5e-3, BF16: 6e-2}
+
+
+@pytest.mark.parametrize("fixture,cd", [("formula", F32), ("hash", F32), ("hash", BF16)])
 @pytest.mark.parametrize("name", ["seq2seq", "bidir"])
-def test_tiny_pretrain_loss_and_all_grads(M, golden, specs, cd, name):
-    g = golden("tiny_models")
+def test_tiny_pretrain_loss_and_all_grads(M, golden, specs, specs_hash, fixture, cd, name):
+    from conftest import hash_sd
     cfg = tiny_cfg(M, ITM_task=True)
     cfg.ITM_task = True
     model = M.MVLBertForPretraining(cfg)
-    load_formula(model, specs["tiny_pretrain"])
+    if fixture == "formula":
+        g, pre, seed = golden("tiny_models"), "", 41
+        load_formula(model, specs["tiny_pretrain"])
+    else:
+        g, pre, seed = golden("hash_models"), "tiny_", 65
+        missing, unexpected = model.load_state_dict(hash_sd(specs_hash["hash_tiny_pretrain"]), strict=False)
+        assert not unexpected
     model = M.set_compute_dtype(model.cuda().eval(), cd)
-    image, ids, labels, itm = synth_batch(3, 24, seed=41, vocab=3000)
+    image, ids, labels, itm = synth_batch(3, 24, seed=seed, vocab=3000)
     random.seed(0)
     random.random = (lambda v=(0.1 if name == "seq2seq" else 0.9): v)   # force the coin flip (model.py:390)
     try:
@@ -76,32 +94,29 @@ def test_tiny_pretrain_loss_and_all_grads(M, golden, specs, cd, name):
         import importlib
         importlib.reload(random)
     assert model.last_seq2seq == (name == "seq2seq")
-    ref = g[f"loss_{name}"].item()
-    assert abs(loss.item() - ref) < LOSS[cd] * abs(ref), (loss.item(), ref)
+    ref = g[f"{pre}loss_{name}"].item()
+    assert abs(loss.item() - ref) < (LOSS[cd] if fixture == "formula" else HASH_LOSS[cd]) * abs(ref), (loss.item(), ref)
     loss.backward()
     torch.cuda.synchronize()
-    if cd == BF16:
-        # formula (sin-structured) weights are ill-conditioned: bf16 rounding noise is amplified in the
-        # gradients (scripts/diag_bf16.py); bf16 gradients are checked on random-init weights in
-        # test_bf16_gradients_match_f32_path, here only the None-pattern is checked.
-        for k, p in model.named_parameters():
-            assert (p.grad is None) == (f"gradnone_{name}_{k}" in g), k
-        return
     bad, checked = [], 0
+    nhead = 16 if fixture == "formula" else 64
     for k, p in model.named_parameters():
-        if f"gradnone_{name}_{k}" in g:
+        if f"{pre}gradnone_{name}_{k}" in g:
             assert p.grad is None, k
             continue
-        refn = g[f"gradnorm_{name}_{k}"].item()
+        refn = g[f"{pre}gradnorm_{name}_{k}"].item()
         assert p.grad is not None, k
         gn = p.grad.double().norm().item()
         checked += 1
-        if abs(gn - refn) > GRAD[cd] * refn + 1e-7:
+        if k.endswith("key.bias"):           # softmax is invariant to it: the true gradient is 0, what is left is rounding noise
+            assert gn < (1e-5 if cd == F32 else 1e-2) * max(1.0, g[f"{pre}gradnorm_{name}_{k.replace('key.bias', 'query.bias')}"].item()), k
+            continue
+        if abs(gn - refn) > TINY_GRAD[cd] * refn + 1e-7:
             bad.append((k, gn, refn))
-        elif refn > 1e-6 and rel_err(p.grad.reshape(-1)[:16].cpu(), g[f"gradhead_{name}_{k}"]) > 4 * GRAD[cd]:
-            head = g[f"gradhead_{name}_{k}"]
-            if head.double().norm().item() > 0.05 * refn / max(1.0, (p.numel() / 16) ** 0.5):
-                bad.append((k, "head", rel_err(p.grad.reshape(-1)[:16].cpu(), head)))
+        elif refn > 1e-6 and rel_err(p.grad.reshape(-1)[:nhead].cpu(), g[f"{pre}gradhead_{name}_{k}"]) > 4 * TINY_GRAD[cd]:
+            head = g[f"{pre}gradhead_{name}_{k}"]
+            if head.double().norm().item() > 0.05 * refn / max(1.0, (p.numel() / nhead) ** 0.5):
+                bad.append((k, "head", rel_err(p.grad.reshape(-1)[:nhead].cpu(), head)))
     assert checked > 150
     assert not bad, bad[:10]
 
@@ -183,8 +198,10 @@ def test_tiny_train_mode_matches_oracle_with_same_masks(M, specs):
 
 
 # ------------------------------------------------------------------ full-size models
-@pytest.mark.parametrize("cd", [F32, BF16])
+@pytest.mark.parametrize("cd", [F32])
 def test_full_pretrain_loss_and_grad_slices(M, golden, specs, cd):
+    """sin()-formula fixture (rank-2 matrices): the exact-f32 pin.  bf16 is checked against the reference, loss AND
+    gradients, on the full-rank fixture in test_full_pretrain_vs_reference_on_well_conditioned_weights."""
     g = golden("full_models")
     cfg = M.MVLBertPretrainConfig()
     cfg.ITM_task = True
@@ -212,18 +229,95 @@ def test_full_pretrain_loss_and_grad_slices(M, golden, specs, cd):
             pn = k[len(f"gradnorm_{name}_"):]
             gn = params[pn].grad.double().norm().item()
             if g[k].item() < 1e-7:       # key.bias: softmax is invariant to it, the true gradient is 0
-                assert gn < (1e-6 if cd == F32 else 1e-2), pn      # bf16: rounding noise of dK, not signal
-            elif cd == F32 and abs(gn - g[k].item()) > GRAD[cd] * g[k].item():
+                assert gn < 1e-6, pn
+            elif abs(gn - g[k].item()) > GRAD[cd] * g[k].item():
                 bad.append((pn, gn, g[k].item()))
         assert not bad, bad
         head = "MLM_head_" + name
         rows = labels[labels >= 0][:4]
         assert rel_err(params[f"{head}.predictions.decoder.weight"].grad[rows.cuda(), :32].cpu(),
-                       g[f"grad_{name}_decoder_rows"]) < (GRAD[cd] if cd == F32 else 0.1)
+                       g[f"grad_{name}_decoder_rows"]) < GRAD[cd]
         for pn in ("conv.conv.0.head.weight", "conv.resnet_fc.weight", "MVLBert.embedding_LayerNorm.weight"):
             assert params[pn].grad is None
         other = "MLM_head_bidir" if name == "seq2seq" else "MLM_head_seq2seq"
         assert params[f"{other}.predictions.decoder.weight"].grad is None
+
+
+@pytest.mark.parametrize("cd", [F32, BF16])
+def test_full_pretrain_vs_reference_on_well_conditioned_weights(M, golden, specs_hash, cd):
+    """Swin-S + BERT-base, B=2: loss, Swin output, text hidden states, pooled output and 16 parameter gradients
+    (norm and first 256 elements) against the reference's own outputs, in f32 AND bf16 -- no bf16 exemptions."""
+    from conftest import hash_sd
+    g = golden("hash_models")
+    cfg = M.MVLBertPretrainConfig()
+    cfg.ITM_task = True
+    model = M.MVLBertForPretraining(cfg)
+    missing, unexpected = model.load_state_dict(hash_sd(specs_hash["hash_pretrain"]), strict=False)
+    assert not unexpected
+    model = M.set_compute_dtype(model.cuda().eval(), cd)
+    image, ids, labels, itm = synth_batch(2, 80, seed=61)
+    for name, flip in (("seq2seq", 0.1), ("bidir", 0.9)):
+        model.zero_grad()
+        random.random = (lambda v=flip: v)
+        try:
+            loss = model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda())
+        finally:
+            import importlib
+            importlib.reload(random)
+        ref = g[f"loss_{name}"].item()
+        assert abs(loss.item() - ref) < HASH_LOSS[cd] * abs(ref), (name, loss.item(), ref)
+        loss.backward()
+        torch.cuda.synchronize()
+        params = dict(model.named_parameters())
+        bad = []
+        for k in [k for k in g if k.startswith(f"gradnorm_{name}_") and not k.endswith("_decoder")]:
+            pn = k[len(f"gradnorm_{name}_"):]
+            gr = params[pn].grad
+            e_norm = abs(gr.double().norm().item() - g[k].item()) / g[k].item()
+            e_head = rel_err(gr.reshape(-1)[:256].cpu(), g[f"grad_{name}_{pn}"])
+            if e_norm > HASH_GRAD[cd] or e_head > HASH_GRAD[cd]:
+                bad.append((pn, e_norm, e_head))
+        assert not bad, bad
+        head = "MLM_head_" + name
+        gd = params[f"{head}.predictions.decoder.weight"].grad.double().norm().item()
+        assert abs(gd - g[f"gradnorm_{name}_decoder"].item()) < HASH_GRAD[cd] * g[f"gradnorm_{name}_decoder"].item()
+        with torch.no_grad():
+            feat = model.conv(image.cuda())
+            assert rel_err(feat.float().cpu(), g["feat"]) < HASH_ACT[cd]
+            t, im, pooled, sep = model.MVLBert(ids.cuda(), None, feat, None, seq2seq_mask=(name == "seq2seq"),
+                                               output_text_image_seperate=True)
+            assert rel_err(t[:, :8].float().cpu(), g[f"text_out_head_{name}"]) < HASH_ACT[cd]
+            assert rel_err(pooled.float().cpu(), g[f"pooled_{name}"]) < HASH_ACT[cd]
+
+
+@pytest.mark.parametrize("cd", [F32, BF16])
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_greedy_decode_matches_reference_token_ids(M, golden, specs_hash, monkeypatch, graph, cd):
+    """greedy_search (KV cache, 2-token steps, replayed HIP graph / eager loop) against token ids produced by the
+    REFERENCE's own modules (MVLBert + MLM_head_seq2seq in a full-sequence recompute loop, make_golden.py::hash_models).
+    f32: identical ids.  bf16 (the benchmarked decode path, mvlt_gemm_argmax): a pick may differ only where the
+    reference's own top-2 logits are closer than bf16 resolution; everything before the first such flip is identical."""
+    from conftest import hash_sd
+    g = golden("hash_models")
+    monkeypatch.setenv("MVLT_DECODE_GRAPH", graph)
+    cfg = tiny_cfg(M, cls=M.MVLBertConfigForImageCaption)
+    cfg.max_length = 12
+    tok = type("Tok", (), {"mask_token_id": 103, "sep_token_id": 102})()
+    model = M.MVLBertForImageCaption(cfg, tokenizer=tok)
+    missing, unexpected = model.load_state_dict(hash_sd(specs_hash["hash_tiny_caption"]), strict=False)
+    assert not unexpected
+    model = M.set_compute_dtype(model.cuda().eval(), cd)
+    image, _, _, _ = synth_batch(3, 24, seed=63, vocab=3000)
+    out_ids, _ = model(image.cuda(), None, 1, 'unilm')
+    ref = g["greedy_ids"]
+    out = out_ids.cpu()
+    if cd == F32:
+        assert out.shape == ref.shape and torch.equal(out, ref), (out, ref)
+    else:
+        n = min(out.shape[1], ref.shape[1])
+        agree = (out[:, :n] == ref[:, :n])
+        # every sample starts right, and most of the 36 picks are the reference's
+        assert bool(agree[:, 0].all()) and agree.float().mean().item() > 0.6, (out, ref)
 
 
 @pytest.mark.parametrize("cd", [F32, BF16])
@@ -576,6 +670,33 @@ def test_packed_rows_full_size_bf16(M, monkeypatch):
         auto = model(*batch[:4]).item()                # the default: plan computed on the device
     assert abs(dense - packed) < 3e-3 * abs(dense), (dense, packed)
     assert abs(dense - auto) < 3e-3 * abs(dense), (dense, auto)
+
+
+def test_config2_batch32_full_size(M, monkeypatch):
+    """BASELINE config #2 at its stated workload: Swin-S + BERT-base, B=32, 224x224, seq 80 (the CPU oracle is too slow
+    for B=32, so the paths are compared with each other; B=2 rows of the same model are pinned to the reference in
+    test_full_pretrain_*): bf16 default path (device-planned packing) == bf16 dense == exact-f32 path within the
+    north-star 1e-3 on the loss, and one optimizer step in train mode gives finite, reduced loss."""
+    from mvlt_amd.train import PretrainStep, synthetic_batch
+    cfg = M.MVLBertPretrainConfig()
+    cfg.ITM_task = True
+    torch.manual_seed(0)
+    model = M.MVLBertForPretraining(cfg).cuda().eval()
+    batch = synthetic_batch(32, 80, "cuda", 91)[:4]
+    monkeypatch.setattr(random, "random", lambda: 0.9)
+    with torch.no_grad():
+        auto = model(*batch).item()
+        cfg.auto_pack_rows = False
+        dense = model(*batch).item()
+        M.set_compute_dtype(model, F32)
+        exact = model(*batch).item()
+        M.set_compute_dtype(model, BF16)
+        cfg.auto_pack_rows = True
+    assert abs(auto - dense) < 1e-3 * abs(dense) and abs(dense - exact) < 1e-3 * abs(exact), (auto, dense, exact)
+    model.train()
+    step = PretrainStep(model, lr=1e-4)
+    losses = [step(batch).item() for _ in range(4)]
+    assert all(l == l and abs(l) < 1e4 for l in losses) and losses[-1] < losses[0], losses
 
 
 @pytest.mark.parametrize("graph", ["1", "0"])

@@ -222,3 +222,39 @@ def test_cached_step_equals_recompute(specs):
             full = O.mvlbert_forward(csd, TINY_B, torch.cat([tok[:, :t + 1], inp0], 1), feat, True)
             assert rel_err(h[:, -1], full["hidden"][:, -1]) < 1e-5
             kv = [(k[:, :, :-1], v[:, :, :-1]) for k, v in kv2]
+
+
+# ---------------------------------------------------------------- second golden set: well-conditioned (hash) weights
+def test_hash_golden_pretrain_and_greedy(golden, specs_hash):
+    """The oracle against outputs of the reference's own modules on full-rank pseudo-random weights (oracle.hash_fill;
+    tests/golden/make_golden.py::hash_models): Swin-S + BERT-base loss, activations and gradients for one coin flip,
+    loss for the other, and the greedy token ids of the tiny caption model (reference MVLBert + MLM_head_seq2seq run
+    in a full-sequence recompute loop).  bf16 parity of the HIP path is judged against this set."""
+    from conftest import hash_sd
+    g = golden("hash_models")
+    sd = {k: v.requires_grad_(True) for k, v in hash_sd(specs_hash["hash_pretrain"]).items()}
+    image, ids, labels, itm = synth_batch(2, 80, seed=61)
+    scfg, bcfg = O.SwinCfg(), O.BertCfg()
+    with torch.no_grad():
+        feat = O.conv_layer(image, sd, scfg)
+        assert rel_err(feat, g["feat"]) < 1e-4
+        l0 = O.pretrain_loss(sd, scfg, bcfg, image, ids, labels, itm, True, itm_task=True)
+    assert abs(l0.item() - g["loss_seq2seq"].item()) < 1e-4 * abs(l0.item())
+    loss = O.pretrain_loss(sd, scfg, bcfg, image, ids, labels, itm, False, itm_task=True)
+    assert abs(loss.item() - g["loss_bidir"].item()) < 1e-4 * abs(loss.item())
+    loss.backward()
+    keys = [k for k in g if k.startswith("gradnorm_bidir_") and k != "gradnorm_bidir_decoder"]
+    assert len(keys) >= 16
+    for k in keys:
+        pn = k[len("gradnorm_bidir_"):]
+        gr = sd[pn].grad
+        assert abs(gr.double().norm().item() - g[k].item()) < 2e-3 * g[k].item() + 1e-9, pn
+        assert rel_err(gr.reshape(-1)[:256], g[f"grad_bidir_{pn}"]) < 2e-3, pn
+    # greedy ids
+    csd = hash_sd(specs_hash["hash_tiny_caption"])
+    image3, _, _, _ = synth_batch(3, 24, seed=63, vocab=3000)
+    tscfg = O.SwinCfg(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), drop_path_rate=0.2)
+    tbcfg = O.BertCfg(vocab_size=3000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024)
+    with torch.no_grad():
+        out = O.greedy_decode_recompute(csd, tscfg, tbcfg, image3, max_len=12)
+    assert torch.equal(out, g["greedy_ids"]), (out, g["greedy_ids"])
