@@ -207,7 +207,13 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     use_dist = world > 1 or os.environ.get("MVLT_FORCE_DDP") == "1"     # FORCE: exercise RCCL + reducer on 1 rank
+    real_stdout = None
     if use_dist:
+        # RCCL prints a version banner on stdout when the communicator is created; stdout must carry ONE JSON line,
+        # so file descriptor 1 points at stderr for the run and the line goes out through a saved duplicate
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -332,7 +338,11 @@ def main():
             out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+        if real_stdout is not None:
+            os.write(real_stdout, (line + "\n").encode())
+        else:
+            print(line, flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -115,13 +115,27 @@ class GradReducer:
             self.pending_hi = lo
 
     def _launch(self, arena: Arena, lo: int, hi: int) -> None:
+        fork = None
         if arena.flat.is_cuda:
             from . import ops
             ops.LnReduceQueue.flush_all()         # LayerNorm gamma/beta gradients are reduced in deferred batches
-            ops.join_side(arena.flat.device)      # weight gradients are produced on the side stream
+            # The bucket needs the dgrad chain (main stream) AND the weight gradients (side stream).  Joining the
+            # side stream into the MAIN stream here would stall the backward pass at every bucket; instead a
+            # helper stream waits for both and the collective is issued from it (RCCL's own stream then waits
+            # for the helper), so the main stream keeps running ahead.
+            fork = self.__dict__.get("_fork_stream")
+            if fork is None:
+                fork = self._fork_stream = torch.cuda.Stream(device=arena.flat.device)
+            fork.wait_stream(torch.cuda.current_stream())
+            fork.wait_stream(ops.side_stream(arena.flat.device))
         ranges = plan_ranges(arena, lo, hi, self.done)
         op = dist.ReduceOp.AVG if (self.average and self._avg_op) else dist.ReduceOp.SUM
-        if self.comm_dtype == torch.float32:
+        if self.comm_dtype == torch.float32 and fork is not None and self.on_bucket is None:
+            with torch.cuda.stream(fork):
+                hs = [dist.all_reduce(arena.grad[a:b], op=op, group=self.pg, async_op=True) for a, b in ranges]
+        elif self.comm_dtype == torch.float32:
+            if fork is not None:
+                torch.cuda.current_stream().wait_stream(ops.side_stream(arena.flat.device))
             hs = [dist.all_reduce(arena.grad[a:b], op=op, group=self.pg, async_op=True) for a, b in ranges]
         else:
             if self.on_bucket is not None:
@@ -129,6 +143,8 @@ class GradReducer:
             if self.comm_buf is None or self.comm_buf.numel() != arena.total:
                 self.comm_buf = torch.empty(arena.total, dtype=self.comm_dtype, device=arena.grad.device)
             hs = []
+            if fork is not None:
+                torch.cuda.current_stream().wait_stream(ops.side_stream(arena.flat.device))
             for a, b in ranges:
                 buf = self.comm_buf[a:b]
                 if arena.grad.is_cuda:
@@ -154,6 +170,9 @@ class GradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
+        if arena.flat.is_cuda:
+            from . import ops
+            ops.join_side(arena.flat.device)      # (also releases the tensors kept alive for the side stream)
         for a, b in self.pending_casts:          # compressed exchange: summed bf16 -> f32 gradient arena
             if arena.grad.is_cuda:
                 from . import ops
