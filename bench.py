@@ -175,6 +175,52 @@ def timed_run(step, batch, steps, use_dist, dist):
     return elapsed, loss
 
 
+def other_configs(M):
+    """BASELINE configs #4 and #5 at their stated sizes, one GPU, reported as extra keys of the same line (the
+    headline stays config #2).  #4: greedy report generation, Swin-S + BERT-base, B=32, max_length=150 (MIMIC-CXR
+    shape, run_report_generation_cxr.py:385-386), bf16, replayed HIP graph.  #5: Swin-B + BERT-base pretrain step,
+    per-GPU batch 8 (global 64 on 8 GPUs), seq 128."""
+    from mvlt_amd.train import PretrainStep, synthetic_batch
+    res = {}
+    torch.manual_seed(0)
+    cfg = M.MVLBertConfigForImageCaption()
+    cfg.max_length, cfg.eos_token_id = 150, None                      # fixed work: never stop early
+    tok = type("Tok", (), {"mask_token_id": 103, "sep_token_id": 102})()
+    cap = M.MVLBertForImageCaption(cfg, tokenizer=tok).cuda().eval()
+    img = torch.randn(32, 3, 224, 224, device="cuda")
+    for _ in range(2):
+        cap(img, None, 1, "unilm")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        ids, _ = cap(img, None, 1, "unilm")
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    res["config4_decode"] = {"workload": "greedy decode, Swin-S + BERT-base, B=32, max_length=150, bf16, KV cache, HIP graph replay",
+                             "ms_per_batch": round(dt * 1e3, 2), "reports_per_s": round(32 / dt, 1),
+                             "tokens_per_s": round(32 * ids.shape[1] / dt, 0),
+                             "us_per_2token_step": round(dt / ids.shape[1] * 1e6, 1),
+                             "hbm_floor_us_per_step": 54.0,
+                             "note": "floor = 217 MB of bf16 weights per step at 4 TB/s effective per step chain (SURVEY 8d); the step is "
+                                     "a chain of ~100 dependent small kernels, i.e. latency bound"}
+    del cap
+    c5 = M.MVLBertPretrainConfig().use_swin_base()
+    c5.ITM_task = True
+    m5 = M.MVLBertForPretraining(c5).cuda().train()
+    st5 = PretrainStep(m5)
+    b5 = synthetic_batch(8, 128, "cuda", 77)[:4]
+    for _ in range(4):
+        st5(b5)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        st5(b5)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    res["config5_swin_b"] = {"workload": "pretrain step (MLM+ITM), Swin-B [2,2,18,2] + added Linear(1024,768) + BERT-base, batch 8/GPU, seq 128, bf16",
+                             "ms_per_step": round(dt * 1e3, 3), "pairs_per_s": round(8 / dt, 1),
+                             "step_tflops_reference_equivalent": round(8 / dt * 206.1 / 1e3, 1)}
+    del m5, st5
+    torch.cuda.empty_cache()
+    return res
+
+
 def profiled_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (cannot be collected
     inside this process): profiles/r2_dominant_kernel_traffic.json, written by scripts/pmc_traffic.py."""
@@ -336,6 +382,8 @@ def main():
             out.update(dense)
         if extra is not None:
             out.update(extra)
+        if world == 1 and not args.no_extra:
+            out["other_configs"] = other_configs(M)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         line = json.dumps(out)

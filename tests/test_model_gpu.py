@@ -400,6 +400,77 @@ def test_greedy_decode_matches_full_recompute_oracle(M, specs, monkeypatch, grap
 
 
 @pytest.mark.parametrize("cd", [F32, BF16])
+def test_decode_config4_full_size(M, monkeypatch, cd):
+    """BASELINE config #4 at its real size (run_report_generation_cxr.py:315-333,385-386): Swin-S + BERT-base, B=32,
+    max_length=150, greedy.  The replayed HIP graph (fused last-row head + argmax) must give the token ids of the
+    eager per-token loop for all 150 steps, and the first steps must equal the CPU oracle's full-sequence recompute
+    (B=4 slice, 6 steps: the recompute is quadratic on the CPU).  bf16 = the benchmarked path."""
+    from oracle import mvlt_oracle as O
+    cfg = M.MVLBertConfigForImageCaption()
+    cfg.max_length = 150
+    cfg.eos_token_id = None                       # fixed work: never stop early
+    tok = type("Tok", (), {"mask_token_id": 103, "sep_token_id": 102})()
+    torch.manual_seed(1)
+    model = M.MVLBertForImageCaption(cfg, tokenizer=tok)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = M.set_compute_dtype(model.cuda().eval(), cd)
+    image = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    outs = {}
+    for graph in ("1", "0"):
+        monkeypatch.setenv("MVLT_DECODE_GRAPH", graph)
+        ids, scores = model(image.cuda(), None, 1, 'unilm')
+        assert ids.shape == (32, 150)
+        outs[graph] = ids.cpu()
+    same = (outs["1"] == outs["0"])
+    if cd == F32:
+        assert bool(same.all())
+    else:
+        # bf16: the graph path picks from f32 accumulators (mvlt_gemm_argmax), the eager loop from bf16-rounded
+        # logits; a near-tie may flip and the sequence then diverges -- the first tokens must agree for every sample
+        assert bool(same[:, :4].all()) and same.float().mean().item() > 0.5
+    with torch.no_grad():
+        ref = O.greedy_decode_recompute(sd, O.SwinCfg(), O.BertCfg(eos_token_id=-1), image[:4], max_len=6)
+    got = outs["1"][:4, :6]
+    if cd == F32:
+        assert torch.equal(got, ref), (got, ref)
+    else:
+        assert bool((got[:, :2] == ref[:, :2]).all()) and (got == ref).float().mean().item() >= 0.75, (got, ref)
+
+
+def test_sample_mode_decoding(M, specs_hash):
+    """sample_mode='sample' (model.py:896-906: multinomial over softmax(logits)): reproducible under torch's seed,
+    token scores are the log-probabilities of the sampled tokens, and the first-step frequencies follow the softmax."""
+    from conftest import hash_sd
+    cfg = tiny_cfg(M, cls=M.MVLBertConfigForImageCaption)
+    cfg.max_length = 6
+    cfg.eos_token_id = None
+    tok = type("Tok", (), {"mask_token_id": 103, "sep_token_id": 102})()
+    model = M.MVLBertForImageCaption(cfg, tokenizer=tok)
+    model.load_state_dict(hash_sd(specs_hash["hash_tiny_caption"]), strict=False)
+    model = M.set_compute_dtype(model.cuda().eval(), F32)
+    image, _, _, _ = synth_batch(1, 24, seed=63, vocab=3000)
+    img = image.cuda().expand(512, -1, -1, -1).contiguous()      # 512 copies of one image: 512 draws per step
+    torch.manual_seed(11)
+    ids1, sc1 = model(img, None, 1, 'unilm', sample_mode='sample')
+    torch.manual_seed(11)
+    ids2, sc2 = model(img, None, 1, 'unilm', sample_mode='sample')
+    assert torch.equal(ids1, ids2) and torch.equal(sc1, sc2)
+    assert ids1.shape == (512, 6) and int(ids1.min()) >= 0 and int(ids1.max()) < 3000 and bool((sc1 <= 0).all())
+    # step 0 distribution from the module's own cached-step API
+    with torch.no_grad():
+        feat = model.conv(img[:1])
+        mask = torch.full((1, 1), 103, device="cuda")
+        out0, _ = model.MVLBert(mask, None, feat, None, use_cache=True, seq2seq_mask=True)
+        logits = model.MLM_head_seq2seq(out0.last_hidden_state[:, -1:])[0, 0].float()
+    p = torch.softmax(logits, -1).cpu()
+    first = ids1[:, 0].cpu()
+    assert rel_err(sc1[:512].cpu(), torch.log(p[first])) < 1e-4          # scores are concatenated step after step
+    top = torch.topk(p, 5).indices
+    freq = torch.stack([(first == t).float().mean() for t in top])
+    assert bool(((freq - p[top]).abs() < 4 * (p[top] * (1 - p[top]) / 512).sqrt() + 1e-3).all()), (freq, p[top])
+
+
+@pytest.mark.parametrize("cd", [F32, BF16])
 def test_cached_step_api_equals_full_forward(M, specs, cd):
     """MVLBert.forward(past_key_values=..., use_cache=True) (model.py:82-108): a 2-token cached step
     reproduces the hidden state of the full seq2seq forward at the same position."""
@@ -800,6 +871,37 @@ def test_swin_b_config5_projection_and_training_step(M):
     l0 = step(batch).item()
     l1 = step(batch).item()
     assert l0 == l0 and l1 == l1 and model.conv.feature_proj.weight.grad is not None
+
+
+@pytest.mark.parametrize("cd", [F32, BF16])
+def test_config5_full_depth(M, monkeypatch, cd):
+    """BASELINE config #5 at its stated depth: Swin-B depths [2,2,18,2] (C = 128..1024) + the build-added
+    Linear(1024, 768) + 12 BERT layers, per-GPU batch 8, seq 128 (L = 179), eval mode: Swin tokens and the pretrain
+    loss against the CPU oracle (the reference itself cannot run Swin-B)."""
+    import torch.nn.functional as F
+    from oracle import mvlt_oracle as O
+    from mvlt_amd.train import synthetic_batch
+    cfg = M.MVLBertPretrainConfig().use_swin_base(drop_path_rate=0.0)
+    cfg.ITM_task = True
+    torch.manual_seed(6)
+    model = M.MVLBertForPretraining(cfg)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = M.set_compute_dtype(model.cuda().eval(), cd)
+    image, ids, labels, itm = synthetic_batch(8, 128, "cpu", 9)[:4]
+    monkeypatch.setattr(random, "random", lambda: 0.9)
+    with torch.no_grad():
+        feat = model.conv(image.cuda())
+        loss = model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda())
+        scfg = O.SwinCfg(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), drop_path_rate=0.0)
+        bcfg = O.BertCfg()
+        rfeat = F.linear(F.gelu(O.swin_forward(image, sd, "conv.conv.0.", scfg)), sd["conv.feature_proj.weight"],
+                         sd["conv.feature_proj.bias"])
+        o = O.mvlbert_forward(sd, bcfg, ids, rfeat, False)
+        logits = O.mlm_head(o["text"], sd, "MLM_head_bidir", bcfg)
+        ref = F.cross_entropy(logits.transpose(1, 2), labels, ignore_index=-100) + \
+            F.cross_entropy(O._lin(o["pooled"], sd, "ITM_mlp"), itm)
+    assert rel_err(feat.float().cpu(), rfeat) < HASH_ACT[cd]
+    assert abs(loss.item() - ref.item()) < HASH_LOSS[cd] * abs(ref.item()), (loss.item(), ref.item())
 
 
 # ------------------------------------------------------------------ fine-tuning paths: gradients vs the oracle
