@@ -198,8 +198,8 @@ def other_configs(M):
                              "ms_per_batch": round(dt * 1e3, 2), "reports_per_s": round(32 / dt, 1),
                              "tokens_per_s": round(32 * ids.shape[1] / dt, 0),
                              "us_per_2token_step": round(dt / ids.shape[1] * 1e6, 1),
-                             "hbm_floor_us_per_step": 54.0,
-                             "note": "floor = 217 MB of bf16 weights per step at 4 TB/s effective per step chain (SURVEY 8d); the step is "
+                             "hbm_floor_us_per_step": 27.1,
+                             "note": "floor = 217 MB of bf16 weights streamed per step (SURVEY 8d) at the 8 TB/s HBM peak; the step is "
                                      "a chain of ~100 dependent small kernels, i.e. latency bound"}
     del cap
     c5 = M.MVLBertPretrainConfig().use_swin_base()
