@@ -305,7 +305,7 @@ def main():
     # exactly the reference's work (the default plans the packing on the device from the ids themselves)
     dense = None
     if not args.no_extra:
-        cfg.auto_pack_rows = False
+        cfg.auto_pack_rows = False               # (also turns the labelled-rows-first MLM head off: all 80 rows per sample)
         for _ in range(max(2, args.warmup // 2)):
             step(batch)
         e1, l1 = timed_run(step, batch, args.steps, use_dist, dist)
@@ -362,7 +362,9 @@ def main():
                                       "storage + f32 accumulate/master, fwd+bwd+allreduce+AdamW, random-init weights; "
                                       "reference call signature model(image, caption_masked, caption_label, ITM_label)",
                           "global_batch": PER_GPU_BATCH * world, "seq_len": SEQ, "parallelism": f"dp{world}",
-                          "mlm_head_rows": "all (80 per sample, as the reference)",
+                          "mlm_head_rows": "module default: labelled rows gathered first, their count stays on the device and "
+                                           "the head's kernels read it (rows with ignore_index contribute nothing, "
+                                           "model.py:410); value_dense_rows also evaluates the head on all 80 rows per sample",
                           "bert_rows": "module default: packing plan computed on the device from the ids/labels (no new "
                                        "argument, no host sync); the zero-padded caption tails are not materialised, "
                                        "loss and gradients equal the dense run (tests/test_model_gpu.py::"
@@ -375,8 +377,8 @@ def main():
                # default path (padded caption rows skipped) are in executed_gflop_per_pair
                "step_tflops_per_gpu": round(value / world * GFLOP_PER_PAIR / 1e3, 2),
                "step_mfma_frac": round(value / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS, 4),
-               "executed_gflop_per_pair": round(packed_gflop_per_pair(batch_full, all_mlm_rows=True), 1),
-               "step_tflops_per_gpu_executed": round(value / world * packed_gflop_per_pair(batch_full, all_mlm_rows=True) / 1e3, 2),
+               "executed_gflop_per_pair": round(packed_gflop_per_pair(batch_full), 1),
+               "step_tflops_per_gpu_executed": round(value / world * packed_gflop_per_pair(batch_full) / 1e3, 2),
                "roofline": roofline}
         if dense is not None:
             out.update(dense)

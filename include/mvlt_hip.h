@@ -291,6 +291,13 @@ int mvlt_ce_fwd(int dtype, const void* logits, int64_t ld, int rows, int V, cons
 int mvlt_ce_bwd(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
                 const float* lse, const float* count, float grad_scale, const float* grad_scale_dev,
                 void* dlogits, void* stream);   /* grad_scale_dev (optional): upstream dL/dloss on the device */
+/* the same with the number of valid rows on the DEVICE (rows = upper bound; see MvltGemm.m_dev): rows beyond
+ * *rows_dev are neither read nor written */
+int mvlt_ce_fwd_ragged(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
+                       float* lse, float* loss_sum, float* count, const int32_t* rows_dev, void* stream);
+int mvlt_ce_bwd_ragged(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
+                       const float* lse, const float* count, float grad_scale, const float* grad_scale_dev,
+                       void* dlogits, const int32_t* rows_dev, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.AdamW step (run_pretrain.py:165-166: lr 4e-5, betas (0.9,0.999),

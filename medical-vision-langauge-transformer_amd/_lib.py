@@ -136,6 +136,8 @@ SYMBOLS = {
     "mvlt_droppath_scale": (i32, [vp, i32, f32, u64, u32, vp]),
     "mvlt_ce_fwd": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
     "mvlt_ce_bwd": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, f32, vp, vp, vp]),
+    "mvlt_ce_fwd_ragged": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "mvlt_ce_bwd_ragged": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp]),
     "mvlt_gelu_bwd": (i32, [i32, vp, vp, vp, i64, vp]),
     "mvlt_softmax_rows": (i32, [i32, vp, i64, i32, i32, vp, vp]),
     "mvlt_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),

@@ -210,7 +210,7 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
     using GB = TileGeom<T, BN, BK_>;
     using Vec = typename TypeInfo<T>::Vec;
     constexpr int FM = BM / 32, FN = BN / 32;
-    const GemmDev p = effective<AK>(p_in);
+    const GemmDev& p = p_in;                     // (already the effective problem: see gemm_kernel / gemm_group_kernel)
     const int m0 = by * BM, n0 = bx * BN;
     if (m0 >= p.M) return;                       // (uniform per workgroup; only with m_dev)
     const int ks = bz * p.k_per_split;
@@ -342,10 +342,16 @@ template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2>
 __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     __shared__ __attribute__((aligned(16))) T sA[TileGeom<T, BM, AK>::ELEMS];
     __shared__ __attribute__((aligned(16))) T sB[TileGeom<T, BN, BK_>::ELEMS];
+    // ragged batches (m_dev): the tile list is the EFFECTIVE one -- the XCD remap deals contiguous chunks of it to the
+    // XCDs, so remapping the upper-bound list would leave the XCDs that own the empty tail idle
+    const GemmDev q = effective<AK>(p);
     const int gx = gridDim.x;
-    const int t = xcd_remap(blockIdx.y * gx + blockIdx.x, gx * gridDim.y);
+    const int gy = AK ? (int)gridDim.y : min((int)gridDim.y, (q.M + BM - 1) / BM);
+    const int orig = blockIdx.y * gx + blockIdx.x;
+    if (orig >= gx * gy) return;
+    const int t = xcd_remap(orig, gx * gy);
     const int by = t / gx;
-    gemm_body<T, BM, BN, AK, BK_, PF2>(p, t - by * gx, by, blockIdx.z, sA, sB);
+    gemm_body<T, BM, BN, AK, BK_, PF2>(q, t - by * gx, by, blockIdx.z, sA, sB);
 }
 
 // Skinny products (M <= 64: the 2-token decode step, poolers, classifier heads): the weight matrix is read once
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(256, 3) void gemm_group_kernel(const GemmGroupDev g
         const int t = xcd_remap(t0, total);
         int i = 0;
         while (i + 1 < gp.n && t >= gp.start[i + 1]) ++i;
-        const GemmDev& p = gp.g[i];
+        const GemmDev p = effective<AK>(gp.g[i]);
         const int local = t - gp.start[i];
         const int gx = (p.N + BN - 1) / BN;
         const int by = local / gx;

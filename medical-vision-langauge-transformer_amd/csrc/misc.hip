@@ -243,10 +243,11 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, in
 // ------------------------------------------------------------------ cross entropy
 template <typename T>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* logits, long ld, int rows, int V, const int64_t* labels,
-                                                    float* lse, float* loss_sum, float* count) {
+                                                    float* lse, float* loss_sum, float* count, const int* rows_dev) {
     // one workgroup per row (rows with ignore_index are skipped entirely)
     __shared__ float red[8];
     const int r = blockIdx.x;
+    if (rows_dev && r >= *rows_dev) return;            // rows beyond the device-side count do not exist
     const long lab = labels[r];
     if (lab < 0) { if (threadIdx.x == 0 && lse) lse[r] = 0.f; return; }
     const T* x = logits + (long)r * ld;
@@ -277,8 +278,9 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* logits, long ld, i
 template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, long ld, int rows, int V, const int64_t* labels,
                                                     const float* lse, const float* count, float gscale,
-                                                    const float* gscale_dev, T* dl) {
+                                                    const float* gscale_dev, T* dl, const int* rows_dev) {
     const int r = blockIdx.x;
+    if (rows_dev && r >= *rows_dev) return;            // never read downstream (MvltGemm.m_dev): not even zero-filled
     if (gscale_dev) gscale *= gscale_dev[0];
     const long lab = labels[r];
     const T* x = logits + (long)r * ld;
@@ -708,20 +710,29 @@ extern "C" int mvlt_colsum(int dtype, const void* x, int64_t ld, int M, int N, f
 
 extern "C" int mvlt_ce_fwd(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
                            float* lse, float* loss_sum, float* count, void* stream) {
+    return mvlt_ce_fwd_ragged(dtype, logits, ld, rows, V, labels, lse, loss_sum, count, nullptr, stream);
+}
+extern "C" int mvlt_ce_fwd_ragged(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
+                                  float* lse, float* loss_sum, float* count, const int32_t* rows_dev, void* stream) {
     MVLT_CHECK(logits && labels && loss_sum && count && rows > 0 && V > 0 && ld >= V, MVLT_ERR_ARG);
     BY_DTYPE(dtype,
-             hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), (const float*)logits, (long)ld, rows, V, labels, lse, loss_sum, count),
-             hipLaunchKernelGGL(ce_fwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, (long)ld, rows, V, labels, lse, loss_sum, count));
+             hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), (const float*)logits, (long)ld, rows, V, labels, lse, loss_sum, count, rows_dev),
+             hipLaunchKernelGGL(ce_fwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, (long)ld, rows, V, labels, lse, loss_sum, count, rows_dev));
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }
 extern "C" int mvlt_ce_bwd(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
                            const float* lse, const float* count, float grad_scale, const float* grad_scale_dev,
                            void* dlogits, void* stream) {
+    return mvlt_ce_bwd_ragged(dtype, logits, ld, rows, V, labels, lse, count, grad_scale, grad_scale_dev, dlogits, nullptr, stream);
+}
+extern "C" int mvlt_ce_bwd_ragged(int dtype, const void* logits, int64_t ld, int rows, int V, const int64_t* labels,
+                                  const float* lse, const float* count, float grad_scale, const float* grad_scale_dev,
+                                  void* dlogits, const int32_t* rows_dev, void* stream) {
     MVLT_CHECK(logits && labels && lse && count && dlogits && rows > 0 && V > 0 && ld >= V, MVLT_ERR_ARG);
     BY_DTYPE(dtype,
-             hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), (const float*)logits, (long)ld, rows, V, labels, lse, count, grad_scale, grad_scale_dev, (float*)dlogits),
-             hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, (long)ld, rows, V, labels, lse, count, grad_scale, grad_scale_dev, (bf16_t*)dlogits));
+             hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(rows), dim3(256), 0, STREAM(stream), (const float*)logits, (long)ld, rows, V, labels, lse, count, grad_scale, grad_scale_dev, (float*)dlogits, rows_dev),
+             hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, (long)ld, rows, V, labels, lse, count, grad_scale, grad_scale_dev, (bf16_t*)dlogits, rows_dev));
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }

@@ -192,34 +192,38 @@ class BertOnlyMLMHead(nn.Module):
         return _MlmLogitsFn.apply(tok, x, self, torch.is_grad_enabled()).view(*shp[:-1], -1)
 
     # ---- engine pieces shared by the fused-loss path and the logits path
-    def _transform(self, ar, x, save):
+    # rd (optional): int32 device scalar, the number of valid rows of x (labelled rows gathered first; MvltGemm.m_dev)
+    def _transform(self, ar, x, save, rd=None):
         pr = self.predictions
         pre = torch.empty_like(x)
-        t1 = ops.gemm(x, ar.compute(pr.transform.dense.weight), bias=pr.transform.dense.bias.data, gelu=True, save_pre=pre)
+        t1 = ops.gemm(x, ar.compute(pr.transform.dense.weight), bias=pr.transform.dense.bias.data, gelu=True, save_pre=pre,
+                      m_dev=rd)
         ln = pr.transform.LayerNorm
-        t2, mean, rstd, _ = ops.layernorm_fwd(t1, ln.weight.data, ln.bias.data, ln.eps, save_stats=save)
+        t2, mean, rstd, _ = ops.layernorm_fwd(t1, ln.weight.data, ln.bias.data, ln.eps, save_stats=save, rows_dev=rd)
         return pre, t1, t2, mean, rstd
 
-    def _logits(self, ar, t2):
+    def _logits(self, ar, t2, rd=None):
         pr = self.predictions
         V = pr.decoder.out_features
         ld = (V + 63) // 64 * 64
-        logits = ops.gemm(t2, ar.compute(pr.decoder.weight), bias=pr.decoder.bias.data, ldc=ld)
+        logits = ops.gemm(t2, ar.compute(pr.decoder.weight), bias=pr.decoder.bias.data, ldc=ld, m_dev=rd)
         return logits, V
 
-    def _backward_from_dlogits(self, ar, dlogits, V, x, pre, t1, t2, mean, rstd):
+    def _backward_from_dlogits(self, ar, dlogits, V, x, pre, t1, t2, mean, rstd, rd=None):
         pr = self.predictions
         g = ar.grad_view
         dl = dlogits[:, :V]
-        dt2 = ops.gemm(dl, ar.compute(pr.decoder.weight), b_kmajor=True)
+        dt2 = ops.gemm(dl, ar.compute(pr.decoder.weight), b_kmajor=True, m_dev=rd)
         ops.gemm(dl, t2, a_kmajor=True, b_kmajor=True, out=g(pr.decoder.weight), out_f32=True,
-                 a_colsum=g(pr.decoder.bias))
+                 a_colsum=g(pr.decoder.bias), m_dev=rd)
         ln = pr.transform.LayerNorm
-        dt1 = ops.layernorm_bwd(dt2, t1, mean, rstd, ln.weight.data, g(ln.weight), g(ln.bias))
+        dt1 = ops.layernorm_bwd(dt2, t1, mean, rstd, ln.weight.data, g(ln.weight), g(ln.bias), rows_dev=rd)
         dpre = ops.gelu_bwd(pre, dt1)
-        dx = ops.gemm(dpre, ar.compute(pr.transform.dense.weight), b_kmajor=True)
+        # rows beyond the device-side count are not computed: their gradient is exactly zero (unlabelled rows)
+        dx = ops.gemm(dpre, ar.compute(pr.transform.dense.weight), b_kmajor=True, m_dev=rd,
+                      out=None if rd is None else torch.zeros_like(x))
         ops.gemm(dpre, x, a_kmajor=True, b_kmajor=True, out=g(pr.transform.dense.weight), out_f32=True,
-                 a_colsum=g(pr.transform.dense.bias))
+                 a_colsum=g(pr.transform.dense.bias), m_dev=rd)
         ar.mark(pr.decoder.weight, pr.decoder.bias, ln.weight, ln.bias, pr.transform.dense.weight, pr.transform.dense.bias)
         return dx
 
@@ -259,26 +263,28 @@ class _MlmLossFn(torch.autograd.Function):
     logits stay in one padded [rows, ld] buffer, CE backward overwrites it in place."""
 
     @staticmethod
-    def forward(ctx, token, x, head, labels, save):
+    def forward(ctx, token, x, head, labels, save, rd=None):
         ar = Arena.of(head, x.dtype)
         ar.refresh_shadow()
-        pre, t1, t2, mean, rstd = head._transform(ar, x, save)
-        logits, V = head._logits(ar, t2)
-        acc, lse = ops.ce_fwd(logits, V, labels)
+        with ops.pin_stream():
+            pre, t1, t2, mean, rstd = head._transform(ar, x, save, rd)
+            logits, V = head._logits(ar, t2, rd)
+            acc, lse = ops.ce_fwd(logits, V, labels, rows_dev=rd)
         loss = acc[0] / acc[1]          # mean over labelled positions (nan if none, as in torch)
         ctx.head = head
-        ctx.saved = (ar, V, x, pre, t1, t2, mean, rstd, logits, labels, lse, acc) if save else None
+        ctx.saved = (ar, V, x, pre, t1, t2, mean, rstd, logits, labels, lse, acc, rd) if save else None
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        ar, V, x, pre, t1, t2, mean, rstd, logits, labels, lse, acc = ctx.saved
+        ar, V, x, pre, t1, t2, mean, rstd, logits, labels, lse, acc, rd = ctx.saved
         backward_begin(ar)
         gs = dloss.reshape(1).to(torch.float32).contiguous()
-        dlogits = ops.ce_bwd(logits, V, labels, lse, acc, grad_scale=1.0, grad_scale_dev=gs)
-        dx = ctx.head._backward_from_dlogits(ar, dlogits, V, x, pre, t1, t2, mean, rstd)
+        with ops.pin_stream():
+            dlogits = ops.ce_bwd(logits, V, labels, lse, acc, grad_scale=1.0, grad_scale_dev=gs, rows_dev=rd)
+            dx = ctx.head._backward_from_dlogits(ar, dlogits, V, x, pre, t1, t2, mean, rstd, rd)
         ctx.saved = None
-        return None, dx, None, None, None
+        return None, dx, None, None, None, None
 
 
 class _LinearCEFn(torch.autograd.Function):
@@ -453,6 +459,16 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
             labels = caption_label.reshape(-1).to(torch.int64).contiguous()
             cap = getattr(self.config, "mlm_max_labels_per_sample", None)
             compact = cap is not None and cap * B < B * T
+            # default: labelled rows are gathered FIRST and their number stays on the device; the head's kernels read
+            # it (MvltGemm.m_dev) -- loss and gradients are those of the all-rows head (ignore_index rows contribute
+            # nothing, model.py:410), for any number of labels, with no host sync and no capacity to configure
+            rd = None
+            lab_first = auto and not compact and getattr(self.config, "mlm_labelled_rows_first", True)
+            if lab_first:
+                valid = labels >= 0
+                order = torch.argsort((~valid).to(torch.int8), stable=True)
+                sel_labels = labels[order].contiguous()
+                rd = valid.sum(dtype=torch.int32).reshape(1)
             if compact:
                 # Only labelled positions contribute to F.cross_entropy(ignore_index=-100) (model.py:410),
                 # so the MLM head (768x30522 decoder, 312 MB of f32 logits in the reference) is evaluated on
@@ -464,7 +480,7 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
                 sel_labels = labels[order].contiguous()
             if auto:
                 # packed row of every caption position (dropped positions: the sample's [CLS] row; label -100)
-                x = hidden[text_row[order] if compact else text_row]
+                x = hidden[text_row[order] if (compact or lab_first) else text_row]
             elif packed:
                 # flat (b, t) -> packed row of caption position t; rows of unlabelled picks are clamped into
                 # range (their label is -100, whatever they gather is ignored)
@@ -476,8 +492,8 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
                 x = text_out.reshape(B * T, H)[order]
             else:
                 x = text_out.reshape(B * T, H)
-            mlm_loss = _MlmLossFn.apply(_token(head, dev), x.contiguous(), head, sel_labels if compact else labels,
-                                        torch.is_grad_enabled())
+            mlm_loss = _MlmLossFn.apply(_token(head, dev), x.contiguous(), head,
+                                        sel_labels if (compact or lab_first) else labels, torch.is_grad_enabled(), rd)
             if compact:
                 mlm_loss = torch.where(valid.sum() > cap * B, torch.full_like(mlm_loss, float("nan")), mlm_loss)
             if packed:

@@ -734,31 +734,33 @@ def droppath_scale(B, p, seed, tag, device):
 
 
 # ----------------------------------------------------------------------------- loss / optimizer / decode
-def ce_fwd(logits, V, labels):
-    """logits [rows, ld>=V]; returns (loss_sum, count, lse) device tensors (mean = sum/count)."""
+def ce_fwd(logits, V, labels, rows_dev=None):
+    """logits [rows, ld>=V]; returns (loss_sum, count, lse) device tensors (mean = sum/count).
+    rows_dev (int32 device scalar): only the first *rows_dev rows exist."""
     _need_cuda(logits)
     rows = logits.shape[0]
     assert labels.dtype == torch.int64 and labels.numel() == rows and labels.is_contiguous()
     acc = torch.zeros(2, dtype=torch.float32, device=logits.device)
     lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
-    L.check(L.lib().mvlt_ce_fwd(_dt(logits), _p(logits), logits.stride(0), rows, V, _p(labels), _p(lse),
-                                C.c_void_p(acc.data_ptr()), C.c_void_p(acc.data_ptr() + 4), _stream()), "mvlt_ce_fwd")
+    L.check(L.lib().mvlt_ce_fwd_ragged(_dt(logits), _p(logits), logits.stride(0), rows, V, _p(labels), _p(lse),
+                                       C.c_void_p(acc.data_ptr()), C.c_void_p(acc.data_ptr() + 4), _p(rows_dev), _stream()),
+            "mvlt_ce_fwd")
     return acc, lse
 
 
-def ce_bwd(logits, V, labels, lse, acc, grad_scale=1.0, out=None, grad_scale_dev=None):
+def ce_bwd(logits, V, labels, lse, acc, grad_scale=1.0, out=None, grad_scale_dev=None, rows_dev=None):
     if out is None:
         out = logits
     if grad_scale_dev is not None:
         assert grad_scale_dev.dtype == torch.float32 and grad_scale_dev.numel() == 1
-    L.check(L.lib().mvlt_ce_bwd(_dt(logits), _p(logits), logits.stride(0), logits.shape[0], V, _p(labels), _p(lse),
-                                C.c_void_p(acc.data_ptr() + 4), float(grad_scale), _p(grad_scale_dev), _p(out),
-                                _stream()), "mvlt_ce_bwd")
+    L.check(L.lib().mvlt_ce_bwd_ragged(_dt(logits), _p(logits), logits.stride(0), logits.shape[0], V, _p(labels), _p(lse),
+                                       C.c_void_p(acc.data_ptr() + 4), float(grad_scale), _p(grad_scale_dev), _p(out),
+                                       _p(rows_dev), _stream()), "mvlt_ce_bwd")
     return out
 
 
-def gelu_bwd(x, dy):
-    dx = torch.empty_like(x)
+def gelu_bwd(x, dy, out=None):
+    dx = torch.empty_like(x) if out is None else out
     L.check(L.lib().mvlt_gelu_bwd(_dt(x), _p(x), _p(dy), _p(dx), x.numel(), _stream()), "mvlt_gelu_bwd")
     return dx
 
