@@ -28,6 +28,7 @@ struct GemmDev {
     int a_vec, b_vec, epi_vec;
     float* a_colsum; float* ws_colsum;   // optional: column sums of a k-major A (bias gradient), fused
     const int* m_dev;                    // optional: valid storage rows of A on the device (MvltGemm.m_dev)
+    int atomic_out;                      // grouped weight gradients with in-launch split-K: f32 atomicAdd onto zeroed C
 };
 
 // Ragged batches planned on the GPU: the launch is sized for the upper bound, the kernel reads the real count.
@@ -313,7 +314,8 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
     if (AK && do_colsum) {
         const int m = m0 + threadIdx.x;
         if (m < p.M) {
-            if (p.split_k > 1) p.ws_colsum[(long)bz * p.M + m] = csum;
+            if (p.atomic_out) atomicAdd(&p.a_colsum[m], csum);
+            else if (p.split_k > 1) p.ws_colsum[(long)bz * p.M + m] = csum;
             else p.a_colsum[m] = (p.epi & MVLT_EPI_ACCUM) ? p.a_colsum[m] + csum : csum;
         }
     }
@@ -325,7 +327,15 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4);
-            if (p.split_k > 1) {
+            if (p.atomic_out) {
+                // k-slices of one output tile meet in the f32 output itself (zeroed by the launcher): no slabs, no
+                // reduce launch; the order of the 2..8 additions per element is not fixed (last-bit differences)
+                if (m < p.M) {
+                    float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) atomicAdd(c + r, acc[i][j][r]);
+                }
+            } else if (p.split_k > 1) {
                 if (m < p.M && n < p.N) {
                     float* w = p.ws + ((long)bz * p.M + m) * p.N + n;
                     if ((p.N & 3) == 0) store4f(w, acc[i][j]);
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(64) void argmax_parts_kernel(const float* part_val,
 // Several independent products in one launch (the weight gradients of one layer): the tile lists of the
 // items are concatenated, a workgroup finds its item by a scan of the (<= 8) prefix counts.
 constexpr int GROUP_MAX = 8;
-struct GemmGroupDev { int n; int start[GROUP_MAX + 1]; GemmDev g[GROUP_MAX]; };
+struct GemmGroupDev { int n; int split; int start[GROUP_MAX + 1]; GemmDev g[GROUP_MAX]; };   // start[]: in (tile, k-slice) units
 
 template <typename T, int BM, int BN, bool AK, bool BK_>
 __global__ __launch_bounds__(256, 3) void gemm_group_kernel(const GemmGroupDev gp) {
@@ -486,10 +496,11 @@ __global__ __launch_bounds__(256, 3) void gemm_group_kernel(const GemmGroupDev g
         int i = 0;
         while (i + 1 < gp.n && t >= gp.start[i + 1]) ++i;
         const GemmDev p = effective<AK>(gp.g[i]);
+        const int gx = (p.N + BN - 1) / BN, gy = (p.M + BM - 1) / BM;
         const int local = t - gp.start[i];
-        const int gx = (p.N + BN - 1) / BN;
-        const int by = local / gx;
-        gemm_body<T, BM, BN, AK, BK_, false>(p, local - by * gx, by, 0, sA, sB);
+        const int bz = local / (gx * gy), tile = local - bz * gx * gy;          // k-slice bz of output tile `tile`
+        const int by = tile / gx;
+        gemm_body<T, BM, BN, AK, BK_, false>(p, tile - by * gx, by, bz, sA, sB);
     }
 }
 
@@ -640,6 +651,7 @@ static int fill_dev(const MvltGemm* p, const Plan& pl, GemmDev& d) {
     d.ws = reinterpret_cast<float*>(p->workspace);
     d.a_colsum = p->a_colsum;
     d.m_dev = p->m_dev;
+    d.atomic_out = 0;
     d.ws_colsum = d.ws ? d.ws + (size_t)d.split_k * p->M * p->N : nullptr;
     d.a_vec = (p->lda % E == 0) && aligned16(p->A);
     d.b_vec = (p->ldb % E == 0) && aligned16(p->B);
@@ -707,13 +719,13 @@ template <typename T>
 static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
     GemmGroupDev g{};
     g.n = n;
-    int bn = 0;
+    bool all128 = true, all96 = true;
+    for (int i = 0; i < n; ++i) { all128 = all128 && items[i].N % 128 == 0; all96 = all96 && items[i].N % 96 == 0; }
+    const int bn = all128 ? 128 : (all96 ? 96 : 0);
+    MVLT_CHECK(bn != 0, MVLT_ERR_UNSUPPORTED);
     for (int i = 0; i < n; ++i) {
         const MvltGemm* p = items + i;
         MVLT_CHECK(p->a_kmajor && p->b_kmajor && p->dtype == items[0].dtype, MVLT_ERR_UNSUPPORTED);
-        const int want = (p->N % 128 == 0) ? 128 : (p->N % 96 == 0 ? 96 : 0);
-        MVLT_CHECK(want != 0 && (bn == 0 || bn == want), MVLT_ERR_UNSUPPORTED);
-        bn = want;
         Plan pl{64, bn, 1};
         { const int rc = fill_dev<T>(p, pl, g.g[i]); if (rc != MVLT_OK) return rc; }
     }
@@ -725,9 +737,47 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
         if (t128 >= 256) bm = 128;
         if (const char* ov = getenv("MVLT_GROUP_BM")) bm = atoi(ov) == 128 ? 128 : 64;
     }
+    long tiles = 0;
+    int kmin = items[0].K;
+    for (int i = 0; i < n; ++i) { tiles += (long)ceil_div(items[i].M, bm) * ceil_div(items[i].N, bn); kmin = items[i].K < kmin ? items[i].K : kmin; }
+    // In-launch split-K (experiment, MVLT_GROUP_SPLIT=n, or 0 = automatic): the output tiles are cut into k-slices that
+    // meet in the zeroed f32 output through atomicAdd.  OFF by default: measured on the B=32 step it does not shorten
+    // the stage-2 groups in situ (160 us either way -- beside the dgrad chain their duration is set by the CU share
+    // they get, not by their own k-depth) and the zeroing launch + atomics cost 1 ms per step (17.1 vs 15.9 ms).
+    const int bke = 128 / (int)sizeof(T);
+    int split = 1;
+    if (const char* ov = getenv("MVLT_GROUP_SPLIT")) {
+        const int v = atoi(ov);
+        if (v >= 1) split = v;
+        else if (tiles < 384) {
+            split = (int)((512 + tiles - 1) / tiles);
+            const int nkt = ceil_div(kmin, bke);
+            if (split > nkt / 8) split = nkt / 8;
+            if (split > 64) split = 64;
+            if (split < 1) split = 1;
+        }
+    }
+    g.split = split;
     for (int i = 0; i < n; ++i) {
         g.start[i] = i == 0 ? 0 : g.start[i];
-        g.start[i + 1] = g.start[i] + ceil_div(items[i].M, bm) * ceil_div(items[i].N, bn);
+        g.start[i + 1] = g.start[i] + ceil_div(items[i].M, bm) * ceil_div(items[i].N, bn) * split;
+        if (split > 1) {
+            GemmDev& d = g.g[i];
+            d.split_k = split;
+            d.k_per_split = ceil_div(ceil_div(items[i].K, bke), split) * bke;
+            d.atomic_out = 1;
+        }
+    }
+    if (split > 1) {
+        MvltZeroItem z[2 * GROUP_MAX];
+        int nz = 0;
+        for (int i = 0; i < n; ++i) {
+            MVLT_CHECK(items[i].ldc == items[i].N, MVLT_ERR_UNSUPPORTED);          // contiguous outputs (gradient arena views)
+            z[nz++] = MvltZeroItem{reinterpret_cast<float*>(items[i].C), (int64_t)items[i].M * items[i].N};
+            if (items[i].a_colsum) z[nz++] = MvltZeroItem{items[i].a_colsum, (int64_t)items[i].M};
+        }
+        const int rc = mvlt_zero_batch(z, nz, s);
+        if (rc != MVLT_OK) return rc;
     }
     // at most 2 workgroups per CU (of the 3 that fit): the group runs on the side stream beside the dgrad
     // chain, which should keep a share of every CU (16.8 vs 17.1 ms/step uncapped; MVLT_GROUP_WGS=n overrides, 0 = no cap)
