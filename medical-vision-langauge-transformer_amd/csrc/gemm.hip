@@ -117,10 +117,18 @@ MVLT_DEV void epilogue4(const GemmDev& p, int m, int n, f32x4 v) {
     }
 }
 
+// k-major bf16 tiles of 64 / 128 rows are stored UNPADDED with their 32-byte column chunks XOR-swizzled by a function
+// of k: a ds_read_b64_tr_b16 group of 32 lanes reads 8 k-rows {k0..k0+3, k0+8..k0+11} x 32 bytes, which padding alone
+// cannot spread over the 64 banks (rows k and k+8 alias for every pad that keeps 32-byte chunks aligned: 2-way conflicts,
+// 32 % of the LDS cycles of the weight-gradient kernels, profiles/r2_dominant_kernel_pmc.txt).
+template <int R> MVLT_DEV int kswz(int k) {
+    return R == 128 ? ((k & 3) | ((k >> 1) & 4)) : (((k >> 1) & 1) | ((k >> 2) & 2));
+}
 template <typename T, int R, bool KMAJOR> struct TileGeom {
     static constexpr int E = TypeInfo<T>::E;
     static constexpr int BKE = 128 / (int)sizeof(T);          // k elements per tile
-    static constexpr int PAD = KMAJOR ? (sizeof(T) == 2 ? 16 : 4) : 0;
+    static constexpr bool SWZ = KMAJOR && sizeof(T) == 2 && (R == 64 || R == 128);
+    static constexpr int PAD = KMAJOR ? (SWZ ? 0 : (sizeof(T) == 2 ? 16 : 4)) : 0;
     static constexpr int LD = KMAJOR ? (R + PAD) : BKE;        // elements per LDS row
     static constexpr int ELEMS = KMAJOR ? BKE * LD : R * BKE;
     static constexpr int CHUNKS = R * 8;                        // 16-byte chunks per tile
@@ -180,7 +188,8 @@ MVLT_DEV void tile_store(const typename TypeInfo<T>::Vec* __restrict__ regs, T* 
     for (int i = 0; i < G::PER_THREAD; ++i) {
         const int idx = threadIdx.x + 256 * i;
         const int lr = idx / G::CPR, ch = idx % G::CPR;
-        if (KMAJOR) *reinterpret_cast<Vec*>(lds + lr * G::LD + ch * G::E) = regs[i];
+        if (KMAJOR && G::SWZ) *reinterpret_cast<Vec*>(lds + lr * G::LD + ((((ch >> 1) ^ kswz<R>(lr)) << 4) | ((ch & 1) << 3))) = regs[i];
+        else if (KMAJOR) *reinterpret_cast<Vec*>(lds + lr * G::LD + ch * G::E) = regs[i];
         else        *reinterpret_cast<Vec*>(lds + lr * G::BKE + ((ch ^ (lr & 7)) * G::E)) = regs[i];
     }
 }
@@ -189,11 +198,26 @@ MVLT_DEV void tile_store(const typename TypeInfo<T>::Vec* __restrict__ regs, T* 
 template <typename T, int R, bool KMAJOR>
 MVLT_DEV typename Mma<T>::Frag tile_frag(const T* lds, int row0, int kb) {
     using G = TileGeom<T, R, KMAJOR>;
-    if (KMAJOR) return frag_kmajor(lds, G::LD, row0, kb * Mma<T>::KB);
+    if constexpr (KMAJOR && G::SWZ) {
+        const int l = threadIdx.x & 63;
+        const int g = l >> 4, i = l & 15, q = i >> 2, pp = i & 3;
+        const int k = kb * 32 + 8 * g + q, c = row0 >> 4;
+        const bf16_t* p0 = lds + k * G::LD + ((c ^ kswz<R>(k)) << 4) + 4 * pp;
+        const bf16_t* p1 = lds + (k + 4) * G::LD + ((c ^ kswz<R>(k + 4)) << 4) + 4 * pp;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
+        bf16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    } else if constexpr (KMAJOR) {
+        return frag_kmajor(lds, G::LD, row0, kb * Mma<T>::KB);
+    } else {
     const int l = threadIdx.x & 63;
     const int row = row0 + (l & 15);
     const int ch = (kb * 4 + (l >> 4)) ^ (row & 7);
     return *reinterpret_cast<const typename Mma<T>::Frag*>(lds + row * G::BKE + ch * G::E);
+    }
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
@@ -244,7 +268,8 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
         if (AK && do_colsum) {
             float s0 = 0.f;
 #pragma unroll 8
-            for (int k = 0; k < GA::BKE; ++k) s0 += to_f(sA[k * GA::LD + threadIdx.x]);
+            for (int k = 0; k < GA::BKE; ++k)
+                s0 += to_f(sA[k * GA::LD + (GA::SWZ ? ((((threadIdx.x >> 4) ^ kswz<BM>(k)) << 4) | (threadIdx.x & 15)) : threadIdx.x)]);
             csum += s0;
         }
     };
