@@ -373,6 +373,108 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Both operands k-contiguous (every forward nn.Linear), bf16, K a multiple of 64: the tiles go global -> LDS by
+// `global_load_lds_dwordx4` (LDS-DMA: no staging registers, no ds_write pass -- the register-staged loop spends
+// about as long in ds_write_b128 as in MFMA), two LDS buffers, ONE barrier per k-tile: the DMA of tile t+1 is in
+// flight while tile t is multiplied.  An LDS-DMA instruction writes wave-uniform base + lane * 16 bytes, so the
+// XOR swizzle of the [row][128 B] image is applied to the per-lane SOURCE address (chunk' = chunk ^ (row & 7), the
+// same involution tile_frag applies on the read side).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <int R>
+MVLT_DEV void glds_fill(const bf16_t* const (&src)[R / 32], bf16_t* lds_tile, int wave, long koff) {
+#pragma unroll
+    for (int j = 0; j < R / 32; ++j) {
+        bf16_t* dst = lds_tile + (wave * (R / 32) + j) * 8 * 64;          // 8 rows x 64 elements = 1 KB per instruction
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src[j] + koff), (lds_void_t*)dst, 16, 0, 0);
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
+    using T = bf16_t;
+    constexpr int BKE = 64, FM = BM / 32, FN = BN / 32;
+    __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * BKE];
+    const GemmDev p = effective<false>(p_in);
+    const int gx = gridDim.x;
+    const int gy = min((int)gridDim.y, (p.M + BM - 1) / BM);
+    const int orig = blockIdx.y * gx + blockIdx.x;
+    if (orig >= gx * gy) return;
+    const int t = xcd_remap(orig, gx * gy);
+    const int by = t / gx, bx = t - by * gx, bz = blockIdx.z;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int ks = bz * p.k_per_split;
+    const int ke = min(p.K, ks + p.k_per_split);
+    const int nkt = (ke - ks) / BKE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+    constexpr int STAGE = (BM + BN) * BKE;            // elements per LDS stage: A tile, then B tile
+    // per-lane source pointers: instruction j of this wave covers tile rows 8 (wave R/32 + j) .. +8; lane = (row_in, chunk')
+    const int rin = lane >> 3, chs = (lane & 7) ^ rin;
+    const T* srcA[BM / 32];
+    const T* srcB[BN / 32];
+#pragma unroll
+    for (int j = 0; j < BM / 32; ++j) {
+        const int row = min(m0 + (wave * (BM / 32) + j) * 8 + rin, p.M - 1);
+        srcA[j] = A + (long)row * p.lda + ks + chs * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j) {
+        const int row = min(n0 + (wave * (BN / 32) + j) * 8 + rin, p.N - 1);
+        srcB[j] = B + (long)row * p.ldb + ks + chs * 8;
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nkt > 0) { glds_fill<BM>(srcA, smem, wave, 0); glds_fill<BN>(srcB, smem + BM * BKE, wave, 0); }
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt has landed
+        __syncthreads();                                       // everybody's has; everybody is done reading tile kt-1
+        if (kt + 1 < nkt) {
+            T* nxt = smem + ((kt + 1) & 1) * STAGE;
+            glds_fill<BM>(srcA, nxt, wave, (long)(kt + 1) * BKE);
+            glds_fill<BN>(srcB, nxt + BM * BKE, wave, (long)(kt + 1) * BKE);
+        }
+        const T* a = smem + (kt & 1) * STAGE;
+        const T* b = a + BM * BKE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            typename Mma<T>::Frag fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = tile_frag<T, BM, false>(a, wm * (BM / 2) + i * 16, kb);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = tile_frag<T, BN, false>(b, wn * (BN / 2) + j * 16, kb);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4);
+            if (p.split_k > 1) {
+                if (m < p.M && n < p.N) {
+                    float* w = p.ws + ((long)bz * p.M + m) * p.N + n;
+                    if ((p.N & 3) == 0) store4f(w, acc[i][j]);
+                    else for (int r = 0; r < 4; ++r) if (n + r < p.N) w[r] = acc[i][j][r];
+                }
+            } else {
+                epilogue4<T>(p, m, n, acc[i][j]);
+            }
+        }
+    }
+}
+
 template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2>
 __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     __shared__ __attribute__((aligned(16))) T sA[TileGeom<T, BM, AK>::ELEMS];
@@ -705,6 +807,36 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     }
     dim3 grid(ceil_div(p->N, pl.bn), ceil_div(p->M, pl.bm), d.split_k);
     const bool ak = p->a_kmajor != 0, bk = p->b_kmajor != 0;
+    if constexpr (sizeof(T) == 2) {
+        // MVLT_GLDS: 0 = never, 1 = every tile, 2 (default) = 64-row tiles only.  Standalone the LDS-DMA loop is 5-12 %
+        // faster on 128x128 tiles and 18-24 % on 64x64; inside the training step the 128x128 form (64 KB of LDS, two
+        // workgroups per CU) is SLOWER than the register-staged one (three per CU, shares the CU better with the
+        // weight-gradient stream): 16.5 vs 16.1 ms per step.
+        static const int glds_mode = [] { const char* e = getenv("MVLT_GLDS"); return e ? atoi(e) : 2; }();
+        const bool glds_on = glds_mode == 1 || (glds_mode == 2 && pl.bm == 64);
+        const int kspan = d.split_k > 1 ? d.k_per_split : p->K;
+        if (glds_on && !ak && !bk && p->K % 64 == 0 && kspan % 64 == 0 && d.a_vec && d.b_vec) {
+            bool done = true;
+            if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<128, 128>), grid, dim3(256), 0, s, d);
+            else if (pl.bm == 128 && pl.bn == 96) hipLaunchKernelGGL((gemm_glds_kernel<128, 96>), grid, dim3(256), 0, s, d);
+            else if (pl.bm == 64 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<64, 128>), grid, dim3(256), 0, s, d);
+            else if (pl.bm == 64 && pl.bn == 96) hipLaunchKernelGGL((gemm_glds_kernel<64, 96>), grid, dim3(256), 0, s, d);
+            else if (pl.bm == 64 && pl.bn == 64) hipLaunchKernelGGL((gemm_glds_kernel<64, 64>), grid, dim3(256), 0, s, d);
+            else done = false;
+            if (done) {
+                MVLT_LAUNCH_CHECK();
+                if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
+                if (d.split_k > 1) {
+                    long total = (long)p->M * ((p->N + 3) / 4);
+                    int blocks = (int)((total + 63) / 64);
+                    if (blocks > 8192) blocks = 8192;
+                    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, s, d);
+                    MVLT_LAUNCH_CHECK();
+                }
+                return MVLT_OK;
+            }
+        }
+    }
     if (pl.bm == 128 && pl.bn == 128) launch_layout<T, 128, 128>(d, ak, bk, grid, s);
     else if (pl.bm == 128 && pl.bn == 96) launch_layout<T, 128, 96>(d, ak, bk, grid, s);
     else if (pl.bm == 64 && pl.bn == 128) launch_layout<T, 64, 128>(d, ak, bk, grid, s);

@@ -127,6 +127,8 @@ GroupTimer g_timer;
 struct WItem { const Tensor* dy; const Tensor* x; int64_t dw; int64_t db; };
 // weight gradients of one layer: dW_i = dY_i^T X_i, db_i = colsum(dY_i)  (ops.wgrad_group)
 void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws, const int32_t* k_dev = nullptr) {
+    static const bool skip = [] { const char* e = getenv("MVLT_SKIP_WGRAD"); return e && e[0] == '1'; }();   // timing experiment only
+    if (skip) return;
     const int n = (int)items.size();
     bool all128 = true, all96 = true;
     for (auto& it : items) { all128 &= it.x->size(1) % 128 == 0; all96 &= it.x->size(1) % 96 == 0; }
