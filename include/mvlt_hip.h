@@ -260,6 +260,15 @@ typedef struct MvltEmbed {
 int mvlt_pack_plan(const int64_t* text_ids, const int64_t* labels, int B, int T, int n_img,
                    int32_t* row_start, int32_t* seq_len, int32_t* total_rows, int64_t* row_start64, int64_t* text_row,
                    void* stream);
+/* MLM head on the labelled rows (F.cross_entropy(ignore_index=-100), model.py:410, only reads them): stable partition
+ * of the N caption positions, labelled ones first.  gather_row[slot] = text_row[i] (the packed row of position i;
+ * i itself when text_row is NULL), sel_labels[slot] = labels[i], count[0] = number of labelled positions (feeds
+ * MvltGemm.m_dev).  One launch, no host sync; N <= 2^20. */
+int mvlt_label_plan(const int64_t* labels, const int64_t* text_row, int N, int32_t* gather_row, int64_t* sel_labels,
+                    int32_t* count, void* stream);
+/* out[rowmap[i], :] = in[i, :] for i < min(rows, *count): backward of a row gather with unique source rows */
+int mvlt_rows_scatter(int dtype, const void* in, void* out, int rows, int C, const int32_t* rowmap,
+                      const int32_t* count, void* stream);
 int mvlt_embed_fwd(const MvltEmbed* p, void* stream);
 int mvlt_embed_bwd(const MvltEmbed* p, void* stream);  /* dword/dpos/dtype_emb are ACCUMULATED (zero them first) */
 

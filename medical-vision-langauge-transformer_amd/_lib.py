@@ -125,6 +125,8 @@ SYMBOLS = {
     "mvlt_swin_wmsa_bwd": (i32, [C.POINTER(MvltSwinWmsa), vp]),
     "mvlt_im2col_patch": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "mvlt_pack_plan": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "mvlt_label_plan": (i32, [vp, vp, i32, vp, vp, vp, vp]),
+    "mvlt_rows_scatter": (i32, [i32, vp, vp, i32, i32, vp, vp, vp]),
     "mvlt_embed_fwd": (i32, [C.POINTER(MvltEmbed), vp]),
     "mvlt_embed_bwd": (i32, [C.POINTER(MvltEmbed), vp]),
     "mvlt_rows_transform": (i32, [i32, vp, vp, i32, i32, vp, vp, i32, f32, u64, u32, vp]),

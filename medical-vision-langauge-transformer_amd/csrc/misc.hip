@@ -81,6 +81,46 @@ __global__ __launch_bounds__(256) void pack_plan_kernel(const int64_t* text, con
     }
 }
 
+// Labelled rows first (mvlt_label_plan): stable partition of the N caption positions by (label >= 0), one workgroup.
+__global__ __launch_bounds__(1024) void label_plan_kernel(const int64_t* labels, const int64_t* text_row, int N,
+                                                          int* gather_row, int64_t* sel_labels, int* count) {
+    __shared__ int part[1024];
+    __shared__ int total;
+    const int per = (N + 1023) / 1024;
+    const int lo = min(threadIdx.x * per, N), hi = min(lo + per, N);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += labels[i] >= 0;
+    part[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {                       // 1024 partial counts: a serial scan is ~1 us
+        int acc = 0;
+        for (int t = 0; t < 1024; ++t) { const int v = part[t]; part[t] = acc; acc += v; }
+        total = acc;
+        count[0] = acc;
+    }
+    __syncthreads();
+    int il = part[threadIdx.x];                   // labelled positions before this thread's segment
+    int iu = total + (lo - il);                   // unlabelled ones go behind all labelled rows, in order
+    for (int i = lo; i < hi; ++i) {
+        const int64_t lab = labels[i];
+        const int slot = lab >= 0 ? il++ : iu++;
+        gather_row[slot] = text_row ? (int)text_row[i] : i;
+        sel_labels[slot] = lab;
+    }
+}
+
+// out[rowmap[i], :] = in[i, :] for i < *count (unique destination rows: the backward pass of the labelled-row gather)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_scatter_kernel(const T* in, T* out, int rows, int C, const int* rowmap, const int* count) {
+    const int n = min(rows, *count);
+    const int CV = C / 4;
+    const long total = (long)n * CV;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % CV) * 4, i = (int)(idx / CV);
+        store4f(out + (long)rowmap[i] * C + c, load4f(in + (long)i * C + c));
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbDev p) {
     const int HV = p.H / 4;
@@ -602,6 +642,24 @@ extern "C" int mvlt_pack_plan(const int64_t* text_ids, const int64_t* labels, in
     MVLT_CHECK(B > 0 && B <= 65536 && T > 0 && n_img >= 0, MVLT_ERR_ARG);
     hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(256), 0, STREAM(stream), text_ids, labels, B, T, n_img, row_start, seq_len,
                        total_rows, row_start64, text_row);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_label_plan(const int64_t* labels, const int64_t* text_row, int N, int32_t* gather_row,
+                               int64_t* sel_labels, int32_t* count, void* stream) {
+    MVLT_CHECK(labels && gather_row && sel_labels && count && N > 0 && N <= (1 << 20), MVLT_ERR_ARG);
+    hipLaunchKernelGGL(label_plan_kernel, dim3(1), dim3(1024), 0, STREAM(stream), labels, text_row, N, gather_row, sel_labels, count);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+extern "C" int mvlt_rows_scatter(int dtype, const void* in, void* out, int rows, int C, const int32_t* rowmap,
+                                 const int32_t* count, void* stream) {
+    MVLT_CHECK(in && out && rowmap && count && rows > 0 && C > 0 && C % 4 == 0, MVLT_ERR_ARG);
+    const int g = grid_for((long)rows * (C / 4), 256);
+    BY_DTYPE(dtype, hipLaunchKernelGGL(rows_scatter_kernel<float>, dim3(g), dim3(256), 0, STREAM(stream), (const float*)in, (float*)out, rows, C, rowmap, count),
+             hipLaunchKernelGGL(rows_scatter_kernel<bf16_t>, dim3(g), dim3(256), 0, STREAM(stream), (const bf16_t*)in, (bf16_t*)out, rows, C, rowmap, count));
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }

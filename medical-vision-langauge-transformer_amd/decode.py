@@ -157,14 +157,17 @@ class _GreedyGraph:
         self.past.add_(1)                        # the [MASK] slot is overwritten by the next step (model.py:890-894)
 
     def capture(self):
+        # scratch buffers (split-K workspace) used inside the graph get their own tag: the captured pointers must
+        # never be freed or handed to other work by a later, larger request on the main stream
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):            # warm-up outside the capture (allocator, lazy module state)
+        with torch.cuda.stream(side), ops.on_stream(side, "graph"):     # warm-up outside the capture (allocator, lazy state)
             self.head(); self.forward2()
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.head(); self.forward2()
+            with ops.on_stream(torch.cuda.current_stream(), "graph"):
+                self.head(); self.forward2()
         self.graph = g
 
 
@@ -226,7 +229,8 @@ def greedy_search(model, image_feature, learning_strategy='unilm', sample_mode='
     tok = getattr(model, "tokenizer", None)
     mask_id = tok.mask_token_id if tok is not None else cfg.mask_token_id
     feat = image_feature.to(cd).contiguous()
-    if sample_mode == 'greedy' and os.environ.get("MVLT_DECODE_GRAPH", "1") == "1":
+    # (the fused decoder-GEMM + argmax of the graph path holds the whole batch in one 64-row tile)
+    if sample_mode == 'greedy' and os.environ.get("MVLT_DECODE_GRAPH", "1") == "1" and feat.shape[0] <= 64:
         return _greedy_graph_loop(model, feat, max_length, pad, eos, mask_id, cd)
     B, n_img, H = feat.shape
     nH = cfg.num_attention_heads

@@ -287,6 +287,27 @@ class _MlmLossFn(torch.autograd.Function):
         return None, dx, None, None, None, None
 
 
+class _GatherRowsFn(torch.autograd.Function):
+    """x = hidden[gather_row] with the backward pass of the labelled-row head: only the first `count` gathered rows
+    carry a gradient and their source rows are distinct, so the backward pass is one scatter into a zeroed buffer
+    (torch's index_put_(accumulate=True) sorts the indices: a radix sort plus ~50 tiny copies per step)."""
+
+    @staticmethod
+    def forward(ctx, hidden, gather_row, count):
+        ctx.save_for_backward(gather_row, count)
+        ctx.shape = hidden.shape
+        with ops.pin_stream():
+            return ops.rows_transform(hidden, rowmap=gather_row)
+
+    @staticmethod
+    def backward(ctx, dx):
+        gather_row, count = ctx.saved_tensors
+        dh = torch.zeros(ctx.shape, dtype=dx.dtype, device=dx.device)
+        with ops.pin_stream():
+            ops.rows_scatter(dx.contiguous(), gather_row, count, dh)
+        return dh, None, None
+
+
 class _LinearCEFn(torch.autograd.Function):
     """Small classifier + cross entropy (ITM, model.py:415-418)."""
 
@@ -465,10 +486,8 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
             rd = None
             lab_first = auto and not compact and getattr(self.config, "mlm_labelled_rows_first", True)
             if lab_first:
-                valid = labels >= 0
-                order = torch.argsort((~valid).to(torch.int8), stable=True)
-                sel_labels = labels[order].contiguous()
-                rd = valid.sum(dtype=torch.int32).reshape(1)
+                with ops.pin_stream():
+                    gather_row, sel_labels, rd = ops.label_plan(labels, text_row)
             if compact:
                 # Only labelled positions contribute to F.cross_entropy(ignore_index=-100) (model.py:410),
                 # so the MLM head (768x30522 decoder, 312 MB of f32 logits in the reference) is evaluated on
@@ -478,9 +497,11 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
                 valid = labels >= 0
                 order = torch.argsort((~valid).to(torch.int8), stable=True)[: cap * B]
                 sel_labels = labels[order].contiguous()
-            if auto:
+            if lab_first:
+                x = _GatherRowsFn.apply(hidden, gather_row, rd)
+            elif auto:
                 # packed row of every caption position (dropped positions: the sample's [CLS] row; label -100)
-                x = hidden[text_row[order] if (compact or lab_first) else text_row]
+                x = hidden[text_row[order] if compact else text_row]
             elif packed:
                 # flat (b, t) -> packed row of caption position t; rows of unlabelled picks are clamped into
                 # range (their label is -100, whatever they gather is ignored)

@@ -146,6 +146,9 @@ class pin_stream:
         _stream_cache[0], _stream_cache[1] = self.prev
 
 
+_ws_graph_keep = []
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -167,6 +170,8 @@ def workspace(name, nbytes, device):
     key = (name, device.index, _stream_cache[1])      # the side stream gets its own scratch buffers
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and _stream_cache[1] == "graph":
+            _ws_graph_keep.append(buf)                 # a captured HIP graph has this pointer baked in: never free it
         if buf is not None and _stream_cache[1] == "side":
             buf.record_stream(side_stream(device))     # a queued side-stream kernel may still be using it
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -624,6 +629,26 @@ def pack_plan(text_ids, labels, n_img):
     L.check(L.lib().mvlt_pack_plan(_p(text_ids), _p(labels), B, T, n_img, _p(rs), _p(sl), _p(tot), _p(rs64), _p(trow),
                                    _stream()), "mvlt_pack_plan")
     return rs, sl, tot, rs64, trow
+
+
+def label_plan(labels, text_row):
+    """Labelled caption positions first (mvlt_label_plan) -> (gather_row i32 [N], sel_labels i64 [N], count i32 [1])."""
+    _need_cuda(labels)
+    assert labels.dtype == torch.int64 and labels.is_contiguous()
+    N = labels.numel()
+    dev = labels.device
+    gr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    sel = torch.empty(N, dtype=torch.int64, device=dev)
+    L.check(L.lib().mvlt_label_plan(_p(labels), _p(text_row), N, _p(gr), _p(sel), C.c_void_p(gr.data_ptr() + 4 * N), _stream()),
+            "mvlt_label_plan")
+    return gr[:N], sel, gr[N:]
+
+
+def rows_scatter(x, rowmap, count, out):
+    """out[rowmap[i]] = x[i] for i < count (device scalar)."""
+    L.check(L.lib().mvlt_rows_scatter(_dt(x), _p(x), _p(out), x.shape[0], x.shape[1], _p(rowmap), _p(count), _stream()),
+            "mvlt_rows_scatter")
+    return out
 
 
 def _embed_struct(dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_id, pos_offset, type_override):
