@@ -101,6 +101,13 @@ int mvlt_gemm_group(const MvltGemm* items, int n, void* stream);
 int mvlt_gemm_argmax(const MvltGemm* p, float* part_val, int32_t* part_idx, int64_t* out_idx, float* out_val,
                      void* stream);
 
+/* Decode step (model.py:82-108: 2 new tokens per sample): skinny product with the reduction split over workgroups,
+ * acc[M,N] (f32, row stride N) += A[M,K] B[N,K]^T, M <= 64, both operands k-contiguous, no epilogue; k_splits
+ * workgroups share every 16-column tile and meet in acc through atomicAdd.  Pair it with mvlt_layernorm_acc_fwd, which
+ * applies bias + residual + LayerNorm (the BertSelfOutput / BertOutput tail, modeling_bert.py:282-293,340-351) and zeroes
+ * acc again. */
+int mvlt_gemm_skinny_accum(const MvltGemm* p, float* acc, int k_splits, void* stream);
+
 /* column sums: out[n] = sum_m x[m*ld + n]  (bias gradients), f32 out.
  * workspace: f32 [mvlt_colsum_workspace_rows(M)][N]. */
 int mvlt_colsum(int dtype, const void* x, int64_t ld, int M, int N, float* out, int accumulate,
@@ -152,6 +159,10 @@ typedef struct MvltLayerNormBwd {
 } MvltLayerNormBwd;
 int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream);
 int mvlt_layernorm_bwd_workspace_rows(void);
+/* y[r,:] = LayerNorm(acc[r,:] + bias + residual[r,:]) * gamma + beta, rows <= a few hundred, C <= 2048; acc (f32) is
+ * zeroed after it is read (see mvlt_gemm_skinny_accum).  residual may be NULL. */
+int mvlt_layernorm_acc_fwd(int dtype, float* acc, const float* bias, const void* residual, const float* gamma,
+                           const float* beta, float eps, int rows, int C, void* y, void* stream);
 /* deferred parameter-gradient reduction: one launch per 24 LayerNorms instead of one per LayerNorm.
  * items is a HOST array; workspace = the buffer given to mvlt_layernorm_bwd, nparts = mvlt_layernorm_bwd_nparts(rows, C). */
 typedef struct MvltLnReduceItem { const float* workspace; int nparts, C; float* dgamma; float* dbeta; } MvltLnReduceItem;

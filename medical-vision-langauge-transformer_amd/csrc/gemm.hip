@@ -589,6 +589,64 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Ge
     }
 }
 
+// Skinny product with K split over workgroups (decode: M = 2B rows, N = 768, K = 768 / 3072).  The plain skinny kernel
+// gives every 16-column workgroup the WHOLE activation matrix to read (N/16 x M x K bytes through L2: 48 x 393 KB for
+// the FFN-out product, 10 us per workgroup at the ~50 GB/s a CU takes in); here workgroup (j, s) reads only k-slice s
+// of it and adds its partial 64x16 tile into an f32 accumulator with atomicAdd.  No epilogue: the consumer
+// (mvlt_layernorm_acc_fwd: + bias + residual, LayerNorm, and it zeroes the accumulator again) is the launch that
+// follows anyway.
+template <typename T>
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_accum_kernel(const GemmDev p, float* accout) {
+    using M_ = Mma<T>;
+    using Frag = typename M_::Frag;
+    constexpr int KB = M_::KB, E = TypeInfo<T>::E;
+    __shared__ f32x4 red[SKINNY_WAVES][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r15 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+    const T* brow = B + (long)min(n0 + r15, p.N - 1) * p.ldb + g * E;
+    const T* arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) arow[i] = A + (long)min(16 * i + r15, p.M - 1) * p.lda + g * E;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkb = p.K / KB;
+    const int per = (nkb + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kb_lo = blockIdx.y * per, kb_hi = min(nkb, kb_lo + per);
+    for (int kb0 = kb_lo + wave; kb0 < kb_hi; kb0 += SKINNY_WAVES * SKINNY_UNROLL) {
+        Frag fb[SKINNY_UNROLL], fa[SKINNY_UNROLL][4];
+#pragma unroll
+        for (int u = 0; u < SKINNY_UNROLL; ++u) {
+            const int kb = kb0 + u * SKINNY_WAVES;
+            const int k = (kb < kb_hi ? kb : kb0) * KB;
+            fb[u] = *reinterpret_cast<const Frag*>(brow + k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[u][i] = *reinterpret_cast<const Frag*>(arow[i] + k);
+        }
+#pragma unroll
+        for (int u = 0; u < SKINNY_UNROLL; ++u) {
+            if (kb0 + u * SKINNY_WAVES < kb_hi) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) M_::mma(acc[i], fb[u], fa[u][i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    const int i = wave;
+    if (i < 4 && 16 * i + r15 < p.M) {
+        f32x4 v = red[0][i][lane];
+#pragma unroll
+        for (int w = 1; w < SKINNY_WAVES; ++w) v += red[w][i][lane];
+        float* c = accout + (long)(16 * i + r15) * p.N + n0 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n0 + 4 * g + r < p.N) atomicAdd(c + r, v[r]);
+    }
+}
+
 // one wave per row: (max, first index) over the workgroup partials
 __global__ __launch_bounds__(64) void argmax_parts_kernel(const float* part_val, const int* part_idx, int nparts,
                                                           int64_t* out_idx, float* out_val) {
@@ -982,6 +1040,23 @@ extern "C" int mvlt_gemm_argmax(const MvltGemm* p, float* part_val, int32_t* par
     if (p->dtype == MVLT_F32) return gemm_argmax_dispatch<float>(p, part_val, part_idx, out_idx, out_val, s);
     if (p->dtype == MVLT_BF16) return gemm_argmax_dispatch<bf16_t>(p, part_val, part_idx, out_idx, out_val, s);
     return MVLT_ERR_UNSUPPORTED;
+}
+
+extern "C" int mvlt_gemm_skinny_accum(const MvltGemm* p, float* acc, int k_splits, void* stream) {
+    MVLT_CHECK(p && p->A && p->B && acc && k_splits >= 1 && k_splits <= 64, MVLT_ERR_ARG);
+    MVLT_CHECK(p->M > 0 && p->M <= 64 && p->N > 0 && p->K > 0 && !p->a_kmajor && !p->b_kmajor && p->epilogue == 0, MVLT_ERR_UNSUPPORTED);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    GemmDev d{};
+    d.M = p->M; d.N = p->N; d.K = p->K; d.A = p->A; d.lda = p->lda; d.B = p->B; d.ldb = p->ldb;
+    if (p->dtype == MVLT_BF16) {
+        MVLT_CHECK(p->K % 32 == 0 && p->lda % 8 == 0 && p->ldb % 8 == 0 && aligned16(p->A) && aligned16(p->B), MVLT_ERR_UNSUPPORTED);
+        hipLaunchKernelGGL((gemm_skinny_accum_kernel<bf16_t>), dim3(ceil_div(p->N, 16), k_splits), dim3(64 * SKINNY_WAVES), 0, s, d, acc);
+    } else if (p->dtype == MVLT_F32) {
+        MVLT_CHECK(p->K % 16 == 0 && p->lda % 4 == 0 && p->ldb % 4 == 0 && aligned16(p->A) && aligned16(p->B), MVLT_ERR_UNSUPPORTED);
+        hipLaunchKernelGGL((gemm_skinny_accum_kernel<float>), dim3(ceil_div(p->N, 16), k_splits), dim3(64 * SKINNY_WAVES), 0, s, d, acc);
+    } else return MVLT_ERR_UNSUPPORTED;
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
 }
 
 extern "C" int mvlt_gemm(const MvltGemm* p, void* stream) {

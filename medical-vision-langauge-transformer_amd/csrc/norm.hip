@@ -242,6 +242,52 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnRed
     }
 }
 
+// y = LayerNorm(acc + bias + residual) for a few rows (decode: 2B <= 64 rows), one wave per row; acc is the f32 output
+// of mvlt_gemm_skinny_accum and is ZEROED after it is read, ready for the next accumulation.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_acc_fwd_kernel(float* acc, const float* bias, const T* residual, const float* gamma,
+                                                        const float* beta, float eps, int rows, int C, T* y) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float* a = acc + (long)r * C;
+    constexpr int MAXV = 8;                           // C <= 2048
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < C) {
+            v[j] = load4f(a + c) + load4f(bias + c);
+            if (residual) v[j] += load4f(residual + (long)r * C + c);
+            store4f(a + c, f32x4{0.f, 0.f, 0.f, 0.f});
+            s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        if (c < C) {
+            const f32x4 ga = load4f(gamma + c), be = load4f(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * ga[e] + be[e];
+            store4f(y + (long)r * C + c, o);
+        }
+    }
+}
+
 constexpr int LN_BWD_PARTS = 256;
 constexpr int LN_BWD_WAVES = 16;
 static int ln_env(const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; }
@@ -294,6 +340,18 @@ int dispatch(const LnDev& d, bool merge, hipStream_t s) {
 }  // namespace
 
 extern "C" int mvlt_layernorm_bwd_workspace_rows(void) { return LN_BWD_PARTS; }
+
+extern "C" int mvlt_layernorm_acc_fwd(int dtype, float* acc, const float* bias, const void* residual, const float* gamma,
+                                      const float* beta, float eps, int rows, int C, void* y, void* stream) {
+    MVLT_CHECK(acc && bias && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, MVLT_ERR_ARG);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(ceil_div(rows, 4));
+    if (dtype == MVLT_BF16) hipLaunchKernelGGL(ln_acc_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, acc, bias, (const bf16_t*)residual, gamma, beta, eps, rows, C, (bf16_t*)y);
+    else if (dtype == MVLT_F32) hipLaunchKernelGGL(ln_acc_fwd_kernel<float>, grid, dim3(256), 0, s, acc, bias, (const float*)residual, gamma, beta, eps, rows, C, (float*)y);
+    else return MVLT_ERR_UNSUPPORTED;
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
 
 extern "C" int mvlt_layernorm_fwd(const MvltLayerNorm* p, void* stream) {
     MVLT_CHECK(p && p->x && p->y && p->gamma && p->beta, MVLT_ERR_ARG);

@@ -26,22 +26,47 @@ from .bert import EncoderOutput
 from .runtime import compute_dtype_of
 
 
+_SKINNY_SPLIT = os.environ.get("MVLT_DECODE_SPLITK", "1") != "0"
+_SPLITS = tuple(int(v) for v in os.environ.get("MVLT_DECODE_SPLITS", "2,4").split(","))      # (attention output, FFN-out)
+
+
 def _layers_cached(mv, ar, x, kc, vc, past, n_new):
     """x: [B*n_new, H] embeddings of the new tokens -> last hidden [B*n_new, H]."""
     cfg = mv.config
     H = cfg.hidden_size
     nH = cfg.num_attention_heads
+    rows = x.shape[0]
+    # the two N = H products of a layer (attention output, FFN-out) split their reduction over workgroups and meet in
+    # an f32 accumulator; bias + residual + LayerNorm read it (and zero it again) in the launch that follows anyway
+    split = _SKINNY_SPLIT and rows <= 64
+    acc = None
+    if split:
+        key = ("decode_acc", rows, H, x.device.index)
+        acc = ar._views.get(key)
+        if acc is None:
+            acc = ar._views[key] = torch.zeros((rows, H), dtype=torch.float32, device=x.device)
     for i, layer in enumerate(mv.encoder.layer):
         sa, so = layer.attention.self, layer.attention.output
         qkv = ops.gemm(x, ar.compute(sa.query.weight, 3 * H), bias=ar.master_span(sa.query.bias, 3 * H))
         ctx = ops.attn_cached(qkv, kc[i], vc[i], past, (H // nH) ** -0.5)
-        y1 = ops.gemm(ctx, ar.compute(so.dense.weight), bias=so.dense.bias.data, residual=x)
-        x1, _, _, _ = ops.layernorm_fwd(y1, so.LayerNorm.weight.data, so.LayerNorm.bias.data, so.LayerNorm.eps,
-                                        save_stats=False)
+        if split:
+            ops.gemm_skinny_accum(ctx, ar.compute(so.dense.weight), acc, _SPLITS[0])
+            x1 = ops.layernorm_acc_fwd(acc, so.dense.bias.data, x, so.LayerNorm.weight.data, so.LayerNorm.bias.data,
+                                       so.LayerNorm.eps, x.dtype)
+        else:
+            y1 = ops.gemm(ctx, ar.compute(so.dense.weight), bias=so.dense.bias.data, residual=x)
+            x1, _, _, _ = ops.layernorm_fwd(y1, so.LayerNorm.weight.data, so.LayerNorm.bias.data, so.LayerNorm.eps,
+                                            save_stats=False)
         a = ops.gemm(x1, ar.compute(layer.intermediate.dense.weight), bias=layer.intermediate.dense.bias.data, gelu=True)
-        y2 = ops.gemm(a, ar.compute(layer.output.dense.weight), bias=layer.output.dense.bias.data, residual=x1)
-        x, _, _, _ = ops.layernorm_fwd(y2, layer.output.LayerNorm.weight.data, layer.output.LayerNorm.bias.data,
-                                       layer.output.LayerNorm.eps, save_stats=False)
+        lo = layer.output
+        if split:
+            ops.gemm_skinny_accum(a, ar.compute(lo.dense.weight), acc, _SPLITS[1])
+            x = ops.layernorm_acc_fwd(acc, lo.dense.bias.data, x1, lo.LayerNorm.weight.data, lo.LayerNorm.bias.data,
+                                      lo.LayerNorm.eps, x1.dtype)
+        else:
+            y2 = ops.gemm(a, ar.compute(lo.dense.weight), bias=lo.dense.bias.data, residual=x1)
+            x, _, _, _ = ops.layernorm_fwd(y2, lo.LayerNorm.weight.data, lo.LayerNorm.bias.data, lo.LayerNorm.eps,
+                                           save_stats=False)
     return x
 
 

@@ -311,6 +311,28 @@ def gemm_argmax(A, W, bias=None):
     return idx, val
 
 
+def gemm_skinny_accum(A, W, acc, k_splits):
+    """acc [M,N] f32 += A [M<=64, K] @ W[N,K]^T with the reduction split over k_splits workgroups per column tile."""
+    _need_cuda(A, W)
+    M, K = A.shape
+    N = W.shape[0]
+    assert acc.dtype == torch.float32 and acc.shape == (M, N) and acc.is_contiguous() and A.stride(1) == 1 and W.stride(1) == 1
+    p = L.MvltGemm()
+    p.dtype, p.M, p.N, p.K = _dt(A), M, N, K
+    p.A, p.lda, p.B, p.ldb = A.data_ptr(), _ld(A), W.data_ptr(), _ld(W)
+    L.check(L.lib().mvlt_gemm_skinny_accum(C.byref(p), _p(acc), int(k_splits), _stream()), "mvlt_gemm_skinny_accum")
+    return acc
+
+
+def layernorm_acc_fwd(acc, bias, residual, gamma, beta, eps, dtype, out=None):
+    """LayerNorm(acc + bias + residual); acc (f32 [rows, C]) is zeroed by the kernel after it is read."""
+    rows, Cn = acc.shape
+    y = out if out is not None else torch.empty((rows, Cn), dtype=dtype, device=acc.device)
+    L.check(L.lib().mvlt_layernorm_acc_fwd(_DT[dtype], _p(acc), _p(bias), _p(residual), _p(gamma), _p(beta), float(eps),
+                                           rows, Cn, _p(y), _stream()), "mvlt_layernorm_acc_fwd")
+    return y
+
+
 def wgrad_group(items):
     """Weight gradients of one layer: items = [(dY [R,No], X [R,Ni], dW f32 [No,Ni], dbias f32 [No] | None), ...]
     -> dW_i = dY_i^T X_i (and dbias_i = column sums of dY_i).  When the items qualify (mvlt_gemm_group) and
