@@ -378,12 +378,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 // (running max / sum) form, and the P.V partial sums are reduced over the key groups once at the end.  No LDS,
 // no barrier.  (The first version walked the keys one at a time with a dependent 2-byte load each: 68 us per
 // layer at past = 200; the two-pass LDS version 21 us.)
+// NW waves per (b, head) take the key blocks round-robin (a report of 150 tokens has <= 202 keys = 4 blocks of 64: one
+// memory round trip per wave instead of four dependent ones) and meet in LDS: wave 0 merges the (max, sum, P.V) triples.
 constexpr int CACHED_MAXNEW = 4, CACHED_MAXK = 1 << 20, CACHED_U = 8;
-template <typename T>
-__global__ __launch_bounds__(64) void attn_cached_kernel(const MvltAttnCached p) {
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_cached_kernel(const MvltAttnCached p) {
     constexpr int E = TypeInfo<T>::E, HD = 64, FC = HD / E, KG = 64 / FC;
     using Vec = typename TypeInfo<T>::Vec;
-    const int lane = threadIdx.x, fc = lane % FC, kg = lane / FC;
+    __shared__ float wm[NW][CACHED_MAXNEW], wl[NW][CACHED_MAXNEW], wo[NW][CACHED_MAXNEW][HD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane % FC, kg = lane / FC;
     const int h = blockIdx.x % p.nH, b = blockIdx.x / p.nH;
     const int past = p.past_dev ? *p.past_dev : p.past;
     const int C = p.nH * HD;
@@ -401,13 +404,13 @@ __global__ __launch_bounds__(64) void attn_cached_kernel(const MvltAttnCached p)
             const Vec qv = *reinterpret_cast<const Vec*>(qkv + (long)r * 3 * C);
 #pragma unroll
             for (int e = 0; e < E; ++e) q[r][e] = to_f(qv[e]) * p.scale;
-            if (kg == 0) {       // append this row's K/V chunk (the loop below reads new rows from qkv_new, not the cache)
+            if (kg == 0 && wave == 0) {       // append this row's K/V chunk (the loop below reads new rows from qkv_new, not the cache)
                 *reinterpret_cast<Vec*>(kc + (long)(past + r) * HD) = *reinterpret_cast<const Vec*>(qkv + (long)r * 3 * C + C);
                 *reinterpret_cast<Vec*>(vc + (long)(past + r) * HD) = *reinterpret_cast<const Vec*>(qkv + (long)r * 3 * C + 2 * C);
             }
         }
     }
-    for (int k0 = 0; k0 < nk; k0 += KG * CACHED_U) {
+    for (int k0 = wave * KG * CACHED_U; k0 < nk; k0 += NW * KG * CACHED_U) {
         Vec kv[CACHED_U], vv[CACHED_U];
 #pragma unroll
         for (int u = 0; u < CACHED_U; ++u) {
@@ -463,17 +466,53 @@ __global__ __launch_bounds__(64) void attn_cached_kernel(const MvltAttnCached p)
         float lt = l[r];
 #pragma unroll
         for (int off = FC; off < 64; off <<= 1) lt += __shfl_xor(lt, off, 64);
-        const float inv = 1.0f / lt;
-        Vec ov;
+        float ov[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             float v = o[r][e];
 #pragma unroll
             for (int off = FC; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            ov[e] = from_f<T>(v * inv);
+            ov[e] = v;
         }
-        if (kg == 0)
-            *reinterpret_cast<Vec*>(reinterpret_cast<T*>(p.out) + ((long)b * p.n_new + r) * C + h * HD + fc * E) = ov;
+        if (NW == 1) {
+            const float inv = 1.0f / lt;
+            Vec ovv;
+#pragma unroll
+            for (int e = 0; e < E; ++e) ovv[e] = from_f<T>(ov[e] * inv);
+            if (kg == 0)
+                *reinterpret_cast<Vec*>(reinterpret_cast<T*>(p.out) + ((long)b * p.n_new + r) * C + h * HD + fc * E) = ovv;
+        } else if (kg == 0) {
+            if (fc == 0) { wm[wave][r] = m[r]; wl[wave][r] = lt; }
+#pragma unroll
+            for (int e = 0; e < E; ++e) wo[wave][r][fc * E + e] = ov[e];
+        }
+    }
+    if (NW > 1) {
+        __syncthreads();
+        if (wave == 0 && kg == 0) {
+#pragma unroll
+            for (int r = 0; r < CACHED_MAXNEW; ++r) {
+                if (r >= p.n_new) break;
+                float mx = wm[0][r];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) mx = fmaxf(mx, wm[w][r]);
+                float lt = 0.f, acc[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const float a = __expf(wm[w][r] - mx);            // a wave that saw no key: exp(-3e38 - mx) = 0
+                    lt += wl[w][r] * a;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[e] += wo[w][r][fc * E + e] * a;
+                }
+                const float inv = 1.0f / lt;
+                Vec ovv;
+#pragma unroll
+                for (int e = 0; e < E; ++e) ovv[e] = from_f<T>(acc[e] * inv);
+                *reinterpret_cast<Vec*>(reinterpret_cast<T*>(p.out) + ((long)b * p.n_new + r) * C + h * HD + fc * E) = ovv;
+            }
+        }
     }
 }
 
@@ -825,8 +864,12 @@ extern "C" int mvlt_attn_cached(const MvltAttnCached* p, void* stream) {
                       aligned16(p->qkv_new) && aligned16(p->k_cache) && aligned16(p->v_cache) && aligned16(p->out);
     if (fast) {
         dim3 grid(p->B * p->nH);
-        BY_DTYPE(p->dtype, hipLaunchKernelGGL(attn_cached_kernel<float>, grid, dim3(64), 0, STREAM(stream), *p),
-                 hipLaunchKernelGGL(attn_cached_kernel<bf16_t>, grid, dim3(64), 0, STREAM(stream), *p));
+        // bf16: a key block is 64 keys; four waves cover the <= 202 keys of a 150-token report in one round trip each
+        if (p->cache_cap > 64 && p->dtype == MVLT_BF16)
+            hipLaunchKernelGGL((attn_cached_kernel<bf16_t, 4>), grid, dim3(256), 0, STREAM(stream), *p);
+        else
+            BY_DTYPE(p->dtype, hipLaunchKernelGGL((attn_cached_kernel<float, 1>), grid, dim3(64), 0, STREAM(stream), *p),
+                     hipLaunchKernelGGL((attn_cached_kernel<bf16_t, 1>), grid, dim3(64), 0, STREAM(stream), *p));
     } else {
         dim3 grid(p->B * p->nH * p->n_new);
         BY_DTYPE(p->dtype, hipLaunchKernelGGL(attn_cached_serial_kernel<float>, grid, dim3(64), 0, STREAM(stream), *p),
