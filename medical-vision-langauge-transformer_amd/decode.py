@@ -38,7 +38,8 @@ def _layers_cached(mv, ar, x, kc, vc, past, n_new):
     rows = x.shape[0]
     # the two N = H products of a layer (attention output, FFN-out) split their reduction over workgroups and meet in
     # an f32 accumulator; bias + residual + LayerNorm read it (and zero it again) in the launch that follows anyway
-    split = _SKINNY_SPLIT and rows <= 64
+    # (bf16 only: the exact-f32 parity mode keeps the deterministic summation order of the plain skinny kernel)
+    split = _SKINNY_SPLIT and rows <= 64 and x.dtype == torch.bfloat16
     acc = None
     if split:
         key = ("decode_acc", rows, H, x.device.index)
