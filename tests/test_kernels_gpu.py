@@ -682,3 +682,65 @@ def test_device_row_count_gemm_and_layernorm(ops, dt):
     torch.nn.functional.layer_norm(xr, (C_,), gr, br, 1e-5).backward(dyl[:R].float())
     t = tol(dt) * 2
     assert rel(dx[:R], xr.grad) < t and rel(dg, gr.grad) < t and rel(dbt, br.grad) < t and bool((dx[R:] == 7.0).all())
+
+
+def test_label_plan_and_rows_scatter(ops):
+    """mvlt_label_plan (labelled positions first, stable; INT: bit-exact) and mvlt_rows_scatter (backward of the gather)."""
+    torch.manual_seed(9)
+    N, H = 37 * 24, 64
+    labels = torch.full((N,), -100, dtype=torch.int64)
+    pick = torch.randperm(N)[:101]
+    labels[pick] = torch.randint(0, 3000, (101,))
+    text_row = torch.randperm(4 * N)[:N].to(torch.int64)                 # distinct packed rows
+    gr, sel, cnt = ops.label_plan(labels.cuda(), text_row.cuda())
+    order = torch.cat([torch.nonzero(labels >= 0).flatten(), torch.nonzero(labels < 0).flatten()])
+    assert int(cnt.item()) == 101
+    assert torch.equal(gr.cpu().long(), text_row[order]) and torch.equal(sel.cpu(), labels[order])
+    gr2, sel2, cnt2 = ops.label_plan(labels.cuda(), None)                # identity rows
+    assert torch.equal(gr2.cpu().long(), order) and int(cnt2.item()) == 101
+    for dt in DT:
+        dx = rnd((N, H), dt, 10)
+        out = torch.zeros((4 * N, H), dtype=dt, device="cuda")
+        ops.rows_scatter(dx, gr, cnt, out)
+        ref = torch.zeros((4 * N, H), dtype=dt)
+        ref[text_row[order][:101]] = dx.cpu()[:101]
+        assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_ragged_cross_entropy(ops, dt):
+    """mvlt_ce_fwd_ragged / _bwd_ragged: rows beyond the device-side count are neither read (NaN poison) nor written."""
+    rows, V, R = 40, 1000, 23
+    ld = 1024
+    logits = rnd((rows, ld), dt, 11)
+    logits[R:] = float("nan")
+    labels = torch.randint(0, V, (rows,))
+    labels[3] = -100
+    rd = torch.tensor([R], dtype=torch.int32).cuda()
+    acc, lse = ops.ce_fwd(logits, V, labels.cuda(), rows_dev=rd)
+    ref = torch.nn.functional.cross_entropy(logits[:R, :V].float().cpu(), labels[:R], ignore_index=-100, reduction="sum")
+    assert abs(acc[0].item() - ref.item()) < tol(dt) * abs(ref.item()) and acc[1].item() == R - 1
+    keep = logits.clone()
+    d = ops.ce_bwd(logits, V, labels.cuda(), lse, acc, rows_dev=rd)
+    lg = keep[:R, :V].float().cpu().requires_grad_(True)
+    torch.nn.functional.cross_entropy(lg, labels[:R], ignore_index=-100).backward()
+    assert rel(d[:R, :V].float().cpu(), lg.grad) < tol(dt) * 2
+    assert bool(torch.isnan(d[R:].float()).all())                       # untouched
+
+
+def test_skinny_accum_and_layernorm_from_accumulator(ops):
+    """Decode tails: acc += A W^T with the reduction split over workgroups (mvlt_gemm_skinny_accum), then
+    LayerNorm(acc + bias + residual) with the accumulator zeroed again (mvlt_layernorm_acc_fwd)."""
+    for dt in DT:
+        M, N, K = 64, 768, 3072
+        a = rnd((M, K), dt, 12, K ** -0.5); w = rnd((N, K), dt, 13)
+        bias = torch.randn(N).cuda(); res = rnd((M, N), dt, 14)
+        g = (1.0 + 0.1 * torch.randn(N)).cuda(); b = (0.1 * torch.randn(N)).cuda()
+        acc = torch.zeros((M, N), device="cuda")
+        for splits in (1, 4):
+            ops.gemm_skinny_accum(a, w, acc, splits)
+            ref = a.float() @ w.float().t()
+            assert rel(acc, ref) < tol(dt)
+            y = ops.layernorm_acc_fwd(acc, bias, res, g, b, 1e-12, dt)
+            yr = torch.nn.functional.layer_norm(ref + bias + res.float(), (N,), g, b, 1e-12)
+            assert rel(y, yr) < tol(dt) * 2 and float(acc.abs().max()) == 0.0
