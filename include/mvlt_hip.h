@@ -218,9 +218,10 @@ int mvlt_attn_bwd(const MvltAttn* p, void* stream);   /* delta_ws: f32 [nseq,nH,
  *   attn_out [B*res*res, C]  attention output, window order (A operand of the proj weight gradient)
  *   lse      f32 [B*nW, nH, 49], mean / rstd f32 [B*res*res] (token order)
  * backward (mvlt_swin_wmsa_bwd): dy_win = gradient of the proj output in WINDOW order (rowscale already applied);
- *   recomputes q,k,v from xn_win, writes dqkv [B*res*res, 3C] (window order, for the qkv weight gradient) and
- *   dxn_win [B*res*res, C] = dqkv Wqkv (window order; LayerNorm backward consumes it through its dy_rowmap);
- *   dbias_table f32 [169, nH] is ACCUMULATED (zero it first). */
+ *   output-projection dgrad, attention backward and qkv dgrad in one launch: reads q,k,v from qkv_win and lse (saved
+ *   by the forward pass) and the transposed weight copies wproj_t / wqkv_t, writes dqkv [B*res*res, 3C] (window
+ *   order, for the qkv weight gradient) and dxn_win [B*res*res, C] = dqkv Wqkv (window order; LayerNorm backward
+ *   consumes it through its dy_rowmap); dbias_table f32 [169, nH] is ACCUMULATED (zero it first). */
 typedef struct MvltSwinWmsa {
     int dtype, B, res, C, nH, shift;
     const void* x; void* y; const int32_t* w2n;
@@ -234,10 +235,14 @@ typedef struct MvltSwinWmsa {
     /* optional, training: q,k,v in the [B*res*res, 3C] window-order layout MvltAttn uses (forward: write-only
      * output, so the unfused mvlt_attn_bwd can run on a fused forward; backward: read instead of recomputed) */
     void* qkv_win;
+    /* backward only: TRANSPOSED compute-dtype copies of the projection weights, wproj_t [C_in, C_out] = proj.weight^T and
+     * wqkv_t [C, 3C] = qkv.weight^T (mvlt_transpose_batch makes them): the dgrad products then read k-contiguous rows */
+    const void* wproj_t; const void* wqkv_t;
 } MvltSwinWmsa;
 int mvlt_swin_wmsa_supported(int dtype, int C, int nH);   /* 1 when the fused kernels cover this width */
 int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream);
 int mvlt_swin_wmsa_bwd(const MvltSwinWmsa* p, void* stream);
+int mvlt_swin_wmsa_bwd_supported(int dtype, int C, int nH);
 
 /* ------------------------------------------------------------------ data movement / embeddings
  * PatchEmbed im2col (visual_feature_extractor.py:562): img f32 NCHW [B,3,S,S]

@@ -74,7 +74,8 @@ class MvltSwinWmsa(C.Structure):
                 ("wqkv", vp), ("bqkv", vp), ("wproj", vp), ("bproj", vp),
                 ("bias_table", vp), ("scale", f32), ("rowscale", vp),
                 ("xn_win", vp), ("attn_out", vp), ("lse", vp), ("mean", vp), ("rstd", vp),
-                ("dy_win", vp), ("dqkv", vp), ("dxn_win", vp), ("dbias_table", vp), ("qkv_win", vp)]
+                ("dy_win", vp), ("dqkv", vp), ("dxn_win", vp), ("dbias_table", vp), ("qkv_win", vp),
+                ("wproj_t", vp), ("wqkv_t", vp)]
 
 
 class MvltEmbed(C.Structure):
@@ -125,6 +126,7 @@ SYMBOLS = {
     "mvlt_swin_wmsa_supported": (i32, [i32, i32, i32]),
     "mvlt_swin_wmsa_fwd": (i32, [C.POINTER(MvltSwinWmsa), vp]),
     "mvlt_swin_wmsa_bwd": (i32, [C.POINTER(MvltSwinWmsa), vp]),
+    "mvlt_swin_wmsa_bwd_supported": (i32, [i32, i32, i32]),
     "mvlt_im2col_patch": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "mvlt_pack_plan": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "mvlt_label_plan": (i32, [vp, vp, i32, vp, vp, vp, vp]),

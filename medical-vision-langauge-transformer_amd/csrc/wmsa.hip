@@ -394,6 +394,349 @@ __global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
     }
 }
 
+// ===================================================================================================== backward
+// mvlt_swin_wmsa_bwd: output-projection dgrad + window-attention backward + qkv dgrad of one block in ONE launch.
+//   dao = dy_win Wproj            (per head: [64, C] x [C, 32], weights read through the TRANSPOSED copy wproj_t)
+//   per head: P = exp(S - lse), dP = dao V^T, delta = rowsum(P o dP), dS = P o (dP - delta),
+//             dQ = scale dS K, dK = scale dS^T Q, dV = P^T dao, dBias[relidx] += dS
+//   dxn = dqkv Wqkv               ([64, 96] x [96, C] per head, accumulated over heads; wqkv_t)
+// The attention part runs twice, in both orientations (keys on accumulator rows -> dQ, dBias; queries on accumulator
+// rows -> dK, dV), like attn.hip, so no score tile is ever transposed through LDS.  q/k/v come from what the forward
+// pass saved (qkv_win); dao and delta never leave the chip; dqkv is written once for the qkv weight gradient.
+// Workgroups are persistent over windows (<= 512 of them) so the bias-table gradient is flushed once per workgroup.
+struct WmsaBwdDev {
+    int nwin, nW, res, shift, nH;
+    const void* dy; const void* qkv; const float* lse; const void* wproj_t; const void* wqkv_t;
+    const float* bias_table; float scale;
+    void* dqkv; void* dxn; float* dbias;
+};
+
+template <typename T, int C> struct WmsaBwdGeom {
+    static constexpr int PAD = sizeof(T) == 2 ? 8 : 4;
+    static constexpr int LDX = C + PAD, LDH = 32 + PAD;
+    static constexpr size_t XB = (size_t)64 * LDX * sizeof(T);            // dy tile
+    static constexpr size_t HB = (size_t)64 * LDH * sizeof(T);            // one [64, 32] head tile
+    static constexpr int TBL = 176;
+    // dy | q k v | dao | dq dk dv | lse, delta | bias values, bias gradients
+    static constexpr size_t bytes(int nH) { return XB + 7 * HB + 2 * 64 * sizeof(float) + (size_t)2 * nH * TBL * sizeof(float); }
+};
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void wmsa_bwd_kernel(const WmsaBwdDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using GM = WmsaBwdGeom<T, C>;
+    using M = Mma<T>;
+    using Frag = typename M::Frag;
+    using Vec = typename TypeInfo<T>::Vec;
+    constexpr int E = TypeInfo<T>::E, KB = M::KB;
+    constexpr int LDX = GM::LDX, LDH = GM::LDH;
+    constexpr int KSTEPS = C / KB, KBD = 32 / KB;
+    constexpr int TPB = Tok<T>::TPB, KBT = 4 / TPB;
+    constexpr int NTP = C / 16, NTPW = (NTP + 3) / 4;
+    constexpr int nH = C / 32;
+    T* dyt = reinterpret_cast<T*>(smem_raw);
+    T* qt = reinterpret_cast<T*>(smem_raw + GM::XB);
+    T* kt = qt + 64 * LDH;
+    T* vt = kt + 64 * LDH;
+    T* dot = vt + 64 * LDH;                 // dao of the head ("dO")
+    T* dqt = dot + 64 * LDH;
+    T* dkt = dqt + 64 * LDH;
+    T* dvt = dkt + 64 * LDH;
+    float* lsel = reinterpret_cast<float*>(dvt + 64 * LDH);
+    float* dl = lsel + 64;
+    float* tbl = dl + 64;
+    float* tblg = tbl + nH * GM::TBL;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c15 = lane & 15;
+    const T* wp = reinterpret_cast<const T*>(p.wproj_t);
+    const T* wq = reinterpret_cast<const T*>(p.wqkv_t);
+    const T* dyg = reinterpret_cast<const T*>(p.dy);
+    const T* qkvg = reinterpret_cast<const T*>(p.qkv);
+
+    for (int i = threadIdx.x; i < nH * GM::TBL; i += 256) {
+        const int h = i / GM::TBL, e = i - h * GM::TBL;
+        tbl[i] = e < 169 ? p.bias_table[e * nH + h] : NEG_BIG;
+        tblg[i] = 0.f;
+    }
+    // orientation A: this wave's lanes are queries 16 wave + c15, registers are keys 16 t + 4 g + j
+    // orientation B: lanes are keys 16 wave + c15, registers are queries; relidx(q, k) = 168 - relidx(k, q)
+    LanePairs lp;
+    lp.init(16 * wave + c15, g, p.shift);
+    const int lrow = 16 * wave + c15;
+    // dBias: every window maps (query, key) to the same lane / register, so dS is summed in registers over all windows
+    // this workgroup walks and reaches the LDS table (then global memory) once; per-window LDS atomics -- 4096 colliding
+    // ds_add_f32 per head -- were most of the first version's time.  Only for <= 3 heads (stage 0): more heads would need the head loop unrolled (512 registers, spills); they use the LDS table.
+    constexpr int REGH = nH <= 3 ? nH : 0;
+    f32x4 dbacc[REGH > 0 ? REGH : 1][4];
+#pragma unroll
+    for (int h = 0; h < (REGH > 0 ? REGH : 1); ++h)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dbacc[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Software pipeline over (window, head): the dy rows of the next window and the q/k/v rows + lse of the next head
+    // are requested into registers one step ahead and written to LDS when their tiles are free, so a workgroup does not
+    // start every head with an exposed HBM round trip.
+    constexpr int CPR = C / E, CPL = CPR / 4;
+    static_assert(CPR % 4 == 0, "row chunks");
+    constexpr int CH = 32 / E, NQ = 64 * 3 * CH / 256;          // 16-byte q/k/v chunks per thread and head
+    Vec dyr[CPL], qr[NQ];
+    float lser = 0.f;
+    auto fetch_dy = [&](int win) {
+        const int row = threadIdx.x >> 2, sub = threadIdx.x & 3;
+        const T* src = dyg + ((long)win * 49 + row) * C;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) dyr[i] = row < 49 ? *reinterpret_cast<const Vec*>(src + (sub + 4 * i) * E) : zero_vec<T>();
+    };
+    auto fetch_qkv = [&](int win, int h) {
+        const T* qg = qkvg + (long)win * 49 * 3 * C + h * 32;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int ch = idx % CH, part = (idx / CH) % 3, r = idx / (CH * 3);
+            qr[i] = r < 49 ? *reinterpret_cast<const Vec*>(qg + (long)r * 3 * C + part * C + ch * E) : zero_vec<T>();
+        }
+        if (threadIdx.x < 64) lser = threadIdx.x < 49 ? p.lse[((long)win * nH + h) * 49 + threadIdx.x] : 0.f;
+    };
+    if ((int)blockIdx.x < p.nwin) { fetch_dy(blockIdx.x); fetch_qkv(blockIdx.x, 0); }
+
+#pragma unroll 1
+    for (int win = blockIdx.x; win < p.nwin; win += gridDim.x) {
+        __syncthreads();                                       // the previous window is done with every tile
+        // ---- dy tile (window order rows are contiguous)
+        {
+            const int row = threadIdx.x >> 2, sub = threadIdx.x & 3;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) *reinterpret_cast<Vec*>(dyt + row * LDX + (sub + 4 * i) * E) = dyr[i];
+        }
+        uint32_t mbits = 0;
+        if (p.shift != 0) {
+            const int w = win % p.nW, nwx = p.res / 7;
+            const int wy = w / nwx, wx = w - wy * nwx;
+            mbits = (wy == nwx - 1 ? lp.rowbits : 0u) | (wx == nwx - 1 ? lp.colbits : 0u);
+        }
+        f32x4 pacc[4][NTPW];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NTPW; ++jj) pacc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+
+#pragma unroll (nH <= 3 ? nH : 1)
+        for (int h = 0; h < nH; ++h) {
+            // ================= dao_h rows [16 wave, +16) = dy rows x Wproj[:, 32 h ..]  (both 16-column tiles per wave)
+            {
+                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                const T* arow = dyt + (16 * wave + c15) * LDX + g * E;
+                const T* w0 = wp + (long)(32 * h + c15) * C + g * E;
+                const T* w1 = w0 + (long)16 * C;
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const Frag fa = *reinterpret_cast<const Frag*>(arow + kk * KB);
+                    M::mma(acc[0], *reinterpret_cast<const Frag*>(w0 + kk * KB), fa);
+                    M::mma(acc[1], *reinterpret_cast<const Frag*>(w1 + kk * KB), fa);
+                }
+                store4f(dot + lrow * LDH + 4 * g, acc[0]);
+                store4f(dot + lrow * LDH + 16 + 4 * g, acc[1]);
+            }
+            // ================= q, k, v of the head (saved by the forward pass) and the softmax statistics -> LDS
+            {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const int idx = threadIdx.x + 256 * i;
+                    const int ch = idx % CH, part = (idx / CH) % 3, r = idx / (CH * 3);
+                    *reinterpret_cast<Vec*>(qt + (part * 64 + r) * LDH + ch * E) = qr[i];
+                }
+                if (threadIdx.x < 64) lsel[threadIdx.x] = lser;
+                // next (window, head) of this workgroup: request it now
+                const int nwin_ = h + 1 < nH ? win : win + (int)gridDim.x;
+                if (nwin_ < p.nwin) {
+                    fetch_qkv(nwin_, h + 1 < nH ? h + 1 : 0);
+                    if (h + 1 == nH) fetch_dy(nwin_);
+                }
+            }
+            __syncthreads();
+            const float* tb = tbl + h * GM::TBL;
+            float* tg = tblg + h * GM::TBL;
+            // ================= orientation A: queries on lanes -> delta, dBias, dQ
+            {
+                f32x4 sc[4], dp[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = sc[t]; }
+                Frag fq[KBD], fd[KBD];
+#pragma unroll
+                for (int kb = 0; kb < KBD; ++kb) {
+                    fq[kb] = frag_rowmajor<T>(qt, LDH, 16 * wave, kb * KB);
+                    fd[kb] = frag_rowmajor<T>(dot, LDH, 16 * wave, kb * KB);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int kb = 0; kb < KBD; ++kb) {
+                        M::mma(sc[t], frag_rowmajor<T>(kt, LDH, 16 * t, kb * KB), fq[kb]);
+                        M::mma(dp[t], frag_rowmajor<T>(vt, LDH, 16 * t, kb * KB), fd[kb]);
+                    }
+                const float lq = lsel[lrow];
+                float delta = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = fmaf(sc[t][j], p.scale, tb[(lp.ridx[t] >> (8 * j)) & 255u]);
+                        if (mbits & (1u << (4 * t + j))) v -= 100.0f;
+                        const float pr = __expf(v - lq);                  // padded pairs: exp(-1e30 - lse) = 0
+                        sc[t][j] = pr;
+                        delta += pr * dp[t][j];
+                    }
+                delta += __shfl_xor(delta, 16, 64);
+                delta += __shfl_xor(delta, 32, 64);
+                if (g == 0) dl[lrow] = delta;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ds = sc[t][j] * (dp[t][j] - delta);
+                        sc[t][j] = ds;
+                        if (REGH > 0) dbacc[REGH > 0 ? h : 0][t][j] += ds;
+                        else {
+                            const uint32_t ri = (lp.ridx[t] >> (8 * j)) & 255u;
+                            if (ri < 169u) atomicAdd(tg + ri, ds);
+                        }
+                    }
+                f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int kb = 0; kb < KBT; ++kb) {
+                    const Frag fp = frag_acc<4>(sc, kb, T());
+#pragma unroll
+                    for (int td = 0; td < 2; ++td) M::mma(dq[td], frag_tok(kt, LDH, 16 * td, kb), fp);
+                }
+#pragma unroll
+                for (int td = 0; td < 2; ++td) store4f(dqt + lrow * LDH + 16 * td + 4 * g, dq[td] * p.scale);
+            }
+            __syncthreads();                                   // delta of every query is in LDS
+            // ================= orientation B: keys on lanes -> dK, dV
+            {
+                f32x4 sc[4], dp[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = sc[t]; }
+                Frag fk[KBD], fv[KBD];
+#pragma unroll
+                for (int kb = 0; kb < KBD; ++kb) {
+                    fk[kb] = frag_rowmajor<T>(kt, LDH, 16 * wave, kb * KB);
+                    fv[kb] = frag_rowmajor<T>(vt, LDH, 16 * wave, kb * KB);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int kb = 0; kb < KBD; ++kb) {
+                        M::mma(sc[t], frag_rowmajor<T>(qt, LDH, 16 * t, kb * KB), fk[kb]);
+                        M::mma(dp[t], frag_rowmajor<T>(dot, LDH, 16 * t, kb * KB), fv[kb]);
+                    }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int qr = 16 * t + 4 * g + j;
+                        const uint32_t ri = (lp.ridx[t] >> (8 * j)) & 255u;           // relidx(lane key as query, register as key)
+                        float v = fmaf(sc[t][j], p.scale, tb[ri < 169u ? 168u - ri : 169u]);
+                        if (mbits & (1u << (4 * t + j))) v -= 100.0f;
+                        const float pr = __expf(v - lsel[qr]);
+                        sc[t][j] = pr;                                                 // P[q, k]
+                        dp[t][j] = pr * (dp[t][j] - dl[qr]);                           // dS[q, k]
+                    }
+                f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dk[2] = {dv[0], dv[0]};
+#pragma unroll
+                for (int kb = 0; kb < KBT; ++kb) {
+                    const Frag fp = frag_acc<4>(sc, kb, T());
+                    const Frag fs = frag_acc<4>(dp, kb, T());
+#pragma unroll
+                    for (int td = 0; td < 2; ++td) {
+                        M::mma(dv[td], frag_tok(dot, LDH, 16 * td, kb), fp);
+                        M::mma(dk[td], frag_tok(qt, LDH, 16 * td, kb), fs);
+                    }
+                }
+#pragma unroll
+                for (int td = 0; td < 2; ++td) {
+                    store4f(dvt + lrow * LDH + 16 * td + 4 * g, dv[td]);
+                    store4f(dkt + lrow * LDH + 16 * td + 4 * g, dk[td] * p.scale);
+                }
+            }
+            __syncthreads();
+            // ================= dqkv of the head -> HBM (qkv weight gradient), and dxn += dqkv_h Wqkv[(q|k|v) head rows, :]
+            {
+                T* og = reinterpret_cast<T*>(p.dqkv) + (long)win * 49 * 3 * C + h * 32;
+                for (int idx = threadIdx.x; idx < 49 * 3 * CH; idx += 256) {
+                    const int ch = idx % CH, part = (idx / CH) % 3, r = idx / (CH * 3);
+                    *reinterpret_cast<Vec*>(og + (long)r * 3 * C + part * C + ch * E) =
+                        *reinterpret_cast<const Vec*>(dqt + (part * 64 + r) * LDH + ch * E);
+                }
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+#pragma unroll
+                    for (int kb = 0; kb < KBD; ++kb) {
+                        Frag fa[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fa[i] = frag_rowmajor<T>(dqt + part * 64 * LDH, LDH, 16 * i, kb * KB);
+#pragma unroll
+                        for (int jj = 0; jj < NTPW; ++jj) {
+                            const int t = wave + 4 * jj;
+                            if (t < NTP) {
+                                const Frag fb = *reinterpret_cast<const Frag*>(wq + (long)(16 * t + c15) * 3 * C + part * C + h * 32 + kb * KB + g * E);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) M::mma(pacc[i][jj], fb, fa[i]);
+                            }
+                        }
+                    }
+            }
+            // (the next head's first barrier comes after its dao / q,k,v writes, which touch other tiles than dq/dk/dv)
+        }
+        // ---- dxn rows of this window
+        {
+            T* xg = reinterpret_cast<T*>(p.dxn) + (long)win * 49 * C;
+#pragma unroll
+            for (int jj = 0; jj < NTPW; ++jj) {
+                const int t = wave + 4 * jj;
+                if (t < NTP) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (16 * i + c15 < 49) store4f(xg + (long)(16 * i + c15) * C + 16 * t + 4 * g, pacc[i][jj]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (REGH > 0) {
+#pragma unroll
+        for (int h = 0; h < (REGH > 0 ? REGH : 1); ++h)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t ri = (lp.ridx[t] >> (8 * j)) & 255u;
+                    if (ri < 169u) atomicAdd(tblg + h * GM::TBL + ri, dbacc[h][t][j]);
+                }
+        __syncthreads();
+    }
+    if (p.dbias)
+        for (int i = threadIdx.x; i < nH * 169; i += 256) {
+            const int h = i / 169, e = i - h * 169;
+            atomicAdd(&p.dbias[e * nH + h], tblg[h * GM::TBL + e]);
+        }
+}
+
+template <typename T, int C>
+int launch_bwd(const WmsaBwdDev& d, hipStream_t s) {
+    using GM = WmsaBwdGeom<T, C>;
+    constexpr size_t sh = GM::bytes(C / 32);
+    static_assert(sh <= 160 * 1024, "LDS");
+    auto k = wmsa_bwd_kernel<T, C>;
+    if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static const int cap = [] { const char* e = getenv("MVLT_WMSA_BWD_GRID"); return e ? atoi(e) : 512; }();
+    const int grid = d.nwin < cap ? d.nwin : cap;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), sh, s, d);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
 template <typename T, int C, int G, int NW>
 int launch_fwd(const WmsaDev& d, hipStream_t s) {
     using GM = WmsaGeom<T, C, G>;
@@ -482,7 +825,41 @@ extern "C" int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream) {
     return dispatch_fwd_bf16(d, p->C, s);
 }
 
+extern "C" int mvlt_swin_wmsa_bwd_supported(int dtype, int C, int nH) {
+    if (nH * 32 != C) return 0;
+    if (dtype == MVLT_BF16) return C == 96 || C == 192 || C == 384 || C == 128 || C == 256;
+    if (dtype == MVLT_F32) return C == 96 || C == 192 || C == 128;
+    return 0;
+}
+
 extern "C" int mvlt_swin_wmsa_bwd(const MvltSwinWmsa* p, void* stream) {
-    (void)p; (void)stream;
-    return MVLT_ERR_UNSUPPORTED;
+    MVLT_CHECK(p && p->dy_win && p->qkv_win && p->lse && p->wproj_t && p->wqkv_t && p->bias_table, MVLT_ERR_ARG);
+    MVLT_CHECK(p->dqkv && p->dxn_win, MVLT_ERR_ARG);
+    MVLT_CHECK(p->B > 0 && p->res > 0 && p->res % 7 == 0 && p->shift >= 0 && p->shift < 7, MVLT_ERR_ARG);
+    MVLT_CHECK(aligned16(p->dy_win) && aligned16(p->qkv_win) && aligned16(p->wproj_t) && aligned16(p->wqkv_t), MVLT_ERR_ARG);
+    MVLT_CHECK(aligned16(p->dqkv) && aligned16(p->dxn_win), MVLT_ERR_ARG);
+    if (!mvlt_swin_wmsa_bwd_supported(p->dtype, p->C, p->nH)) return MVLT_ERR_UNSUPPORTED;
+    WmsaBwdDev d{};
+    d.nW = (p->res / 7) * (p->res / 7);
+    d.nwin = p->B * d.nW; d.res = p->res; d.shift = p->shift; d.nH = p->nH;
+    d.dy = p->dy_win; d.qkv = p->qkv_win; d.lse = p->lse; d.wproj_t = p->wproj_t; d.wqkv_t = p->wqkv_t;
+    d.bias_table = p->bias_table; d.scale = p->scale;
+    d.dqkv = p->dqkv; d.dxn = p->dxn_win; d.dbias = p->dbias_table;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p->dtype == MVLT_F32) {
+        switch (p->C) {
+            case 96:  return launch_bwd<float, 96>(d, s);
+            case 192: return launch_bwd<float, 192>(d, s);
+            case 128: return launch_bwd<float, 128>(d, s);
+            default: return MVLT_ERR_UNSUPPORTED;
+        }
+    }
+    switch (p->C) {
+        case 96:  return launch_bwd<bf16_t, 96>(d, s);
+        case 192: return launch_bwd<bf16_t, 192>(d, s);
+        case 384: return launch_bwd<bf16_t, 384>(d, s);
+        case 128: return launch_bwd<bf16_t, 128>(d, s);
+        case 256: return launch_bwd<bf16_t, 256>(d, s);
+        default: return MVLT_ERR_UNSUPPORTED;
+    }
 }

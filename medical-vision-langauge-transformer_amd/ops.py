@@ -624,6 +624,30 @@ def swin_wmsa_fwd(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj
     return y, saved
 
 
+def swin_wmsa_bwd_supported(dtype, C_, nH):
+    return bool(L.lib().mvlt_swin_wmsa_bwd_supported(_DT[dtype], C_, nH))
+
+
+def swin_wmsa_bwd(dy_win, qkv_win, lse, B, res, nH, shift, wproj_t, wqkv_t, table, scale, dtable):
+    """Output-projection dgrad + window-attention backward + qkv dgrad in one launch (mvlt_swin_wmsa_bwd).
+    dy_win [rows, C] window order (DropPath scale applied); wproj_t = proj.weight^T, wqkv_t = qkv.weight^T (compute
+    dtype, contiguous).  Returns (dqkv [rows, 3C], dxn_win [rows, C]); dtable (f32 [169, nH]) is accumulated."""
+    _need_cuda(dy_win)
+    rows, Cn = dy_win.shape
+    assert dy_win.is_contiguous() and qkv_win.is_contiguous() and qkv_win.shape == (rows, 3 * Cn)
+    assert wproj_t.is_contiguous() and wproj_t.shape == (Cn, Cn) and wqkv_t.is_contiguous() and wqkv_t.shape == (Cn, 3 * Cn)
+    assert lse.dtype == torch.float32 and table.dtype == torch.float32 and dtable.dtype == torch.float32
+    p = L.MvltSwinWmsa()
+    p.dtype, p.B, p.res, p.C, p.nH, p.shift = _DT[dy_win.dtype], B, res, Cn, nH, shift
+    p.dy_win, p.qkv_win, p.lse = dy_win.data_ptr(), qkv_win.data_ptr(), lse.data_ptr()
+    p.wproj_t, p.wqkv_t, p.bias_table, p.scale = wproj_t.data_ptr(), wqkv_t.data_ptr(), table.data_ptr(), float(scale)
+    dqkv = torch.empty_like(qkv_win)
+    dxn = torch.empty_like(dy_win)
+    p.dqkv, p.dxn_win, p.dbias_table = dqkv.data_ptr(), dxn.data_ptr(), dtable.data_ptr()
+    L.check(L.lib().mvlt_swin_wmsa_bwd(C.byref(p), _stream()), "mvlt_swin_wmsa_bwd")
+    return dqkv, dxn
+
+
 # ----------------------------------------------------------------------------- data movement
 def im2col_patch(img, dtype, patch):
     _need_cuda(img)

@@ -104,6 +104,7 @@ class PatchEmbed(nn.Module):
         self.norm = nn.LayerNorm(embed_dim)
 
 
+_FUSED_WMSA_BWD = os.environ.get("MVLT_FUSED_WMSA_BWD", "0") == "1"
 _FUSED_WMSA = os.environ.get("MVLT_FUSED_WMSA", "auto")     # "0" never, "1" wherever supported, "auto" where it wins
 
 
@@ -401,12 +402,20 @@ class SwinTransformer(nn.Module):
                                      g(blk.norm2.bias), dres=dx2,
                                      branch=dict(rowmap=n2w, rowscale=(s1, Lt) if s1 is not None else None),
                                      defer=self.__dict__["_lnq"])
-        dao = ops.gemm(dyw, ar.compute(at.proj.weight), b_kmajor=True)
         dtab = g(at.relative_position_bias_table)          # zeroed for all blocks at once in _backward
-        dqkv = ops.attn_bwd(dao, qkv, ao, lse, L.ATTN_SWIN, B * nW, ws * ws, nH, C // nH, at.scale,
-                            dbias_table=dtab, bias_table=at.relative_position_bias_table.data, nW=nW, win_res=H,
-                            shift=blk.shift_size)
-        dxn1w = ops.gemm(dqkv, ar.compute(at.qkv.weight), b_kmajor=True)
+        if _FUSED_WMSA_BWD and ops.swin_wmsa_bwd_supported(dyw.dtype, C, nH):
+            # opt-in (MVLT_FUSED_WMSA_BWD=1, Python host path): proj dgrad + attention backward + qkv dgrad in one
+            # launch.  Correct, but slower than the three launches at B=32 (profiles/r2_wmsa_pmc.md), hence not default.
+            wpt = ar.compute(at.proj.weight).t().contiguous()
+            wqt = ar.compute(at.qkv.weight).t().contiguous()
+            dqkv, dxn1w = ops.swin_wmsa_bwd(dyw, qkv, lse, B, H, nH, blk.shift_size, wpt, wqt,
+                                            at.relative_position_bias_table.data, at.scale, dtab)
+        else:
+            dao = ops.gemm(dyw, ar.compute(at.proj.weight), b_kmajor=True)
+            dqkv = ops.attn_bwd(dao, qkv, ao, lse, L.ATTN_SWIN, B * nW, ws * ws, nH, C // nH, at.scale,
+                                dbias_table=dtab, bias_table=at.relative_position_bias_table.data, nW=nW, win_res=H,
+                                shift=blk.shift_size)
+            dxn1w = ops.gemm(dqkv, ar.compute(at.qkv.weight), b_kmajor=True)
         dx0 = ops.layernorm_bwd(dxn1w, x, mean1, rstd1, blk.norm1.weight.data, g(blk.norm1.weight),
                                 g(blk.norm1.bias), dy_rowmap=n2w, dres=dx1, defer=self.__dict__["_lnq"])
         # ---- weight / bias gradients (only the optimizer consumes them): side stream, overlapping the next block

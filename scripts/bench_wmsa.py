@@ -61,6 +61,26 @@ for st, (res, C, nH) in enumerate([(56, 96, 3), (28, 192, 6), (14, 384, 12)]):
         tf_eval = timeit(lambda: lib.mvlt_swin_wmsa_fwd(ctypes.byref(pe), st_), n=200)
         tf_save = timeit(lambda: lib.mvlt_swin_wmsa_fwd(ctypes.byref(ps), st_), n=200)
         line = f"s{st} res={res} C={C} shift={shift}: fused fwd {tf_eval:6.1f} us ({flop/tf_eval/1e6:6.1f} TFLOP/s), +saves {tf_save:6.1f} us"
+        # backward: proj dgrad + attention backward + qkv dgrad, fused (one launch) vs the three launches
+        if ops.swin_wmsa_bwd_supported(dt, C, nH):
+            lib.mvlt_swin_wmsa_fwd(ctypes.byref(ps), st_)
+            dyw = torch.randn(rows, C, device="cuda").to(dt)
+            dtab = torch.zeros(169, nH, device="cuda")
+            wpt, wqt = wproj.t().contiguous(), wqkv.t().contiguous()
+            pb = L.MvltSwinWmsa()
+            pb.dtype, pb.B, pb.res, pb.C, pb.nH, pb.shift = L.BF16, B, res, C, nH, shift
+            dq_o, dx_o = torch.empty_like(qkv_s), torch.empty_like(x)
+            pb.dy_win, pb.qkv_win, pb.lse, pb.wproj_t, pb.wqkv_t = dyw.data_ptr(), qkv_s.data_ptr(), lse_s.data_ptr(), wpt.data_ptr(), wqt.data_ptr()
+            pb.bias_table, pb.scale, pb.dqkv, pb.dxn_win, pb.dbias_table = tbl.data_ptr(), 32 ** -0.5, dq_o.data_ptr(), dx_o.data_ptr(), dtab.data_ptr()
+            tb = timeit(lambda: lib.mvlt_swin_wmsa_bwd(ctypes.byref(pb), st_), n=200)
+            bflop = 2.0 * B * nW * (49 * C * C + 5 * nH * 49 * 49 * 32 + 49 * C * 3 * C)
+            line += f" | fused bwd {tb:6.1f} us ({bflop/tb/1e6:6.1f} TFLOP/s)"
+            if ONLY != "fused":
+                def unfused_bwd():
+                    dao = ops.gemm(dyw, wproj, b_kmajor=True)
+                    dq = ops.attn_bwd(dao, qkv_s, ao, lse_s, L.ATTN_SWIN, B * nW, 49, nH, 32, 32 ** -0.5, dbias_table=dtab, bias_table=tbl, nW=nW, win_res=res, shift=shift)
+                    return ops.gemm(dq, wqkv, b_kmajor=True)
+                line += f" vs unfused bwd (3 launches) {timeit(unfused_bwd):6.1f} us"
         if ONLY != "fused":
             def unfused():
                 xn, m, r, _ = ops.layernorm_fwd(x, g1, b1, 1e-5, out_rowmap=n2w)

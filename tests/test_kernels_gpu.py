@@ -744,3 +744,44 @@ def test_skinny_accum_and_layernorm_from_accumulator(ops):
             y = ops.layernorm_acc_fwd(acc, bias, res, g, b, 1e-12, dt)
             yr = torch.nn.functional.layer_norm(ref + bias + res.float(), (N,), g, b, 1e-12)
             assert rel(y, yr) < tol(dt) * 2 and float(acc.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("res,C_,shift,B", [(14, 96, 3, 2), (28, 192, 0, 1), (14, 192, 3, 3), (14, 384, 3, 1), (14, 128, 0, 2)])
+def test_swin_wmsa_fused_backward(ops, dt, res, C_, shift, B):
+    """mvlt_swin_wmsa_bwd (proj dgrad + window-attention backward + qkv dgrad in one launch) against the three-launch
+    kernel sequence it replaces, on what the fused forward saves."""
+    from mvlt_amd._lib import ATTN_SWIN
+    from mvlt_amd.indexing import batched_window_maps
+    nH = C_ // 32
+    if not ops.swin_wmsa_bwd_supported(dt, C_, nH):
+        pytest.skip("width not covered by the fused backward kernel in this dtype (LDS)")
+    nW = (res // 7) ** 2
+    rows = B * res * res
+    x = rnd((rows, C_), dt, 70)
+    g1 = (1.0 + 0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(71))).cuda()
+    b1 = (0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(72))).cuda()
+    wqkv = rnd((3 * C_, C_), dt, 73, C_ ** -0.5)
+    bqkv = (0.1 * torch.randn(3 * C_, generator=torch.Generator().manual_seed(74))).cuda()
+    wproj = rnd((C_, C_), dt, 75, C_ ** -0.5)
+    bproj = (0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(76))).cuda()
+    table = (0.5 * torch.randn(169, nH, generator=torch.Generator().manual_seed(77))).cuda()
+    scale = 32 ** -0.5
+    w2n, n2w = batched_window_maps(B, res, res, 7, shift, x.device)
+    y, (xn, qkv, ao, lse, mean, rstd) = ops.swin_wmsa_fwd(x, w2n, B, res, nH, shift, g1, b1, 1e-5, wqkv, bqkv, wproj, bproj,
+                                                      table, scale, save=True)
+    dyw = rnd((rows, C_), dt, 78)
+    # the unfused sequence
+    dao_u = ops.gemm(dyw, wproj, b_kmajor=True)
+    dt_u = torch.zeros(169, nH, device="cuda")
+    dqkv_u = ops.attn_bwd(dao_u, qkv, ao, lse, ATTN_SWIN, B * nW, 49, nH, 32, scale, dbias_table=dt_u, bias_table=table,
+                          nW=nW, win_res=res, shift=shift)
+    dxn_u = ops.gemm(dqkv_u, wqkv, b_kmajor=True)
+    # fused
+    dt_f = torch.zeros(169, nH, device="cuda")
+    dqkv_f, dxn_f = ops.swin_wmsa_bwd(dyw, qkv, lse, B, res, nH, shift, wproj.t().contiguous(), wqkv.t().contiguous(),
+                                      table, scale, dt_f)
+    t = tol(dt) * 2
+    assert rel(dqkv_f, dqkv_u) < t, rel(dqkv_f, dqkv_u)
+    assert rel(dxn_f, dxn_u) < t, rel(dxn_f, dxn_u)
+    assert rel(dt_f, dt_u) < t, rel(dt_f, dt_u)

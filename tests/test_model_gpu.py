@@ -197,6 +197,34 @@ def test_tiny_train_mode_matches_oracle_with_same_masks(M, specs):
     assert worst < 1e-2, worst
 
 
+def test_fused_wmsa_backward_in_the_model(M, specs, monkeypatch):
+    """mvlt_swin_wmsa_bwd inside the Swin backward pass (opt-in, Python host path) gives the gradients of the default
+    three-launch sequence: every parameter of the tiny model, f32."""
+    from mvlt_amd import ops, swin
+    image, ids, labels, itm = synth_batch(3, 24, seed=41, vocab=3000)
+    monkeypatch.setattr(random, "random", lambda: 0.9)
+    runs = []
+    for fused in (False, True):
+        monkeypatch.setattr(ops, "NATIVE", not fused)
+        monkeypatch.setattr(swin, "_FUSED_WMSA_BWD", fused)
+        monkeypatch.setattr(swin, "_FUSED_WMSA", "1")
+        cfg = M.MVLBertPretrainConfig(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=1024,
+                                      vocab_size=3000)
+        cfg.ITM_task = True
+        cfg.swin.update(embed_dim=96, num_heads=[3, 6, 12, 24], depths=[2, 2, 2, 2], drop_path_rate=0.2)   # widths 96 / 192 / 384
+        torch.manual_seed(17)
+        model = M.MVLBertForPretraining(cfg)
+        model = M.set_compute_dtype(model.cuda().eval(), F32)
+        loss = model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = runs
+    assert abs(l0 - l1) < 1e-6 * abs(l0)
+    bad = [(k, rel_err(g1[k], g0[k])) for k in g0 if rel_err(g1[k], g0[k]) > 2e-4 and g0[k].abs().max() > 1e-9 and not k.endswith("key.bias")]
+    assert g0.keys() == g1.keys() and not bad, bad[:10]
+
+
 # ------------------------------------------------------------------ full-size models
 @pytest.mark.parametrize("cd", [F32])
 def test_full_pretrain_loss_and_grad_slices(M, golden, specs, cd):
