@@ -213,7 +213,8 @@ class BertOnlyMLMHead(nn.Module):
         pr = self.predictions
         g = ar.grad_view
         dl = dlogits[:, :V]
-        dt2 = ops.gemm(dl, ar.compute(pr.decoder.weight), b_kmajor=True, m_dev=rd)
+        # with the labelled rows first only a few row tiles are live, each with a 30522-deep reduction: split it
+        dt2 = ops.gemm(dl, ar.compute(pr.decoder.weight), b_kmajor=True, m_dev=rd, split_k=8 if rd is not None else 0)
         ops.gemm(dl, t2, a_kmajor=True, b_kmajor=True, out=g(pr.decoder.weight), out_f32=True,
                  a_colsum=g(pr.decoder.bias), m_dev=rd)
         ln = pr.transform.LayerNorm

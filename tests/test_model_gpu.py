@@ -747,7 +747,7 @@ def test_device_planned_packing_is_the_default_and_equals_the_dense_run(M, specs
     assert l0 == l0 and abs(l0 - l1) < 2e-6 * abs(l0), (l0, l1)
     assert g0.keys() == g1.keys() and len(g0) > 150
     bad = [(k, rel_err(g1[k], g0[k])) for k in g0
-           if rel_err(g1[k], g0[k]) > 2e-4 and not k.endswith("key.bias") and g0[k].abs().max() > 1e-9]
+           if rel_err(g1[k], g0[k]) > 5e-4 and not k.endswith("key.bias") and g0[k].abs().max() > 1e-9]      # f32 summation order only (the decoder dgrad is split-K on the packed path)
     assert not bad, bad[:10]
 
 
