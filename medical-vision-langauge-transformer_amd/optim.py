@@ -118,6 +118,23 @@ class FusedAdamW:
                       ar.shadow[lo:hi] if ar.shadow is not None else None,
                       self.lr, b1, b2, self.eps, self.weight_decay, st + 1, self.grad_scale * extra_scale)
 
+    def _plan_runs(self, ar: Arena, params):
+        """[(lo, hi, ids of the parameters of the run)]: maximal contiguous arena ranges of ``params`` that
+        currently share one step count."""
+        runs, run = [], None
+        for p in params:
+            pid = id(p)
+            o = ar.offset[pid]
+            e = o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            st = ar.steps[pid]
+            if run is not None and run[1] == o and run[3] == st:
+                run[1] = e
+                run[2].append(pid)
+            else:
+                run = [o, e, [pid], st]
+                runs.append(run)
+        return [(lo, hi, tuple(ids)) for lo, hi, ids, _ in runs]
+
     # ------------------------------------------------------------------ overlap with the backward pass
     def overlap_with_backward(self, reducer=None, chunk_bytes: int = 64 << 20) -> "FusedAdamW":
         self._overlap = dict(reducer=reducer, chunk=chunk_bytes // 4)
@@ -178,7 +195,27 @@ class FusedAdamW:
     def step(self):
         ar = self._state()
         if self._overlap is None:
-            self._apply(ar, [p for p in ar.params if ar.has_grad[id(p)]])
+            # the set of parameters with a gradient takes two values in pre-training (seq2seq / bidirectional head):
+            # the contiguous runs are planned once per set, not rebuilt from 582 parameters every step
+            key = ar._published
+            plan = self.__dict__.setdefault("_plans", {}).get(key) if key is not None else None
+            if plan is None:
+                params = [p for p in ar.params if ar.has_grad[id(p)]]
+                plan = self._plan_runs(ar, params)
+                if key is not None and len(self._plans) < 16:
+                    self._plans[key] = plan
+            steps = ar.steps
+            if not all(steps[ids[0]] == steps[i] for _, _, ids in plan for i in ids):
+                # step counts inside a planned run have drifted apart (a parameter that belongs to several sets, a
+                # resumed checkpoint): plan again for the current counts
+                plan = self._plan_runs(ar, [p for p in ar.params if ar.has_grad[id(p)]])
+                if key is not None:
+                    self._plans[key] = plan
+            b1, b2 = self.betas
+            for lo, hi, ids in plan:
+                ops.adamw(ar.flat[lo:hi], ar.grad[lo:hi], ar.exp_avg[lo:hi], ar.exp_avg_sq[lo:hi],
+                          ar.shadow[lo:hi] if ar.shadow is not None else None,
+                          self.lr, b1, b2, self.eps, self.weight_decay, steps[ids[0]] + 1, self.grad_scale)
         else:
             self._apply(ar, [p for p in ar.params if ar.has_grad[id(p)] and id(p) not in self._stepped])
             torch.cuda.current_stream().wait_stream(ops.opt_stream(ar.device))
