@@ -238,6 +238,10 @@ typedef struct MvltSwinWmsa {
     /* backward only: TRANSPOSED compute-dtype copies of the projection weights, wproj_t [C_in, C_out] = proj.weight^T and
      * wqkv_t [C, 3C] = qkv.weight^T (mvlt_transpose_batch makes them): the dgrad products then read k-contiguous rows */
     const void* wproj_t; const void* wqkv_t;
+    /* forward only: 1 = one workgroup per (window, head group) and NO output projection: attn_out [B*res*res, C]
+     * (window order, required) is the result, y / wproj / bproj / rowscale are unused; follow with mvlt_gemm
+     * (bias, DropPath row scale, window-reverse row map, residual).  For launches with too few windows to fill the chip. */
+    int head_split;
 } MvltSwinWmsa;
 int mvlt_swin_wmsa_supported(int dtype, int C, int nH);   /* 1 when the fused kernels cover this width */
 int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream);

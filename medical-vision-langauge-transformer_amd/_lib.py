@@ -75,7 +75,7 @@ class MvltSwinWmsa(C.Structure):
                 ("bias_table", vp), ("scale", f32), ("rowscale", vp),
                 ("xn_win", vp), ("attn_out", vp), ("lse", vp), ("mean", vp), ("rstd", vp),
                 ("dy_win", vp), ("dqkv", vp), ("dxn_win", vp), ("dbias_table", vp), ("qkv_win", vp),
-                ("wproj_t", vp), ("wqkv_t", vp)]
+                ("wproj_t", vp), ("wqkv_t", vp), ("head_split", i32)]
 
 
 class MvltEmbed(C.Structure):

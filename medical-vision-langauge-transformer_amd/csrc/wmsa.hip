@@ -36,6 +36,7 @@ struct WmsaDev {
     const float* bias_table; float scale;
     const float* rowscale;
     void* xn; void* ao; void* qkv; float* lse; float* mean; float* rstd;
+    int head_split;          // 1: one workgroup per (window, head group), no output projection (attn_out is the result)
 };
 
 template <typename T, int C, int G> struct WmsaGeom {
@@ -74,8 +75,8 @@ struct LanePairs {
     }
 };
 
-template <typename T, int C, int G, int NW>
-__global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
+template <typename T, int C, int G, int NW, int MINW = 1>
+__global__ __launch_bounds__(64 * NW, MINW) void wmsa_fwd_kernel(const WmsaDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using GM = WmsaGeom<T, C, G>;
     using M = Mma<T>;
@@ -102,7 +103,11 @@ __global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
     T* ot = reinterpret_cast<T*>(smem_raw + GM::XB + GM::QB);
     float* tbl = reinterpret_cast<float*>(smem_raw + GM::XB + GM::QB + GM::OB);
 
-    const int win = blockIdx.x;
+    // head_split: stage-2-sized launches (128 windows at B=32) cannot fill 256 CUs with one workgroup per window and
+    // every workgroup would stream all 8 C^2 bytes of weights; there the head groups of a window go to separate
+    // workgroups (each streams its own 6 C x 32 G slice) and the output projection is left to a GEMM launch
+    const int win = p.head_split ? blockIdx.x / NHG : blockIdx.x;
+    const int hg0 = p.head_split ? blockIdx.x % NHG : 0, hg_end = p.head_split ? hg0 + 1 : NHG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c15 = lane & 15;
     const T* xg = reinterpret_cast<const T*>(p.x);
     const T* wq = reinterpret_cast<const T*>(p.wqkv);
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
     {
 #pragma unroll
         for (int jj = 0; jj < NTQW; ++jj) {
-            const T* w = wq_ptr(0, wave + NW * jj);
+            const T* w = wq_ptr(hg0, wave + NW * jj);
 #pragma unroll
             for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
         }
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o, 64);
         const float rstd = rsqrtf(q / C + p.eps);
-        if (rv && sub == 0 && p.mean) { p.mean[tok] = mean; p.rstd[tok] = rstd; }
-        T* xs = p.xn ? reinterpret_cast<T*>(p.xn) + ((long)win * 49 + row) * C : nullptr;
+        if (rv && sub == 0 && p.mean && hg0 == 0) { p.mean[tok] = mean; p.rstd[tok] = rstd; }
+        T* xs = (p.xn && hg0 == 0) ? reinterpret_cast<T*>(p.xn) + ((long)win * 49 + row) * C : nullptr;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = (sub + LPR * i) * E;
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
     __syncthreads();
 
 #pragma unroll 1
-    for (int hg = 0; hg < NHG; ++hg) {
+    for (int hg = hg0; hg < hg_end; ++hg) {
         // ================= qkv projection of head group hg: [64, C] x [C, 96 G]
         {
             f32x4 acc[4][NTQW];
@@ -249,6 +254,7 @@ __global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
         }
         // output-projection weight fragments of this head group: requested now, used after the attention phase
         Frag fpj[KSO][NTPW];
+        if (!p.head_split)
 #pragma unroll
         for (int jj = 0; jj < NTPW; ++jj) {
             const int t = min(wave + NW * jj, NTP - 1);
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
             for (int td = 0; td < 2; ++td) store4f(ot + qrow * LDO + hl * 32 + 16 * td + 4 * g, o[td]);
         }
         // the next head group's first qkv weight fragments: requested before the projection slice below
-        if (hg + 1 < NHG) {
+        if (hg + 1 < hg_end) {
 #pragma unroll
             for (int jj = 0; jj < NTQW; ++jj) {
                 const T* w = wq_ptr(hg + 1, wave + NW * jj);
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
         }
 
         // ================= output projection, this group's k-slice: y[64, C] += O_g[64, 32 G] Wproj[:, 32 G hg ..]^T
-        {
+        if (!p.head_split) {
             const T* arow = ot + c15 * LDO;
 #pragma unroll
             for (int ks = 0; ks < KSO; ++ks) {
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(64 * NW) void wmsa_fwd_kernel(const WmsaDev p) {
     }
 
     // ---- epilogue: + bias, DropPath scale, + shortcut, back to token order
-    {
+    if (!p.head_split) {
         const float rs = p.rowscale ? p.rowscale[win / p.nW] : 1.0f;
         T* yg = reinterpret_cast<T*>(p.y);
         int tokm[4];
@@ -729,7 +735,9 @@ int launch_bwd(const WmsaBwdDev& d, hipStream_t s) {
     constexpr size_t sh = GM::bytes(C / 32);
     static_assert(sh <= 160 * 1024, "LDS");
     auto k = wmsa_bwd_kernel<T, C>;
-    if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static const hipError_t attr = sh > 64 * 1024
+        ? hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) : hipSuccess;
+    (void)attr;
     static const int cap = [] { const char* e = getenv("MVLT_WMSA_BWD_GRID"); return e ? atoi(e) : 512; }();
     const int grid = d.nwin < cap ? d.nwin : cap;
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), sh, s, d);
@@ -737,14 +745,16 @@ int launch_bwd(const WmsaBwdDev& d, hipStream_t s) {
     return MVLT_OK;
 }
 
-template <typename T, int C, int G, int NW>
+template <typename T, int C, int G, int NW, int MINW = 1>
 int launch_fwd(const WmsaDev& d, hipStream_t s) {
     using GM = WmsaGeom<T, C, G>;
     constexpr size_t sh = GM::bytes(C / 32);
     static_assert(sh <= 160 * 1024, "LDS");
-    auto k = wmsa_fwd_kernel<T, C, G, NW>;
-    if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(k, dim3(d.nwin), dim3(64 * NW), sh, s, d);
+    auto k = wmsa_fwd_kernel<T, C, G, NW, MINW>;
+    static const hipError_t attr = sh > 64 * 1024            // once per instantiation: the call costs ~10 us of host time
+        ? hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) : hipSuccess;
+    (void)attr;
+    hipLaunchKernelGGL(k, dim3(d.head_split ? d.nwin * (C / 32 / G) : d.nwin), dim3(64 * NW), sh, s, d);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }
@@ -802,11 +812,13 @@ extern "C" int mvlt_swin_wmsa_supported(int dtype, int C, int nH) {
 }
 
 extern "C" int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream) {
-    MVLT_CHECK(p && p->x && p->y && p->w2n && p->ln_gamma && p->ln_beta, MVLT_ERR_ARG);
-    MVLT_CHECK(p->wqkv && p->bqkv && p->wproj && p->bproj && p->bias_table, MVLT_ERR_ARG);
+    MVLT_CHECK(p && p->x && p->w2n && p->ln_gamma && p->ln_beta, MVLT_ERR_ARG);
+    MVLT_CHECK(p->wqkv && p->bqkv && p->bias_table, MVLT_ERR_ARG);
+    if (p->head_split) MVLT_CHECK(p->attn_out, MVLT_ERR_ARG);
+    else MVLT_CHECK(p->y && p->wproj && p->bproj && aligned16(p->y) && aligned16(p->wproj) && aligned16(p->bproj), MVLT_ERR_ARG);
     MVLT_CHECK(p->B > 0 && p->res > 0 && p->res % 7 == 0 && p->shift >= 0 && p->shift < 7, MVLT_ERR_ARG);
-    MVLT_CHECK(aligned16(p->x) && aligned16(p->y) && aligned16(p->wqkv) && aligned16(p->wproj), MVLT_ERR_ARG);
-    MVLT_CHECK(aligned16(p->ln_gamma) && aligned16(p->ln_beta) && aligned16(p->bqkv) && aligned16(p->bproj), MVLT_ERR_ARG);
+    MVLT_CHECK(aligned16(p->x) && aligned16(p->wqkv), MVLT_ERR_ARG);
+    MVLT_CHECK(aligned16(p->ln_gamma) && aligned16(p->ln_beta) && aligned16(p->bqkv), MVLT_ERR_ARG);
     MVLT_CHECK((p->mean == nullptr) == (p->rstd == nullptr), MVLT_ERR_ARG);
     if (p->xn_win) MVLT_CHECK(aligned16(p->xn_win), MVLT_ERR_ARG);
     if (p->attn_out) MVLT_CHECK(aligned16(p->attn_out), MVLT_ERR_ARG);
@@ -820,6 +832,7 @@ extern "C" int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream) {
     d.wqkv = p->wqkv; d.bqkv = p->bqkv; d.wproj = p->wproj; d.bproj = p->bproj;
     d.bias_table = p->bias_table; d.scale = p->scale; d.rowscale = p->rowscale;
     d.xn = p->xn_win; d.ao = p->attn_out; d.qkv = p->qkv_win; d.lse = p->lse; d.mean = p->mean; d.rstd = p->rstd;
+    d.head_split = p->head_split != 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p->dtype == MVLT_F32) return dispatch_fwd_f32(d, p->C, s);
     return dispatch_fwd_bf16(d, p->C, s);

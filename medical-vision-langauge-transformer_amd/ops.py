@@ -603,11 +603,27 @@ def _wmsa_struct(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj,
 
 
 def swin_wmsa_fwd(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj, bproj, table, scale,
-                  rowscale=None, save=False):
+                  rowscale=None, save=False, head_split=False):
     """y = x + rowscale * proj(window_attention(qkv(norm1(x))))  (MvltSwinWmsa): one launch.
-    save=True also returns (xn_win, qkv_win, attn_out, lse, mean, rstd) for the backward pass."""
+    save=True also returns (xn_win, qkv_win, attn_out, lse, mean, rstd) for the backward pass.
+    head_split=True: one workgroup per (window, head group), no output projection: returns (attn_out, saved)."""
     _need_cuda(x)
     p = _wmsa_struct(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj, bproj, table, scale, rowscale)
+    if head_split:
+        p.head_split = 1
+        ao = torch.empty_like(x)
+        p.attn_out = ao.data_ptr()
+        saved = None
+        if save:
+            rows, Cn = x.shape
+            xn = torch.empty_like(x)
+            qkv = torch.empty((rows, 3 * Cn), dtype=x.dtype, device=x.device)
+            lse = torch.empty((rows // 49, nH, 49), dtype=torch.float32, device=x.device)
+            mean, rstd = torch.empty((2, rows), dtype=torch.float32, device=x.device).unbind(0)
+            p.xn_win, p.lse, p.mean, p.rstd, p.qkv_win = xn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), qkv.data_ptr()
+            saved = (xn, qkv, ao, lse, mean, rstd)
+        L.check(L.lib().mvlt_swin_wmsa_fwd(C.byref(p), _stream()), "mvlt_swin_wmsa_fwd")
+        return ao, saved
     y = torch.empty_like(x)
     p.y = y.data_ptr()
     saved = None

@@ -58,6 +58,13 @@ for st, (res, C, nH) in enumerate([(56, 96, 3), (28, 192, 6), (14, 384, 12)]):
         lse_s = torch.empty((rows // 49, nH, 49), device="cuda"); ms = torch.empty((2, rows), device="cuda")
         ps.xn_win, ps.attn_out, ps.qkv_win, ps.lse = xn.data_ptr(), ao.data_ptr(), qkv_s.data_ptr(), lse_s.data_ptr()
         ps.mean, ps.rstd = ms[0].data_ptr(), ms[1].data_ptr()
+        ph = ops._wmsa_struct(*args, rs)
+        ph.head_split = 1
+        ph.attn_out, ph.xn_win, ph.qkv_win, ph.lse = ao.data_ptr(), xn.data_ptr(), qkv_s.data_ptr(), lse_s.data_ptr()
+        ph.mean, ph.rstd = ms[0].data_ptr(), ms[1].data_ptr()
+        th = timeit(lambda: lib.mvlt_swin_wmsa_fwd(ctypes.byref(ph), st_), n=200)
+        tp = timeit(lambda: ops.gemm(ao, wproj, bias=bproj, residual=x, rowmap=w2n, rowscale=(rs, res * res), out=y), n=50)
+        print(f"   head-split (LN + qkv + attention, saves) {th:6.1f} us + proj GEMM {tp:6.1f} us (through the Python wrapper)", flush=True)
         tf_eval = timeit(lambda: lib.mvlt_swin_wmsa_fwd(ctypes.byref(pe), st_), n=200)
         tf_save = timeit(lambda: lib.mvlt_swin_wmsa_fwd(ctypes.byref(ps), st_), n=200)
         line = f"s{st} res={res} C={C} shift={shift}: fused fwd {tf_eval:6.1f} us ({flop/tf_eval/1e6:6.1f} TFLOP/s), +saves {tf_save:6.1f} us"

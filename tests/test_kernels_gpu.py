@@ -345,6 +345,13 @@ def test_swin_wmsa_fused_forward(ops, dt, res, C_, shift, B, dp):
     assert rel(qkv, qkv_u) < t
     assert rel(lse, lse_u) < (1e-5 if dt == torch.float32 else 2e-3)
     assert rel(ao, ao_u) < t and rel(y, y_u) < t
+    # head-split mode: one workgroup per (window, head group), projection left to a GEMM launch -- same numbers
+    ao_s, (xn_s, qkv_s, ao_s2, lse_s, mean_s, rstd_s) = ops.swin_wmsa_fwd(x, w2n, B, res, nH, shift, g1, b1, 1e-5, wqkv, bqkv, wproj,
+                                                                        bproj, table, scale, save=True, head_split=True)
+    assert torch.equal(ao_s, ao) and torch.equal(qkv_s, qkv) and torch.equal(xn_s, xn) and torch.equal(lse_s, lse)
+    assert torch.equal(mean_s, mean) and torch.equal(rstd_s, rstd)
+    y_s = ops.gemm(ao_s, wproj, bias=bproj, residual=x, rowmap=w2n, rowscale=(rs, res * res) if rs is not None else None)
+    assert rel(y_s, y) < t
 
 
 def bert_ref(qkv, B, Lq, nH, mask_add, scale, keep=None, p=0.0):
