@@ -229,7 +229,7 @@ MVLT_DEV int xcd_remap(int orig, int nwg) {
 }
 
 // one output tile (bx, by) of one k-split bz
-template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2>
+template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2, int DEEP = 0>
 MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const int bz, T* sA, T* sB) {
     using GA = TileGeom<T, BM, AK>;
     using GB = TileGeom<T, BN, BK_>;
@@ -261,16 +261,23 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
     FastLoader<T, BN, BK_> lb;
     la.init(A, p.lda, m0, p.M, ks);
     lb.init(B, p.ldb, n0, p.N, ks);
-    // fused bias gradient: blocks of the first output-column tile also sum their A tile over k
-    float csum = 0.f;
-    const bool do_colsum = AK && p.a_colsum != nullptr && bx == 0 && threadIdx.x < BM;
-    auto colsum_tile = [&]() {
+    // fused bias gradient: workgroups of the first output-column tile also sum their A tile over k.  The sums are
+    // taken from the staging REGISTERS (a thread's chunks of a k-major tile all lie in one 16-byte column group:
+    // 256 % CPR == 0), a few adds per k-tile spread over all 256 threads, and meet in LDS once at the end; summing
+    // the LDS image instead (64 dependent ds_reads per k-tile in 64-128 threads while the other waves wait at the
+    // barrier) cost 35-50 % of the weight-gradient launches (profiles/r2_wgrad_colsum.txt).
+    constexpr int EA = GA::E;
+    static_assert(!AK || (256 % GA::CPR == 0 && (size_t)GA::ELEMS * sizeof(T) >= 256 * EA * sizeof(float)), "colsum layout");
+    float cs[EA];
+#pragma unroll
+    for (int e = 0; e < EA; ++e) cs[e] = 0.f;
+    const bool do_colsum = AK && p.a_colsum != nullptr && bx == 0;
+    auto colsum_regs = [&](const Vec* r) {
         if (AK && do_colsum) {
-            float s0 = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < GA::BKE; ++k)
-                s0 += to_f(sA[k * GA::LD + (GA::SWZ ? ((((threadIdx.x >> 4) ^ kswz<BM>(k)) << 4) | (threadIdx.x & 15)) : threadIdx.x)]);
-            csum += s0;
+#pragma unroll
+            for (int i = 0; i < GA::PER_THREAD; ++i)
+#pragma unroll
+                for (int e = 0; e < EA; ++e) cs[e] += to_f(r[i][e]);
         }
     };
     auto compute_tile = [&]() {
@@ -288,14 +295,46 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
         }
     };
     // ---- hot loop: full k-tiles only, no predication, nothing but loads / ds_write / ds_read / MFMA
-    if (!PF2) {
+    if constexpr (DEEP > 1) {
+        // weight gradients (K = thousands of rows, 1-2 workgroups per CU): a ring of DEEP register sets keeps the
+        // loads of DEEP k-tiles in flight -- with one set the loop runs at one memory latency per k-tile.  Every
+        // slot always loads (the compiler then counts vmcnt exactly); past the last tile the pointers stop advancing
+        // and the slot re-reads the last tile, which nobody consumes.
+        Vec qa[DEEP][GA::PER_THREAD], qb[DEEP][GB::PER_THREAD];
+        auto issue = [&](Vec* a, Vec* b, bool adv) {
+            const long sa = adv ? la.step : 0, sb = adv ? lb.step : 0;
+#pragma unroll
+            for (int i = 0; i < GA::PER_THREAD; ++i) { a[i] = *reinterpret_cast<const Vec*>(la.ptr[i]); la.ptr[i] += sa; }
+#pragma unroll
+            for (int i = 0; i < GB::PER_THREAD; ++i) { b[i] = *reinterpret_cast<const Vec*>(lb.ptr[i]); lb.ptr[i] += sb; }
+        };
+        if (nfast > 0) {
+            int issued = 0;
+#pragma unroll
+            for (int j = 0; j < DEEP; ++j) { issue(qa[j], qb[j], issued + 1 < nfast); ++issued; }
+            for (int kt = 0; kt < nfast; kt += DEEP) {
+#pragma unroll
+                for (int j = 0; j < DEEP; ++j) {
+                    if (kt + j < nfast) {
+                        tile_store<T, BM, AK>(qa[j], sA);
+                        tile_store<T, BN, BK_>(qb[j], sB);
+                        colsum_regs(qa[j]);
+                        __syncthreads();
+                        issue(qa[j], qb[j], issued + 1 < nfast); ++issued;
+                        compute_tile();
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+    } else if (!PF2) {
         if (nfast > 0) { la.load(ra); lb.load(rb); }
         for (int kt = 0; kt < nfast; ++kt) {
             tile_store<T, BM, AK>(ra, sA);
             tile_store<T, BN, BK_>(rb, sB);
+            colsum_regs(ra);
             __syncthreads();
             if (kt + 1 < nfast) { la.load(ra); lb.load(rb); }
-            colsum_tile();
             compute_tile();
             __syncthreads();
         }
@@ -308,17 +347,17 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
         for (int kt = 0; kt < nfast; kt += 2) {
             tile_store<T, BM, AK>(ra, sA);
             tile_store<T, BN, BK_>(rb, sB);
+            colsum_regs(ra);
             __syncthreads();
             if (kt + 2 < nfast) { la.load(ra); lb.load(rb); }
-            colsum_tile();
             compute_tile();
             __syncthreads();
             if (kt + 1 < nfast) {
                 tile_store<T, BM, AK>(ra1, sA);
                 tile_store<T, BN, BK_>(rb1, sB);
+                colsum_regs(ra1);
                 __syncthreads();
                 if (kt + 3 < nfast) { la.load(ra1); lb.load(rb1); }
-                colsum_tile();
                 compute_tile();
                 __syncthreads();
             }
@@ -331,18 +370,29 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
         tile_load<T, BN, BK_>(rb, B, p.ldb, n0, p.N, k0, ke, p.b_vec);
         tile_store<T, BM, AK>(ra, sA);
         tile_store<T, BN, BK_>(rb, sB);
+        colsum_regs(ra);
         __syncthreads();
-        colsum_tile();
         compute_tile();
         __syncthreads();
     }
     if (AK && do_colsum) {
+        float* red = reinterpret_cast<float*>(sA);           // free: the k-loop ended on a barrier
+#pragma unroll
+        for (int e = 0; e < EA; ++e) red[threadIdx.x * EA + e] = cs[e];
+        __syncthreads();
+        float csum = 0.f;
+        if (threadIdx.x < BM) {
+            const int ch = threadIdx.x / EA, e = threadIdx.x % EA;
+#pragma unroll 4
+            for (int g = 0; g < 256 / GA::CPR; ++g) csum += red[(g * GA::CPR + ch) * EA + e];
+        }
         const int m = m0 + threadIdx.x;
-        if (m < p.M) {
+        if (threadIdx.x < BM && m < p.M) {
             if (p.atomic_out) atomicAdd(&p.a_colsum[m], csum);
             else if (p.split_k > 1) p.ws_colsum[(long)bz * p.M + m] = csum;
             else p.a_colsum[m] = (p.epi & MVLT_EPI_ACCUM) ? p.a_colsum[m] + csum : csum;
         }
+        __syncthreads();                                      // (persistent callers reuse sA)
     }
 
     // acc[i][j][r] <-> n = nb + 4*(lane>>4) + r, m = mb + (lane & 15)
@@ -669,8 +719,8 @@ __global__ __launch_bounds__(64) void argmax_parts_kernel(const float* part_val,
 constexpr int GROUP_MAX = 8;
 struct GemmGroupDev { int n; int split; int start[GROUP_MAX + 1]; GemmDev g[GROUP_MAX]; };   // start[]: in (tile, k-slice) units
 
-template <typename T, int BM, int BN, bool AK, bool BK_>
-__global__ __launch_bounds__(256, 3) void gemm_group_kernel(const GemmGroupDev gp) {
+template <typename T, int BM, int BN, bool AK, bool BK_, int DEEP>
+__global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GemmGroupDev gp) {
     __shared__ __attribute__((aligned(16))) T sA[TileGeom<T, BM, AK>::ELEMS];
     __shared__ __attribute__((aligned(16))) T sB[TileGeom<T, BN, BK_>::ELEMS];
     // persistent: the grid may be smaller than the tile list (the launcher caps the workgroups per CU so the
@@ -685,7 +735,7 @@ __global__ __launch_bounds__(256, 3) void gemm_group_kernel(const GemmGroupDev g
         const int local = t - gp.start[i];
         const int bz = local / (gx * gy), tile = local - bz * gx * gy;          // k-slice bz of output tile `tile`
         const int by = tile / gx;
-        gemm_body<T, BM, BN, AK, BK_, false>(p, tile - by * gx, by, bz, sA, sB);
+        gemm_body<T, BM, BN, AK, BK_, false, DEEP>(p, tile - by * gx, by, bz, sA, sB);
     }
 }
 
@@ -999,9 +1049,22 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
     int total = g.start[n], per_cu = 2;
     if (const char* ov = getenv("MVLT_GROUP_WGS")) per_cu = atoi(ov);
     if (per_cu > 0 && total > per_cu * 256) total = per_cu * 256;
-    if (bn == 128 && bm == 128) hipLaunchKernelGGL((gemm_group_kernel<T, 128, 128, true, true>), dim3(total), dim3(256), 0, s, g);
-    else if (bn == 128) hipLaunchKernelGGL((gemm_group_kernel<T, 64, 128, true, true>), dim3(total), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_group_kernel<T, 64, 96, true, true>), dim3(total), dim3(256), 0, s, g);
+    static const int deep = [] { const char* e = getenv("MVLT_GROUP_DEEP"); return e ? atoi(e) : 0; }();
+#define GROUP_LAUNCH(BM_, BN_, D_) hipLaunchKernelGGL((gemm_group_kernel<T, BM_, BN_, true, true, D_>), dim3(total), dim3(256), 0, s, g)
+    if constexpr (sizeof(T) == 2) {
+    if (deep == 4) {
+        if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 3); else if (bn == 128) GROUP_LAUNCH(64, 128, 4); else GROUP_LAUNCH(64, 96, 4);
+    } else if (deep == 3) {
+        if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 3); else if (bn == 128) GROUP_LAUNCH(64, 128, 3); else GROUP_LAUNCH(64, 96, 3);
+    } else if (deep == 2) {
+        if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 2); else if (bn == 128) GROUP_LAUNCH(64, 128, 2); else GROUP_LAUNCH(64, 96, 2);
+    } else {
+        if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 0); else if (bn == 128) GROUP_LAUNCH(64, 128, 0); else GROUP_LAUNCH(64, 96, 0);
+    }
+    } else {
+        if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 0); else if (bn == 128) GROUP_LAUNCH(64, 128, 0); else GROUP_LAUNCH(64, 96, 0);
+    }
+#undef GROUP_LAUNCH
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }

@@ -1,21 +1,25 @@
-import os, sys, torch
+"""Time mvlt_layernorm_fwd/bwd at the step's shapes (B=32): python scripts/bench_ln.py
+Prints us per launch and achieved GB/s of algorithmic bytes (fwd: read x, write y; bwd: read x, dy, dres, write dx)."""
+import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mvlt_amd  # noqa
 from mvlt_amd import ops
-dt = torch.bfloat16
-def t(f, n=50):
-    for _ in range(5): f()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): f()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
-for rows, C in ((6272, 384), (4192, 768), (100352, 96), (25088, 192), (1568, 768)):
-    x = torch.randn(rows, C, device="cuda").to(dt); dy = torch.randn(rows, C, device="cuda").to(dt)
-    g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
-    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
-    y, m, r, _ = ops.layernorm_fwd(x, g, b, 1e-5)
-    tf = t(lambda: ops.layernorm_fwd(x, g, b, 1e-5))
-    tb = t(lambda: ops.layernorm_bwd(dy, x, m, r, g, dg, db))
-    mb = rows * C * 2 / 1e6
-    print(f"rows={rows:6d} C={C:4d}  fwd {tf:6.1f} us ({2*mb/tf*1e-6*1e6/1e3:5.2f} TB/s)   bwd(+reduce) {tb:6.1f} us ({3*mb/tb*1e-6*1e6/1e3:5.2f} TB/s)", flush=True)
+
+dev = torch.device("cuda:0")
+SHAPES = [(100352, 96), (25088, 192), (6272, 384), (1568, 768), (4128, 768)]
+for rows, C in SHAPES:
+    x = torch.randn(rows, C, device=dev).bfloat16(); dy = torch.randn_like(x); dres = torch.randn_like(x)
+    g = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
+    y, mean, rstd, _ = ops.layernorm_fwd(x, g, b, 1e-5)
+    dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    q = ops.LnReduceQueue()
+    def fwd(): ops.layernorm_fwd(x, g, b, 1e-5)
+    def bwd(): ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dres, defer=q); q.items.clear(); q.off = 0
+    for name, fn, nbytes in (("fwd", fwd, rows * C * 4), ("bwd", bwd, rows * C * 8)):
+        for _ in range(5): fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(50): fn()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 50
+        print(f"rows={rows:6d} C={C:4d} {name}: {us:7.1f} us  {nbytes / us / 1e3:7.0f} GB/s", flush=True)
