@@ -1011,10 +1011,11 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
     // they get, not by their own k-depth) and the zeroing launch + atomics cost 1 ms per step (17.1 vs 15.9 ms).
     const int bke = 128 / (int)sizeof(T);
     int split = 1;
-    if (const char* ov = getenv("MVLT_GROUP_SPLIT")) {
-        const int v = atoi(ov);
+    const char* ov_split = getenv("MVLT_GROUP_SPLIT");
+    if (ov_split || tiles < 200) {
+        const int v = ov_split ? atoi(ov_split) : 0;
         if (v >= 1) split = v;
-        else if (tiles < 384) {
+        else if (tiles < (ov_split ? 384 : 200)) {
             split = (int)((512 + tiles - 1) / tiles);
             const int nkt = ceil_div(kmin, bke);
             if (split > nkt / 8) split = nkt / 8;

@@ -136,7 +136,9 @@ void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws, con
     long tiles = 0;
     if (bn) for (auto& it : items) tiles += ((it.dy->size(1) + 63) / 64) * ((it.x->size(1) + bn - 1) / bn);
     const int dtype = dtype_of(*items[0].dy);
-    if (!(n > 1 && n <= 8 && bn && tiles >= 200)) {
+    static const long long_k = [] { const char* e = getenv("MVLT_GROUP_LONG_K"); return e ? atol(e) : 8192L; }();
+    // few tiles but a long reduction (Swin stages 0/1): still one launch, cut into k-slices inside mvlt_gemm_group
+    if (!(n > 1 && n <= 8 && bn && (tiles >= 200 || items[0].dy->size(0) >= long_k))) {
         for (auto& it : items) {
             Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db); e.m_dev = k_dev;
             gemm(dtype, (int)it.dy->size(1), (int)it.x->size(1), (int)it.dy->size(0), dp(*it.dy), it.dy->size(1), true,

@@ -333,11 +333,15 @@ def layernorm_acc_fwd(acc, bias, residual, gamma, beta, eps, dtype, out=None):
     return y
 
 
+_GROUP_LONG_K = int(os.environ.get("MVLT_GROUP_LONG_K", "8192"))
+
+
 def wgrad_group(items):
     """Weight gradients of one layer: items = [(dY [R,No], X [R,Ni], dW f32 [No,Ni], dbias f32 [No] | None), ...]
     -> dW_i = dY_i^T X_i (and dbias_i = column sums of dY_i).  When the items qualify (mvlt_gemm_group) and
     their 64-row tiles together fill the GPU, they go out as ONE launch without split-K -- instead of
-    len(items) split-K launches plus their reduce kernels; otherwise one gemm() each."""
+    len(items) split-K launches plus their reduce kernels; with few tiles but >= 8192 reduction rows (Swin stages
+    0/1) still one launch, cut into k-slices that meet in the zeroed f32 output by atomicAdd; otherwise one gemm() each."""
     lib = L.lib()
     n = len(items)
     m_dev = None
@@ -346,7 +350,8 @@ def wgrad_group(items):
         items = [it[:4] for it in items]
     bn = 128 if all(x.shape[1] % 128 == 0 for _, x, _, _ in items) else (96 if all(x.shape[1] % 96 == 0 for _, x, _, _ in items) else 0)
     tiles = sum(((dy.shape[1] + 63) // 64) * ((x.shape[1] + bn - 1) // bn) for dy, x, _, _ in items) if bn else 0
-    if not (1 < n <= 8 and bn and tiles >= 200):
+    # few tiles but a long reduction (Swin stages 0/1): still one launch, cut into k-slices inside mvlt_gemm_group
+    if not (1 < n <= 8 and bn and (tiles >= 200 or items[0][0].shape[0] >= _GROUP_LONG_K)):
         for dy, x, dw, db in items:
             gemm(dy, x, a_kmajor=True, b_kmajor=True, out=dw, out_f32=True, a_colsum=db, m_dev=m_dev)
         return
