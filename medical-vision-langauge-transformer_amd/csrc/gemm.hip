@@ -525,6 +525,117 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     }
 }
 
+// 256 x 256 macro-tile, 8 waves (2 x 4, 128 x 64 outputs per wave), one workgroup per CU, same LDS-DMA double buffer
+// (2 x 64 KB).  For the wide forward products (N >= 1536, 100-256 macro-tiles): a CU's intake from L2 is what bounds the
+// k-loop (profiles/r2_gemm_pmc.md), and a 256 x 256 x 64 k-tile does 8.4 MFLOP per 64 KB loaded -- 1.8x the 128 x 128
+// tiles at 2.25 workgroups per CU -- with 0.375 ds_read_b128 per MFMA instead of 0.5.
+template <int R, int NW>
+MVLT_DEV void glds_fill_n(const bf16_t* const (&src)[R / (8 * NW)], bf16_t* lds_tile, int wave, long koff) {
+#pragma unroll
+    for (int j = 0; j < R / (8 * NW); ++j) {
+        bf16_t* dst = lds_tile + (wave * (R / (8 * NW)) + j) * 8 * 64;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src[j] + koff), (lds_void_t*)dst, 16, 0, 0);
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(512, 1) void gemm_glds8_kernel(const GemmDev p_in) {
+    using T = bf16_t;
+    constexpr int BKE = 64, NW = 8, WN = 4, WM = NW / WN, FM = BM / (16 * WM), FN = BN / (16 * WN);
+    constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW);
+    extern __shared__ __attribute__((aligned(16))) char smem8_raw[];
+    T* smem = reinterpret_cast<T*>(smem8_raw);
+    const GemmDev p = effective<false>(p_in);
+    const int gx = gridDim.x;
+    const int gy = min((int)gridDim.y, (p.M + BM - 1) / BM);
+    const int orig = blockIdx.y * gx + blockIdx.x;
+    if (orig >= gx * gy) return;
+    const int t = xcd_remap(orig, gx * gy);
+    const int by = t / gx, bx = t - by * gx;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int nkt = p.K / BKE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+    constexpr int STAGE = (BM + BN) * BKE;
+    const int rin = lane >> 3, chs = (lane & 7) ^ rin;
+    const T* srcA[PA];
+    const T* srcB[PB];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int row = min(m0 + (wave * PA + j) * 8 + rin, p.M - 1);
+        srcA[j] = A + (long)row * p.lda + chs * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int row = min(n0 + (wave * PB + j) * 8 + rin, p.N - 1);
+        srcB[j] = B + (long)row * p.ldb + chs * 8;
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // L2 warm-up loads: a k-tile of either operand is one 128-byte line per row, 2 x 256 lines per stage; wave w touches
+    // one dword of the lines of rows 64 (w & 3) + lane of A (w < 4) or B (w >= 4), PFD k-tiles ahead of the DMA, so the
+    // DMA finds its tile in the XCD's L2 instead of paying the Infinity-Cache / HBM latency once per k-tile.
+    const int xcode = p_in.k_per_split < 0 ? -p_in.k_per_split : 0;     // (experiment plumbing)
+    const int pfd = xcode & 15;                                          // prefetch distance, 0 = off
+    const bool no_dma = xcode & 256, no_mma = xcode & 512;               // ablation: k-loop without the DMA / without LDS reads + MFMA
+    const T* pfp;
+    {
+        const int r = (wave & 3) * 64 + lane;
+        pfp = wave < 4 ? A + (long)min(m0 + r, p.M - 1) * p.lda : B + (long)min(n0 + r, p.N - 1) * p.ldb;
+    }
+    uint32_t pf = 0;
+    // (always issued -- past the end it re-touches the last tile -- so the vmcnt below is exact: loads return in order,
+    // "all but the newest one" = this wave's DMA of tile kt has landed, the warm-up load behind it may still fly)
+    auto prefetch = [&](int kt2) {
+        if (pfd) asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(pfp + (long)min(kt2, nkt - 1) * BKE) : "memory");
+    };
+    if (nkt > 0) {
+        for (int q = 1; q <= pfd; ++q) prefetch(q);
+        glds_fill_n<BM, NW>(srcA, smem, wave, 0); glds_fill_n<BN, NW>(srcB, smem + BM * BKE, wave, 0);
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (pfd && kt > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(pf) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) :: "memory");
+        __syncthreads();
+        if (kt + 1 < nkt && !no_dma) {
+            T* nxt = smem + ((kt + 1) & 1) * STAGE;
+            glds_fill_n<BM, NW>(srcA, nxt, wave, (long)(kt + 1) * BKE);
+            glds_fill_n<BN, NW>(srcB, nxt + BM * BKE, wave, (long)(kt + 1) * BKE);
+        }
+        prefetch(kt + 1 + pfd);
+        const T* a = smem + (kt & 1) * STAGE;
+        const T* b = a + BM * BKE;
+        if (no_mma) continue;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            typename Mma<T>::Frag fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = tile_frag<T, BM, false>(a, wm * (BM / WM) + i * 16, kb);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = tile_frag<T, BN, false>(b, wn * (BN / WN) + j * 16, kb);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 16 + 4 * (lane >> 4);
+            epilogue4<T>(p, m, n, acc[i][j]);
+        }
+    }
+    asm volatile("" :: "v"(pf));
+}
+
 template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2>
 __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     __shared__ __attribute__((aligned(16))) T sA[TileGeom<T, BM, AK>::ELEMS];
@@ -920,6 +1031,22 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
         // faster on 128x128 tiles and 18-24 % on 64x64; inside the training step the 128x128 form (64 KB of LDS, two
         // workgroups per CU) is SLOWER than the register-staged one (three per CU, shares the CU better with the
         // weight-gradient stream): 16.5 vs 16.1 ms per step.
+        static const int big_mode = [] { const char* e = getenv("MVLT_BIG"); return e ? atoi(e) : 0; }();
+        if (big_mode && !ak && !bk && d.split_k <= 1 && p->K % 64 == 0 && p->N % 256 == 0 && d.a_vec && d.b_vec) {
+            const long t256 = (long)ceil_div(p->M, 256) * (p->N / 256);
+            if (t256 >= 64 && t256 <= 256) {
+                constexpr int sh = 2 * (256 + 256) * 64 * 2;
+                static const bool attr = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds8_kernel<256, 256>),
+                                                                         hipFuncAttributeMaxDynamicSharedMemorySize, sh) == hipSuccess; }();
+                (void)attr;
+                static const int pfd = [] { const char* e = getenv("MVLT_BIG_PFD"); return e ? atoi(e) : 0; }();   // + 256: no DMA, + 512: no MFMA
+                GemmDev d8 = d; if (pfd > 0) d8.k_per_split = -pfd;
+                hipLaunchKernelGGL((gemm_glds8_kernel<256, 256>), dim3(p->N / 256, ceil_div(p->M, 256)), dim3(512), sh, s, d8);
+                MVLT_LAUNCH_CHECK();
+                if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
+                return MVLT_OK;
+            }
+        }
         static const int glds_mode = [] { const char* e = getenv("MVLT_GLDS"); return e ? atoi(e) : 2; }();
         const bool glds_on = glds_mode == 1 || (glds_mode == 2 && pl.bm == 64);
         const int kspan = d.split_k > 1 ? d.k_per_split : p->K;
