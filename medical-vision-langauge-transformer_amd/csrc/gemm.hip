@@ -525,10 +525,10 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     }
 }
 
-// 256 x 256 macro-tile, 8 waves (2 x 4, 128 x 64 outputs per wave), one workgroup per CU, same LDS-DMA double buffer
-// (2 x 64 KB).  For the wide forward products (N >= 1536, 100-256 macro-tiles): a CU's intake from L2 is what bounds the
-// k-loop (profiles/r2_gemm_pmc.md), and a 256 x 256 x 64 k-tile does 8.4 MFLOP per 64 KB loaded -- 1.8x the 128 x 128
-// tiles at 2.25 workgroups per CU -- with 0.375 ds_read_b128 per MFMA instead of 0.5.
+// EXPERIMENT (MVLT_BIG=1, off by default): 256 x 256 macro-tile, 8 waves (2 x 4, 128 x 64 outputs per wave), one
+// workgroup per CU, same LDS-DMA double buffer (2 x 64 KB): 8.4 MFLOP per 64 KB loaded (1.8x the 128 x 128 tiles at 2.25
+// workgroups per CU), 0.375 ds_read_b128 per MFMA instead of 0.5.  Measured (profiles/r2_gemm_pmc.md, "macro-tile"):
+// BERT FFN-in forward 40.3 -> 34-35 us, every other eligible shape slower, 16.0 vs 15.5 ms in the step.
 template <int R, int NW>
 MVLT_DEV void glds_fill_n(const bf16_t* const (&src)[R / (8 * NW)], bf16_t* lds_tile, int wave, long koff) {
 #pragma unroll
@@ -577,40 +577,17 @@ __global__ __launch_bounds__(512, 1) void gemm_glds8_kernel(const GemmDev p_in) 
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // L2 warm-up loads: a k-tile of either operand is one 128-byte line per row, 2 x 256 lines per stage; wave w touches
-    // one dword of the lines of rows 64 (w & 3) + lane of A (w < 4) or B (w >= 4), PFD k-tiles ahead of the DMA, so the
-    // DMA finds its tile in the XCD's L2 instead of paying the Infinity-Cache / HBM latency once per k-tile.
-    const int xcode = p_in.k_per_split < 0 ? -p_in.k_per_split : 0;     // (experiment plumbing)
-    const int pfd = xcode & 15;                                          // prefetch distance, 0 = off
-    const bool no_dma = xcode & 256, no_mma = xcode & 512;               // ablation: k-loop without the DMA / without LDS reads + MFMA
-    const T* pfp;
-    {
-        const int r = (wave & 3) * 64 + lane;
-        pfp = wave < 4 ? A + (long)min(m0 + r, p.M - 1) * p.lda : B + (long)min(n0 + r, p.N - 1) * p.ldb;
-    }
-    uint32_t pf = 0;
-    // (always issued -- past the end it re-touches the last tile -- so the vmcnt below is exact: loads return in order,
-    // "all but the newest one" = this wave's DMA of tile kt has landed, the warm-up load behind it may still fly)
-    auto prefetch = [&](int kt2) {
-        if (pfd) asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(pfp + (long)min(kt2, nkt - 1) * BKE) : "memory");
-    };
-    if (nkt > 0) {
-        for (int q = 1; q <= pfd; ++q) prefetch(q);
-        glds_fill_n<BM, NW>(srcA, smem, wave, 0); glds_fill_n<BN, NW>(srcB, smem + BM * BKE, wave, 0);
-    }
+    if (nkt > 0) { glds_fill_n<BM, NW>(srcA, smem, wave, 0); glds_fill_n<BN, NW>(srcB, smem + BM * BKE, wave, 0); }
     for (int kt = 0; kt < nkt; ++kt) {
-        if (pfd && kt > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(pf) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nkt && !no_dma) {
+        if (kt + 1 < nkt) {
             T* nxt = smem + ((kt + 1) & 1) * STAGE;
             glds_fill_n<BM, NW>(srcA, nxt, wave, (long)(kt + 1) * BKE);
             glds_fill_n<BN, NW>(srcB, nxt + BM * BKE, wave, (long)(kt + 1) * BKE);
         }
-        prefetch(kt + 1 + pfd);
         const T* a = smem + (kt & 1) * STAGE;
         const T* b = a + BM * BKE;
-        if (no_mma) continue;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             typename Mma<T>::Frag fa[FM], fb[FN];
@@ -633,7 +610,6 @@ __global__ __launch_bounds__(512, 1) void gemm_glds8_kernel(const GemmDev p_in) 
             epilogue4<T>(p, m, n, acc[i][j]);
         }
     }
-    asm volatile("" :: "v"(pf));
 }
 
 template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2>
@@ -1039,9 +1015,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
                 static const bool attr = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds8_kernel<256, 256>),
                                                                          hipFuncAttributeMaxDynamicSharedMemorySize, sh) == hipSuccess; }();
                 (void)attr;
-                static const int pfd = [] { const char* e = getenv("MVLT_BIG_PFD"); return e ? atoi(e) : 0; }();   // + 256: no DMA, + 512: no MFMA
-                GemmDev d8 = d; if (pfd > 0) d8.k_per_split = -pfd;
-                hipLaunchKernelGGL((gemm_glds8_kernel<256, 256>), dim3(p->N / 256, ceil_div(p->M, 256)), dim3(512), sh, s, d8);
+                hipLaunchKernelGGL((gemm_glds8_kernel<256, 256>), dim3(p->N / 256, ceil_div(p->M, 256)), dim3(512), sh, s, d);
                 MVLT_LAUNCH_CHECK();
                 if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
                 return MVLT_OK;
