@@ -295,35 +295,46 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
         }
     };
     // ---- hot loop: full k-tiles only, no predication, nothing but loads / ds_write / ds_read / MFMA
-    if constexpr (DEEP > 1) {
-        // weight gradients (K = thousands of rows, 1-2 workgroups per CU): a ring of DEEP register sets keeps the
-        // loads of DEEP k-tiles in flight -- with one set the loop runs at one memory latency per k-tile.  Every
-        // slot always loads (the compiler then counts vmcnt exactly); past the last tile the pointers stop advancing
-        // and the slot re-reads the last tile, which nobody consumes.
-        Vec qa[DEEP][GA::PER_THREAD], qb[DEEP][GB::PER_THREAD];
-        auto issue = [&](Vec* a, Vec* b, bool adv) {
-            const long sa = adv ? la.step : 0, sb = adv ? lb.step : 0;
+    if constexpr (DEEP == 2) {
+        // weight gradients (1-2 workgroups per CU, thousands of k rows): two register sets AND two LDS stages, one
+        // barrier per k-tile.  Tile t+1 (loaded a whole iteration ago) is written to the other LDS stage at the top of
+        // iteration t, so its ds_writes, the global loads of tile t+2 and the ds_reads + MFMAs of tile t all overlap;
+        // with one stage every k-tile was a chain load-wait -> ds_write -> barrier -> ds_read -> MFMA -> barrier.
+        Vec qa[2][GA::PER_THREAD], qb[2][GB::PER_THREAD];
+        T* const sA1 = sA + GA::ELEMS;
+        T* const sB1 = sB + GB::ELEMS;
+        auto compute_stage = [&](const T* a_, const T* b_) {
 #pragma unroll
-            for (int i = 0; i < GA::PER_THREAD; ++i) { a[i] = *reinterpret_cast<const Vec*>(la.ptr[i]); la.ptr[i] += sa; }
+            for (int kb = 0; kb < 2; ++kb) {
+                typename Mma<T>::Frag fa[FM], fb[FN];
 #pragma unroll
-            for (int i = 0; i < GB::PER_THREAD; ++i) { b[i] = *reinterpret_cast<const Vec*>(lb.ptr[i]); lb.ptr[i] += sb; }
+                for (int i = 0; i < FM; ++i) fa[i] = tile_frag<T, BM, AK>(a_, wm * (BM / 2) + i * 16, kb);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) fb[j] = tile_frag<T, BN, BK_>(b_, wn * (BN / 2) + j * 16, kb);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
+            }
         };
         if (nfast > 0) {
-            int issued = 0;
-#pragma unroll
-            for (int j = 0; j < DEEP; ++j) { issue(qa[j], qb[j], issued + 1 < nfast); ++issued; }
-            for (int kt = 0; kt < nfast; kt += DEEP) {
-#pragma unroll
-                for (int j = 0; j < DEEP; ++j) {
-                    if (kt + j < nfast) {
-                        tile_store<T, BM, AK>(qa[j], sA);
-                        tile_store<T, BN, BK_>(qb[j], sB);
-                        colsum_regs(qa[j]);
-                        __syncthreads();
-                        issue(qa[j], qb[j], issued + 1 < nfast); ++issued;
-                        compute_tile();
-                        __syncthreads();
-                    }
+            la.load(qa[0]); lb.load(qb[0]);
+            if (nfast > 1) { la.load(qa[1]); lb.load(qb[1]); }
+            tile_store<T, BM, AK>(qa[0], sA);
+            tile_store<T, BN, BK_>(qb[0], sB);
+            colsum_regs(qa[0]);
+            __syncthreads();
+            for (int kt = 0; kt < nfast; kt += 2) {
+                // even tile kt lives in stage 0, registers set 0 is free again
+                if (kt + 1 < nfast) { tile_store<T, BM, AK>(qa[1], sA1); tile_store<T, BN, BK_>(qb[1], sB1); colsum_regs(qa[1]); }
+                if (kt + 2 < nfast) { la.load(qa[0]); lb.load(qb[0]); }
+                compute_stage(sA, sB);
+                __syncthreads();
+                if (kt + 1 < nfast) {
+                    if (kt + 2 < nfast) { tile_store<T, BM, AK>(qa[0], sA); tile_store<T, BN, BK_>(qb[0], sB); colsum_regs(qa[0]); }
+                    if (kt + 3 < nfast) { la.load(qa[1]); lb.load(qb[1]); }
+                    compute_stage(sA1, sB1);
+                    __syncthreads();
                 }
             }
         }
@@ -808,8 +819,8 @@ struct GemmGroupDev { int n; int split; int start[GROUP_MAX + 1]; GemmDev g[GROU
 
 template <typename T, int BM, int BN, bool AK, bool BK_, int DEEP>
 __global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GemmGroupDev gp) {
-    __shared__ __attribute__((aligned(16))) T sA[TileGeom<T, BM, AK>::ELEMS];
-    __shared__ __attribute__((aligned(16))) T sB[TileGeom<T, BN, BK_>::ELEMS];
+    __shared__ __attribute__((aligned(16))) T sA[(DEEP == 2 ? 2 : 1) * TileGeom<T, BM, AK>::ELEMS];
+    __shared__ __attribute__((aligned(16))) T sB[(DEEP == 2 ? 2 : 1) * TileGeom<T, BN, BK_>::ELEMS];
     // persistent: the grid may be smaller than the tile list (the launcher caps the workgroups per CU so the
     // dgrad chain on the main stream keeps most of every CU); gemm_body ends on a barrier, so LDS is reusable
     const int total = gp.start[gp.n];
@@ -1151,18 +1162,14 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
     int total = g.start[n], per_cu = 2;
     if (const char* ov = getenv("MVLT_GROUP_WGS")) per_cu = atoi(ov);
     if (per_cu > 0 && total > per_cu * 256) total = per_cu * 256;
-    static const int deep = [] { const char* e = getenv("MVLT_GROUP_DEEP"); return e ? atoi(e) : 0; }();
+    static const int deep = [] { const char* e = getenv("MVLT_GROUP_DEEP"); return e ? atoi(e) : 2; }();
 #define GROUP_LAUNCH(BM_, BN_, D_) hipLaunchKernelGGL((gemm_group_kernel<T, BM_, BN_, true, true, D_>), dim3(total), dim3(256), 0, s, g)
     if constexpr (sizeof(T) == 2) {
-    if (deep == 4) {
-        if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 3); else if (bn == 128) GROUP_LAUNCH(64, 128, 4); else GROUP_LAUNCH(64, 96, 4);
-    } else if (deep == 3) {
-        if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 3); else if (bn == 128) GROUP_LAUNCH(64, 128, 3); else GROUP_LAUNCH(64, 96, 3);
-    } else if (deep == 2) {
-        if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 2); else if (bn == 128) GROUP_LAUNCH(64, 128, 2); else GROUP_LAUNCH(64, 96, 2);
-    } else {
-        if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 0); else if (bn == 128) GROUP_LAUNCH(64, 128, 0); else GROUP_LAUNCH(64, 96, 0);
-    }
+        if (deep == 2) {
+            if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 2); else if (bn == 128) GROUP_LAUNCH(64, 128, 2); else GROUP_LAUNCH(64, 96, 2);
+        } else {
+            if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 0); else if (bn == 128) GROUP_LAUNCH(64, 128, 0); else GROUP_LAUNCH(64, 96, 0);
+        }
     } else {
         if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 0); else if (bn == 128) GROUP_LAUNCH(64, 128, 0); else GROUP_LAUNCH(64, 96, 0);
     }
