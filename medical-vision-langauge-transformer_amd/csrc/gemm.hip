@@ -117,18 +117,18 @@ MVLT_DEV void epilogue4(const GemmDev& p, int m, int n, f32x4 v) {
     }
 }
 
-// k-major bf16 tiles of 64 / 128 rows are stored UNPADDED with their 32-byte column chunks XOR-swizzled by a function
+// k-major bf16 tiles of 64 / 96 / 128 rows are stored (96: in 128-wide rows) with their 32-byte column chunks XOR-swizzled by a function
 // of k: a ds_read_b64_tr_b16 group of 32 lanes reads 8 k-rows {k0..k0+3, k0+8..k0+11} x 32 bytes, which padding alone
 // cannot spread over the 64 banks (rows k and k+8 alias for every pad that keeps 32-byte chunks aligned: 2-way conflicts,
 // 32 % of the LDS cycles of the weight-gradient kernels, profiles/r2_dominant_kernel_pmc.txt).
 template <int R> MVLT_DEV int kswz(int k) {
-    return R == 128 ? ((k & 3) | ((k >> 1) & 4)) : (((k >> 1) & 1) | ((k >> 2) & 2));
+    return R >= 96 ? ((k & 3) | ((k >> 1) & 4)) : (((k >> 1) & 1) | ((k >> 2) & 2));
 }
 template <typename T, int R, bool KMAJOR> struct TileGeom {
     static constexpr int E = TypeInfo<T>::E;
     static constexpr int BKE = 128 / (int)sizeof(T);          // k elements per tile
-    static constexpr bool SWZ = KMAJOR && sizeof(T) == 2 && (R == 64 || R == 128);
-    static constexpr int PAD = KMAJOR ? (SWZ ? 0 : (sizeof(T) == 2 ? 16 : 4)) : 0;
+    static constexpr bool SWZ = KMAJOR && sizeof(T) == 2 && (R == 64 || R == 96 || R == 128);
+    static constexpr int PAD = KMAJOR ? (SWZ ? (R == 96 ? 32 : 0) : (sizeof(T) == 2 ? 16 : 4)) : 0;   // 96: six chunks swizzled inside eight
     static constexpr int LD = KMAJOR ? (R + PAD) : BKE;        // elements per LDS row
     static constexpr int ELEMS = KMAJOR ? BKE * LD : R * BKE;
     static constexpr int CHUNKS = R * 8;                        // 16-byte chunks per tile
