@@ -7,6 +7,7 @@ Tolerances (relative Frobenius error unless noted):
   bf16 compute (bf16 storage, f32 accumulate): 3e-2 on hidden states, 2e-3 on the loss, 6e-2 on gradients
 Index / layout outputs are bit-exact (tests/test_hostlogic_cpu.py).
 """
+import os
 import random
 
 import pytest
@@ -305,6 +306,8 @@ def test_full_pretrain_vs_reference_on_well_conditioned_weights(M, golden, specs
             e_head = rel_err(gr.reshape(-1)[:256].cpu(), g[f"grad_{name}_{pn}"])
             if e_norm > HASH_GRAD[cd] or e_head > HASH_GRAD[cd]:
                 bad.append((pn, e_norm, e_head))
+            if os.environ.get("MVLT_TEST_VERBOSE"):
+                print(f"{name} {pn}: norm err {e_norm:.2e}, first-256 err {e_head:.2e}")
         assert not bad, bad
         head = "MLM_head_" + name
         gd = params[f"{head}.predictions.decoder.weight"].grad.double().norm().item()
