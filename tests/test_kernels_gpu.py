@@ -115,7 +115,9 @@ def test_gemm_epilogues(ops, dt):
 @pytest.mark.parametrize("widths,R", [([(768, 3072), (3072, 768), (768, 768), (2304, 768)], 1573),      # one BERT layer, ragged R
                                       ([(384, 1536), (1536, 384), (384, 384), (1152, 384)], 6272),      # one Swin stage-2 block
                                       ([(192, 768), (768, 192), (192, 192), (576, 192)], 1000),         # widths multiple of 96 only
-                                      ([(96, 384), (384, 96)], 500)])                                   # too few tiles -> one by one
+                                      ([(96, 384), (384, 96)], 500),                                    # too few tiles -> one by one
+                                      ([(96, 384), (384, 96), (288, 96), (96, 96)], 9001),              # Swin stage 0: few tiles, long reduction -> in-launch k-slices (atomicAdd), 96-wide swizzled tiles
+                                      ([(192, 768), (768, 192), (576, 192), (192, 192)], 8200)])       # Swin stage 1, same path
 def test_wgrad_group(ops, dt, widths, R):
     """mvlt_gemm_group: the weight gradients of one layer in one launch == the products one by one."""
     items, refs = [], []
@@ -131,6 +133,25 @@ def test_wgrad_group(ops, dt, widths, R):
         assert rel(dw, rw) < tol(dt)
         if db is not None:
             assert rel(db, rb) < tol(dt)
+
+
+@pytest.mark.parametrize("R,used", [(1573, 1000), (9001, 8300)])
+def test_wgrad_group_device_row_count(ops, R, used):
+    """The reduction length of a grouped launch can live on the device (ragged batches): rows at or beyond it are
+    not read -- they hold NaN here -- in the one-launch path and in the k-sliced path."""
+    dt = torch.bfloat16
+    widths = [(768, 3072), (3072, 768), (768, 768), (2304, 768)] if R < 8192 else [(96, 384), (384, 96), (288, 96), (96, 96)]
+    m_dev = torch.tensor([used], dtype=torch.int32, device="cuda")
+    items, refs = [], []
+    for i, (no, ni) in enumerate(widths):
+        dy, x = rnd((R, no), dt, 30 + i, 0.5), rnd((R, ni), dt, 40 + i, 0.5)
+        refs.append((dy[:used].float().t() @ x[:used].float(), dy[:used].float().sum(0)))
+        dy[used:] = float("nan"); x[used:] = float("nan")
+        items.append((dy, x, torch.full((no, ni), float("nan"), device="cuda"), torch.full((no,), float("nan"), device="cuda"), m_dev))
+    ops.wgrad_group(items)
+    torch.cuda.synchronize()
+    for (dy, x, dw, db, _), (rw, rb) in zip(items, refs):
+        assert rel(dw, rw) < tol(dt) and rel(db, rb) < tol(dt)
 
 
 @pytest.mark.parametrize("dt", DT)
