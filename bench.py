@@ -223,7 +223,7 @@ def other_configs(M):
 
 def profiled_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (cannot be collected
-    inside this process): profiles/r2_dominant_kernel_traffic.json, written by scripts/pmc_traffic.py."""
+    inside this process): profiles/r2_dominant_kernel_traffic.json, filled in from the scripts/pmc.py passes (profiles/r2_dominant_kernel_pmc.txt)."""
     f = os.path.join(ROOT, "profiles", "r2_dominant_kernel_traffic.json")
     try:
         with open(f) as fh:
