@@ -1021,7 +1021,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
         static const int big_mode = [] { const char* e = getenv("MVLT_BIG"); return e ? atoi(e) : 0; }();
         if (big_mode && !ak && !bk && d.split_k <= 1 && p->K % 64 == 0 && p->N % 256 == 0 && d.a_vec && d.b_vec) {
             const long t256 = (long)ceil_div(p->M, 256) * (p->N / 256);
-            if (t256 >= 64 && t256 <= 256) {
+            if (t256 >= 64 && (t256 <= 256 || big_mode == 2)) {          // MVLT_BIG=2: any number of macro-tiles (size sweeps)
                 constexpr int sh = 2 * (256 + 256) * 64 * 2;
                 static const bool attr = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds8_kernel<256, 256>),
                                                                          hipFuncAttributeMaxDynamicSharedMemorySize, sh) == hipSuccess; }();
