@@ -83,6 +83,12 @@ typedef struct MvltGemm {
                                         rows of A / C beyond it are neither read nor written (M is the upper bound the
                                         launch is sized for); a_kmajor=1 (weight gradients): the reduction stops there
                                         (K is the upper bound) */
+    const void* prefetch; int64_t prefetch_bytes;
+                                     /* optional: a read-only byte range (the weight matrix of the NEXT nn.Linear of the
+                                        layer) that this launch pulls towards the caches while it runs -- every thread
+                                        reads and drops one dword of a few of its 128-byte lines.  The optimizer's sweep
+                                        evicts all weights from the Infinity Cache once per step; a product whose weight
+                                        panel is already on its way runs 10-20 % faster (profiles/r2_weight_prefetch.txt) */
 } MvltGemm;
 int mvlt_gemm(const MvltGemm* p, void* stream);
 size_t mvlt_gemm_workspace_bytes(const MvltGemm* p);
@@ -357,6 +363,14 @@ int mvlt_argmax(int dtype, const void* logits, int64_t ld, int rows, int V, int6
  * accumulated with atomics and must start from zero; items is a HOST array) */
 typedef struct MvltZeroItem { float* ptr; int64_t n; } MvltZeroItem;
 int mvlt_zero_batch(const MvltZeroItem* items, int n, void* stream);
+
+/* Pull up to 8 read-only byte ranges (the weight matrices of the layer about to run) towards the GPU's caches: one
+ * dword of every 128-byte line is read and dropped.  The optimizer's sweep over 6 GB of state evicts every weight from
+ * the 256 MB Infinity Cache once per step, so each nn.Linear of the reference (model.py / visual_feature_extractor.py
+ * forward passes) would otherwise stream its weight panels from HBM at one miss latency per k-tile.  items is a HOST
+ * array; nothing is written. */
+typedef struct MvltRange { const void* ptr; int64_t bytes; } MvltRange;
+int mvlt_prefetch(const MvltRange* items, int n, void* stream);
 
 /* ------------------------------------------------------------------ input pipeline
  * The reference prepares every sample on the host (run_pretrain_rgc_roco_medicat.py:94-212); these two entry

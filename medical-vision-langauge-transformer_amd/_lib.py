@@ -29,7 +29,8 @@ class MvltGemm(C.Structure):
                 ("bias", vp), ("pre", vp), ("residual", vp), ("ldr", i64), ("aux", vp),
                 ("rowscale", vp), ("rows_per_scale", i32), ("rowmap", vp),
                 ("dropout_p", f32), ("seed", u64), ("tag", u32),
-                ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("a_colsum", vp), ("event_after_main", vp), ("m_dev", vp)]
+                ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("a_colsum", vp), ("event_after_main", vp), ("m_dev", vp),
+                ("prefetch", vp), ("prefetch_bytes", i64)]
 
 
 class MvltLayerNorm(C.Structure):
@@ -94,6 +95,10 @@ class MvltAttnCached(C.Structure):
                 ("qkv_new", vp), ("k_cache", vp), ("v_cache", vp), ("out", vp), ("scale", f32), ("past_dev", vp)]
 
 
+class MvltRange(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_int64)]
+
+
 class MvltZeroItem(C.Structure):
     _fields_ = [("ptr", vp), ("n", i64)]
 
@@ -150,6 +155,7 @@ SYMBOLS = {
     "mvlt_attn_cached": (i32, [C.POINTER(MvltAttnCached), vp]),
     "mvlt_argmax": (i32, [i32, vp, i64, i32, i32, vp, vp]),
     "mvlt_zero_batch": (i32, [C.POINTER(MvltZeroItem), i32, vp]),
+    "mvlt_prefetch": (i32, [C.POINTER(MvltRange), i32, vp]),
     "mvlt_image_normalize": (i32, [vp, vp, i32, i32, i32, vp]),
     "mvlt_mlm_mask": (i32, [C.POINTER(MvltMlmMask), vp]),
 }

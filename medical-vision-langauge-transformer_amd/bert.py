@@ -317,6 +317,14 @@ class MVLBert(nn.Module):
             c, g = ar.compute, ar.grad_view
             w = [c(sa.query.weight, H3).data_ptr(), c(so.dense.weight).data_ptr(), c(li.dense.weight).data_ptr(),
                  c(lo.dense.weight).data_ptr()]
+            # (ptr, bytes) of the weights the neighbouring layers use first: the last product of a pass pulls them
+            # towards the caches while it runs (MvltGemm.prefetch) -- next layer's qkv, previous layer's FFN-out
+            layers = list(self.encoder.layer)
+            i = next(k for k, l in enumerate(layers) if l is layer)
+            nxt = c(layers[i + 1].attention.self.query.weight, H3) if i + 1 < len(layers) else None
+            prv = c(layers[i - 1].output.dense.weight) if i > 0 else None
+            for t in (nxt, prv):
+                w += [t.data_ptr(), t.numel() * t.element_size()] if t is not None else [0, 0]
             f = [ar.master_span(sa.query.bias, H3).data_ptr(), so.dense.bias.data.data_ptr(), li.dense.bias.data.data_ptr(),
                  lo.dense.bias.data.data_ptr(), so.LayerNorm.weight.data.data_ptr(), so.LayerNorm.bias.data.data_ptr(),
                  lo.LayerNorm.weight.data.data_ptr(), lo.LayerNorm.bias.data.data_ptr()]

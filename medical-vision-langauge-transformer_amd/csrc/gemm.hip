@@ -27,6 +27,7 @@ struct GemmDev {
     int split_k; int k_per_split; float* ws;
     int a_vec, b_vec, epi_vec;
     float* a_colsum; float* ws_colsum;   // optional: column sums of a k-major A (bias gradient), fused
+    const char* pf; long pf_lines;       // optional: 128-byte lines of the next product's weights to pull towards the caches
     const int* m_dev;                    // optional: valid storage rows of A on the device (MvltGemm.m_dev)
     int atomic_out;                      // grouped weight gradients with in-launch split-K: f32 atomicAdd onto zeroed C
 };
@@ -226,6 +227,18 @@ MVLT_DEV typename Mma<T>::Frag tile_frag(const T* lds, int row0, int kb) {
 MVLT_DEV int xcd_remap(int orig, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// MvltGemm.prefetch: every thread of the launch reads one dword of a few 128-byte lines of a byte range that a LATER kernel
+// will stream (the next nn.Linear's weights, evicted by the optimizer's sweep since their last use); the value is dropped.
+MVLT_DEV unsigned prefetch_lines(const GemmDev& p) {
+    unsigned acc = 0;
+    if (p.pf) {
+        const long nthr = (long)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
+        const long g = ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        for (long l = g; l < p.pf_lines; l += nthr) acc ^= *reinterpret_cast<const unsigned*>(p.pf + (l << 7));
+    }
+    return acc;
 }
 
 // one output tile (bx, by) of one k-split bz
@@ -459,6 +472,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     constexpr int BKE = 64, FM = BM / 32, FN = BN / 32;
     __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * BKE];
     const GemmDev p = effective<false>(p_in);
+    const unsigned pfv = prefetch_lines(p_in);
     const int gx = gridDim.x;
     const int gy = min((int)gridDim.y, (p.M + BM - 1) / BM);
     const int orig = blockIdx.y * gx + blockIdx.x;
@@ -534,6 +548,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
             }
         }
     }
+    asm volatile("" :: "v"(pfv));
 }
 
 // EXPERIMENT (MVLT_BIG=1, off by default): 256 x 256 macro-tile, 8 waves (2 x 4, 128 x 64 outputs per wave), one
@@ -630,13 +645,16 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     // ragged batches (m_dev): the tile list is the EFFECTIVE one -- the XCD remap deals contiguous chunks of it to the
     // XCDs, so remapping the upper-bound list would leave the XCDs that own the empty tail idle
     const GemmDev q = effective<AK>(p);
+    const unsigned pfv = prefetch_lines(p);
     const int gx = gridDim.x;
     const int gy = AK ? (int)gridDim.y : min((int)gridDim.y, (q.M + BM - 1) / BM);
     const int orig = blockIdx.y * gx + blockIdx.x;
-    if (orig >= gx * gy) return;
-    const int t = xcd_remap(orig, gx * gy);
-    const int by = t / gx;
-    gemm_body<T, BM, BN, AK, BK_, PF2>(q, t - by * gx, by, blockIdx.z, sA, sB);
+    if (orig < gx * gy) {
+        const int t = xcd_remap(orig, gx * gy);
+        const int by = t / gx;
+        gemm_body<T, BM, BN, AK, BK_, PF2>(q, t - by * gx, by, blockIdx.z, sA, sB);
+    }
+    asm volatile("" :: "v"(pfv));
 }
 
 // Skinny products (M <= 64: the 2-token decode step, poolers, classifier heads): the weight matrix is read once
@@ -983,6 +1001,8 @@ static int fill_dev(const MvltGemm* p, const Plan& pl, GemmDev& d) {
     }
     d.ws = reinterpret_cast<float*>(p->workspace);
     d.a_colsum = p->a_colsum;
+    d.pf = (p->prefetch && p->prefetch_bytes >= 128) ? reinterpret_cast<const char*>(p->prefetch) : nullptr;
+    d.pf_lines = d.pf ? (long)(p->prefetch_bytes >> 7) : 0;
     d.m_dev = p->m_dev;
     d.atomic_out = 0;
     d.ws_colsum = d.ws ? d.ws + (size_t)d.split_k * p->M * p->N : nullptr;

@@ -71,6 +71,7 @@ void* workspace(Scratch& s, size_t need, const Tensor& like) {
 
 // ----------------------------------------------------------------------------------------------- GEMM
 struct Epi {
+    const void* pf = nullptr; int64_t pf_bytes = 0;      // MvltGemm.prefetch: the weights of the product that runs next
     const float* bias = nullptr; bool gelu = false; void* pre = nullptr;
     float drop_p = 0.f; uint64_t seed = 0; uint32_t tag = 0;
     const float* rowscale = nullptr; int rps = 1;
@@ -98,6 +99,8 @@ void fill_gemm(MvltGemm& p, int dtype, int M, int N, int K, const void* A, int64
     p.epilogue = epi;
     p.a_colsum = e.a_colsum;
     p.m_dev = e.m_dev;
+    static const bool pf_on = [] { const char* v = getenv("MVLT_WEIGHT_PREFETCH"); return !(v && v[0] == '0'); }();
+    if (pf_on) { p.prefetch = e.pf; p.prefetch_bytes = e.pf_bytes; }
 }
 
 void gemm(int dtype, int M, int N, int K, const void* A, int64_t lda, bool ak, const void* B, int64_t ldb, bool bk,
@@ -245,23 +248,25 @@ std::vector<Tensor> bert_layer_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f
     const uint64_t sd = (uint64_t)seed;
     const int32_t* rd = attn.size() > 10 ? P<const int32_t>(attn[10]) : nullptr;      // valid rows on the device (auto-packed batch)
     Tensor qkv = empty2(rows, 3 * H, x);
-    { Epi e; e.m_dev = rd; e.bias = P<float>(f[0]); linear(x, w[0], (int)(3 * H), qkv, e, st); }
+    const int64_t esz = x.element_size();
+    const bool nb = w.size() >= 8;                       // w[4..7]: (ptr, bytes) of the next layer's qkv / the previous layer's FFN-out weights
+    { Epi e; e.m_dev = rd; e.bias = P<float>(f[0]); e.pf = P(w[1]); e.pf_bytes = H * H * esz; linear(x, w[0], (int)(3 * H), qkv, e, st); }
     Tensor ctx = empty2(rows, H, x);
     Tensor lse = emptyf({a.B, a.nH, a.Lq}, x);
     { MvltAttn p; fill_attn(p, qkv, a, (int)H, dp(ctx), fp(lse), (float)p_a, sd, (uint32_t)(8 * layer + 0));
       ck(mvlt_attn_fwd(&p, st), "mvlt_attn_fwd"); }
     Tensor y1 = empty2(rows, H, x);
     { Epi e; e.m_dev = rd; e.bias = P<float>(f[1]); e.drop_p = (float)p_h; e.seed = sd; e.tag = (uint32_t)(8 * layer + 1);
-      e.residual = dp(x); e.ldr = H; linear(ctx, w[1], (int)H, y1, e, st); }
+      e.residual = dp(x); e.ldr = H; e.pf = P(w[2]); e.pf_bytes = I * H * esz; linear(ctx, w[1], (int)H, y1, e, st); }
     Tensor x1 = empty2(rows, H, x), st1, st2;
     float *m1 = nullptr, *r1 = nullptr, *m2 = nullptr, *r2 = nullptr;
     if (save) { st1 = emptyf({2, rows}, x); m1 = fp(st1); r1 = m1 + rows; st2 = emptyf({2, rows}, x); m2 = fp(st2); r2 = m2 + rows; }
     ln_fwd(y1, (int)rows, (int)H, f[4], f[5], (float)eps, x1, m1, r1, nullptr, st, rd);
     Tensor h = empty2(rows, I, x), act = empty2(rows, I, x);
-    { Epi e; e.m_dev = rd; e.bias = P<float>(f[2]); e.gelu = true; e.pre = dp(h); linear(x1, w[2], (int)I, act, e, st); }
+    { Epi e; e.m_dev = rd; e.bias = P<float>(f[2]); e.gelu = true; e.pre = dp(h); e.pf = P(w[3]); e.pf_bytes = H * I * esz; linear(x1, w[2], (int)I, act, e, st); }
     Tensor y2 = empty2(rows, H, x);
     { Epi e; e.m_dev = rd; e.bias = P<float>(f[3]); e.drop_p = (float)p_h; e.seed = sd; e.tag = (uint32_t)(8 * layer + 2);
-      e.residual = dp(x1); e.ldr = H; linear(act, w[3], (int)H, y2, e, st); }
+      e.residual = dp(x1); e.ldr = H; if (nb) { e.pf = P(w[4]); e.pf_bytes = w[5]; } linear(act, w[3], (int)H, y2, e, st); }
     Tensor x2 = empty2(rows, H, x);
     ln_fwd(y2, (int)rows, (int)H, f[6], f[7], (float)eps, x2, m2, r2, nullptr, st, rd);
     if (!save) return {x2};
@@ -285,21 +290,23 @@ Tensor bert_layer_bwd(const Tensor& dx, const std::vector<Tensor>& sv, const Ptr
     { LnBranch br; if (p_h > 0) { dz2 = empty2(rows, H, x); br.dz = dp(dz2); br.drop_p = (float)p_h; br.seed = sd; br.tag = (uint32_t)(8 * layer + 2); }
       ln_bwd(dx, nullptr, y2, fp(st2), fp(st2) + rows, (int)rows, (int)H, f[6], g[10], g[11], nullptr, dy2, br, st, rd); }
     Tensor dh = empty2(rows, I, x);
-    { Epi e; e.m_dev = rd; e.aux = dp(h); dgrad(dz2, w[3], (int)I, dh, e, st); }
+    const int64_t esz = x.element_size();
+    const bool nb = w.size() >= 8;
+    { Epi e; e.m_dev = rd; e.aux = dp(h); e.pf = P(w[2]); e.pf_bytes = I * H * esz; dgrad(dz2, w[3], (int)I, dh, e, st); }
     Tensor dx1 = empty2(rows, H, x);
-    { Epi e; e.m_dev = rd; e.residual = dp(dy2); e.ldr = H; dgrad(dh, w[2], (int)H, dx1, e, st); }
+    { Epi e; e.m_dev = rd; e.residual = dp(dy2); e.ldr = H; e.pf = P(w[1]); e.pf_bytes = H * H * esz; dgrad(dh, w[2], (int)H, dx1, e, st); }
     Tensor dy1 = empty2(rows, H, x), dz1 = dy1;
     { LnBranch br; if (p_h > 0) { dz1 = empty2(rows, H, x); br.dz = dp(dz1); br.drop_p = (float)p_h; br.seed = sd; br.tag = (uint32_t)(8 * layer + 1); }
       ln_bwd(dx1, nullptr, y1, fp(st1), fp(st1) + rows, (int)rows, (int)H, f[4], g[8], g[9], nullptr, dy1, br, st, rd); }
     Tensor dctx = empty2(rows, H, x);
-    { Epi e; e.m_dev = rd; dgrad(dz1, w[1], (int)H, dctx, e, st); }
+    { Epi e; e.m_dev = rd; e.pf = P(w[0]); e.pf_bytes = 3 * H * H * esz; dgrad(dz1, w[1], (int)H, dctx, e, st); }
     Tensor dqkv = empty2(rows, 3 * H, x);
     { MvltAttn p; fill_attn(p, qkv, a, (int)H, dp(ctx), fp(lse), (float)p_a, sd, (uint32_t)(8 * layer + 0));
       Tensor delta = at::empty_like(lse);
       p.dout = dp(dctx); p.dqkv = dp(dqkv); p.delta_ws = fp(delta);
       ck(mvlt_attn_bwd(&p, st), "mvlt_attn_bwd"); }
     Tensor dxin = empty2(rows, H, x);
-    { Epi e; e.m_dev = rd; e.residual = dp(dy1); e.ldr = H; dgrad(dqkv, w[0], (int)H, dxin, e, st); }
+    { Epi e; e.m_dev = rd; e.residual = dp(dy1); e.ldr = H; if (nb) { e.pf = P(w[6]); e.pf_bytes = w[7]; } dgrad(dqkv, w[0], (int)H, dxin, e, st); }
     // weight / bias gradients on the side stream (off the critical path)
     fork_side(ss);
     for (const Tensor* t : std::initializer_list<const Tensor*>{&dz2, &act, &dh, &x1, &dz1, &ctx, &dqkv, &x}) g_side_keepalive.push_back(*t);
@@ -320,6 +327,8 @@ std::vector<Tensor> swin_block_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f
     const int64_t rows = x.size(0);
     const int Lt = res * res, nW = (res / 7) * (res / 7);
     const int dtype = dtype_of(x);
+    const int64_t esz = x.element_size();
+    const bool nb = w.size() >= 8;                       // w[4..7]: (ptr, bytes) of the next block's qkv / the previous block's fc2 weights
     Tensor xn1w, qkv, ao, lse, stat1, x1 = empty2(rows, C, x);
     float *m1 = nullptr, *r1 = nullptr;
     if (save) { stat1 = emptyf({2, rows}, x); m1 = fp(stat1); r1 = m1 + rows; }
@@ -339,7 +348,7 @@ std::vector<Tensor> swin_block_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f
         xn1w = empty2(rows, C, x);
         ln_fwd(x, (int)rows, C, f[0], f[1], (float)eps, xn1w, m1, r1, P<const int32_t>(maps[1]), st);
         qkv = empty2(rows, 3 * C, x);
-        { Epi e; e.bias = P<float>(f[2]); linear(xn1w, w[0], 3 * C, qkv, e, st); }
+        { Epi e; e.bias = P<float>(f[2]); e.pf = P(w[1]); e.pf_bytes = (int64_t)C * C * esz; linear(xn1w, w[0], 3 * C, qkv, e, st); }
         ao = empty2(rows, C, x); lse = emptyf({rows / 49, nH, 49}, x);
         { MvltAttn p{}; p.dtype = dtype; p.mode = MVLT_ATTN_SWIN; p.nseq = B * nW; p.L = 49; p.nH = nH; p.hd = C / nH;
           p.qkv = dp(qkv); p.out = dp(ao); p.lse = fp(lse); p.scale = (float)scale;
@@ -347,17 +356,17 @@ std::vector<Tensor> swin_block_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f
           ck(mvlt_attn_fwd(&p, st), "mvlt_attn_fwd"); }
         { Epi e; e.bias = P<float>(f[3]); e.residual = dp(x); e.ldr = C; e.rowmap = P<const int32_t>(maps[0]);
           if (s1) { e.rowscale = P<float>(s1); e.rps = Lt; }
-          linear(ao, w[1], C, x1, e, st); }
+          e.pf = P(w[2]); e.pf_bytes = (int64_t)4 * C * C * esz; linear(ao, w[1], C, x1, e, st); }
     }
     Tensor xn2 = empty2(rows, C, x), stat2;
     float *m2 = nullptr, *r2 = nullptr;
     if (save) { stat2 = emptyf({2, rows}, x); m2 = fp(stat2); r2 = m2 + rows; }
     ln_fwd(x1, (int)rows, C, f[5], f[6], (float)eps, xn2, m2, r2, nullptr, st);
     Tensor h = empty2(rows, 4 * C, x), act = empty2(rows, 4 * C, x);
-    { Epi e; e.bias = P<float>(f[7]); e.gelu = true; e.pre = dp(h); linear(xn2, w[2], 4 * C, act, e, st); }
+    { Epi e; e.bias = P<float>(f[7]); e.gelu = true; e.pre = dp(h); e.pf = P(w[3]); e.pf_bytes = (int64_t)4 * C * C * esz; linear(xn2, w[2], 4 * C, act, e, st); }
     Tensor x2 = empty2(rows, C, x);
     { Epi e; e.bias = P<float>(f[8]); e.residual = dp(x1); e.ldr = C; if (s2) { e.rowscale = P<float>(s2); e.rps = Lt; }
-      linear(act, w[3], C, x2, e, st); }
+      if (nb) { e.pf = P(w[4]); e.pf_bytes = w[5]; } linear(act, w[3], C, x2, e, st); }
     if (!save) return {x2};
     return {x2, x, stat1, xn1w, qkv, ao, lse, x1, stat2, xn2, h, act};
 }
@@ -381,14 +390,16 @@ Tensor swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>& sv, const Pt
         ck(mvlt_rows_transform(dtype, dp(dx2), dp(dy2), (int)rows, C, nullptr, P<float>(s2), Lt, 0.f, 0, 0, st), "mvlt_rows_transform");
     }
     Tensor dh = empty2(rows, 4 * C, x);
-    { Epi e; e.aux = dp(h); dgrad(dy2, w[3], 4 * C, dh, e, st); }
+    const int64_t esz = x.element_size();
+    const bool nb = w.size() >= 8;
+    { Epi e; e.aux = dp(h); e.pf = P(w[2]); e.pf_bytes = (int64_t)4 * C * C * esz; dgrad(dy2, w[3], 4 * C, dh, e, st); }
     Tensor dxn2 = empty2(rows, C, x);
-    { Epi e; dgrad(dh, w[2], C, dxn2, e, st); }
+    { Epi e; e.pf = P(w[1]); e.pf_bytes = (int64_t)C * C * esz; dgrad(dh, w[2], C, dxn2, e, st); }
     Tensor dx1 = empty2(rows, C, x), dyw = empty2(rows, C, x);
     { LnBranch br; br.dz = dp(dyw); br.rowmap = n2w; if (s1) { br.rowscale = P<float>(s1); br.rps = Lt; }
       ln_bwd(dxn2, nullptr, x1, fp(stat2), fp(stat2) + rows, (int)rows, C, f[5], g[7], g[8], dp(dx2), dx1, br, st); }
     Tensor dao = empty2(rows, C, x);
-    { Epi e; dgrad(dyw, w[1], C, dao, e, st); }
+    { Epi e; e.pf = P(w[0]); e.pf_bytes = (int64_t)3 * C * C * esz; dgrad(dyw, w[1], C, dao, e, st); }
     Tensor dqkv = empty2(rows, 3 * C, x);
     { MvltAttn p{}; p.dtype = dtype; p.mode = MVLT_ATTN_SWIN; p.nseq = B * nW; p.L = 49; p.nH = nH; p.hd = C / nH;
       p.qkv = dp(qkv); p.out = dp(ao); p.lse = fp(lse); p.scale = (float)scale;
@@ -396,7 +407,7 @@ Tensor swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>& sv, const Pt
       p.dout = dp(dao); p.dqkv = dp(dqkv); p.dbias_table = P<float>(g[6]);
       ck(mvlt_attn_bwd(&p, st), "mvlt_attn_bwd"); }
     Tensor dxn1w = empty2(rows, C, x);
-    { Epi e; dgrad(dqkv, w[0], C, dxn1w, e, st); }
+    { Epi e; if (nb) { e.pf = P(w[6]); e.pf_bytes = w[7]; } dgrad(dqkv, w[0], C, dxn1w, e, st); }
     Tensor dx0 = empty2(rows, C, x);
     { LnBranch br; ln_bwd(dxn1w, n2w, x, fp(stat1), fp(stat1) + rows, (int)rows, C, f[0], g[0], g[1], dp(dx1), dx0, br, st); }
     fork_side(ss);

@@ -901,6 +901,36 @@ extern "C" int mvlt_mlm_mask(const MvltMlmMask* p, void* stream) {
     return MVLT_OK;
 }
 
+namespace {
+struct PrefetchBatch { int n; MvltRange r[8]; };
+__global__ __launch_bounds__(256) void prefetch_kernel(const PrefetchBatch b, unsigned* never) {
+    unsigned acc = 0;
+    for (int i = 0; i < b.n; ++i) {
+        const char* base = reinterpret_cast<const char*>(b.r[i].ptr);
+        const long lines = (b.r[i].bytes + 127) >> 7;
+        for (long l = (long)blockIdx.x * 256 + threadIdx.x; l < lines; l += (long)gridDim.x * 256) {
+            const long off = l << 7;
+            acc ^= *reinterpret_cast<const unsigned*>(base + (off + 4 <= b.r[i].bytes ? off : (b.r[i].bytes - 4) & ~3L));
+        }
+    }
+    if (acc == 0x9e3779b9u && never) *never = acc;          // keeps the loads alive; `never` is a null pointer
+}
+}  // namespace
+
+extern "C" int mvlt_prefetch(const MvltRange* items, int n, void* stream) {
+    MVLT_CHECK(items && n >= 1 && n <= 8, MVLT_ERR_ARG);
+    PrefetchBatch b{};
+    b.n = n;
+    long lines = 0;
+    for (int i = 0; i < n; ++i) { MVLT_CHECK(items[i].ptr && items[i].bytes >= 4, MVLT_ERR_ARG); b.r[i] = items[i]; lines += (items[i].bytes + 127) >> 7; }
+    long blocks = (lines + 511) / 512;
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(prefetch_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM(stream), b, (unsigned*)nullptr);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
 extern "C" int mvlt_zero_batch(const MvltZeroItem* items, int n, void* stream) {
     MVLT_CHECK(items && n >= 0, MVLT_ERR_ARG);
     for (int i0 = 0; i0 < n; i0 += 32) {

@@ -190,7 +190,7 @@ def _ld(t):
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=None, gelu=False,
          save_pre=None, dropout=None, rowscale=None, residual=None, rowmap=None, mul_gelu_grad=None,
-         accumulate=False, split_k=0, ldc=None, a_colsum=None, m_dev=None):
+         accumulate=False, split_k=0, ldc=None, a_colsum=None, m_dev=None, prefetch=None):
     """C = epilogue(A @ B); see MvltGemm.  A: [M,K] (or [K,M] if a_kmajor);
     B: [N,K] torch-Linear layout (or [K,N] if b_kmajor).
     (Written for a short host path: ~330 calls per training step; pointers go into the struct as plain ints.)"""
@@ -261,6 +261,8 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_f32=False, bias=
     p.split_k = split_k
     if m_dev is not None:          # valid storage rows of A on the device (ragged batch planned on the GPU)
         p.m_dev = m_dev.data_ptr()
+    if prefetch is not None:             # weights of the product that runs next: pulled towards the caches by this launch
+        p.prefetch, p.prefetch_bytes = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     if a_colsum is not None:
         assert a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M
         p.a_colsum = a_colsum.data_ptr()
@@ -381,6 +383,15 @@ def wgrad_group(items):
     L.check(lib.mvlt_gemm_group(arr, n, _stream()), "mvlt_gemm_group")
     if evs is not None:
         evs[1].record(st)
+
+
+def prefetch(tensors):
+    """Pull up to 8 read-only tensors (weights about to be used) towards the GPU's caches: one launch, nothing written."""
+    arr = (L.MvltRange * len(tensors))()
+    for i, t in enumerate(tensors):
+        assert t.is_cuda and t.is_contiguous()
+        arr[i].ptr, arr[i].bytes = t.data_ptr(), t.numel() * t.element_size()
+    L.check(L.lib().mvlt_prefetch(arr, len(tensors), _stream()), "mvlt_prefetch")
 
 
 def zero_batch(tensors):

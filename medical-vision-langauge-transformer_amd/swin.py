@@ -363,6 +363,13 @@ class SwinTransformer(nn.Module):
             c, g = ar.compute, ar.grad_view
             dd = lambda p: p.data.data_ptr()
             w = [c(at.qkv.weight).data_ptr(), c(at.proj.weight).data_ptr(), c(mlp.fc1.weight).data_ptr(), c(mlp.fc2.weight).data_ptr()]
+            # (ptr, bytes) of the next block's qkv and the previous block's fc2 weights (MvltGemm.prefetch, see bert.py)
+            blocks = [b for _, b in self._blocks()]
+            i = next(k for k, b in enumerate(blocks) if b is blk)
+            nxt = c(blocks[i + 1].attn.qkv.weight) if i + 1 < len(blocks) else None
+            prv = c(blocks[i - 1].mlp.fc2.weight) if i > 0 else None
+            for t in (nxt, prv):
+                w += [t.data_ptr(), t.numel() * t.element_size()] if t is not None else [0, 0]
             f = [dd(blk.norm1.weight), dd(blk.norm1.bias), dd(at.qkv.bias), dd(at.proj.bias), dd(at.relative_position_bias_table),
                  dd(blk.norm2.weight), dd(blk.norm2.bias), dd(mlp.fc1.bias), dd(mlp.fc2.bias)]
             gr = [g(p).data_ptr() for p in (blk.norm1.weight, blk.norm1.bias, at.qkv.weight, at.qkv.bias, at.proj.weight,

@@ -135,6 +135,25 @@ def test_wgrad_group(ops, dt, widths, R):
             assert rel(db, rb) < tol(dt)
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_weight_prefetch_is_side_effect_free(ops, dt):
+    """MvltGemm.prefetch / mvlt_prefetch only read: the product is bit-identical with and without, for byte ranges
+    that are not multiples of a line, for every kernel family (register-staged, LDS-DMA, k-major B, ragged rows)."""
+    A, W = rnd((4100, 768), dt, 1, 0.1), rnd((768, 768), dt, 2, 0.1)
+    nxt = rnd((3072 * 768 + 37,), dt, 3, 0.1)
+    m_dev = torch.tensor([3001], dtype=torch.int32, device="cuda")
+    for kw in (dict(), dict(b_kmajor=True), dict(m_dev=m_dev)):
+        ref = ops.gemm(A, W, out=torch.zeros(4100, 768, dtype=dt, device="cuda"), **kw)
+        got = ops.gemm(A, W, out=torch.zeros(4100, 768, dtype=dt, device="cuda"), prefetch=nxt, **kw)
+        assert torch.equal(ref, got)
+    W2 = rnd((3072, 768), dt, 4, 0.1)
+    assert torch.equal(ops.gemm(A, W2), ops.gemm(A, W2, prefetch=nxt[:100]))     # shorter than a line: ignored
+    before = nxt.clone()
+    ops.prefetch([nxt, W, W2, nxt[5:1000]])
+    torch.cuda.synchronize()
+    assert torch.equal(before, nxt)
+
+
 @pytest.mark.parametrize("R,used", [(1573, 1000), (9001, 8300)])
 def test_wgrad_group_device_row_count(ops, R, used):
     """The reduction length of a grouped launch can live on the device (ragged batches): rows at or beyond it are
