@@ -81,3 +81,14 @@ def rel_err(a, b):
     a = a.double()
     b = b.double()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_test_data():
+    """Every test starts from the same RNG state: tolerances on f32 summation-order differences and bf16 rounding were
+    set on specific data, and a few tests draw operands without a generator of their own."""
+    import random as _random
+    import torch as _torch
+    _random.seed(20240507)
+    _torch.manual_seed(20240507)
+    yield

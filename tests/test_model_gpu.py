@@ -732,7 +732,7 @@ def test_device_planned_packing_is_the_default_and_equals_the_dense_run(M, specs
     model = M.set_compute_dtype(model.cuda().eval(), F32)
     image, ids, labels, itm = synth_batch(6, 24, seed=47, vocab=3000)
     ids[0] = 0; labels[0] = -100                                   # empty caption
-    ids[1] = torch.randint(1000, 3000, (24,)); ids[1, -1] = 104      # full length
+    ids[1] = torch.randint(1000, 3000, (24,), generator=torch.Generator().manual_seed(48)); ids[1, -1] = 104      # full length (seeded: the f32 summation-order differences checked below depend on the data)
     ids[2, 2] = 0                                                  # a zero id inside the caption
     n3 = int((ids[3] != 0).sum())
     assert n3 < 22
