@@ -218,6 +218,10 @@ class Arena:
         every view each step and the marked set changes with the seq2seq/bidir coin flip, so EVERY marked
         parameter whose ``grad`` is None gets its (cached) view back -- not only the ones whose status changed."""
         self._merge_stashed_grads()
+        if self.grad.is_cuda:
+            from . import ops
+            if ops._side_keepalive:                  # weight gradients still queued on the side stream (a head's, when
+                ops.join_side(self.grad.device)      # no backbone pass behind it has joined already)
         cur = frozenset(id(p) for p in self._marked)
         prev = self._published or frozenset()
         gv = self.__dict__.get("_pgrad_views")
