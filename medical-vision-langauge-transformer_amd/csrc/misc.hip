@@ -59,14 +59,17 @@ __global__ __launch_bounds__(256) void pack_plan_kernel(const int64_t* text, con
                                                         int64_t* text_row) {
     // caption length = 1 + last position with a non-zero id or a label: all B*T positions are looked at independently
     // (a backwards scan per sample is a chain of dependent global loads: 25 us for T = 80) and meet in seq_len by atomicMax
-    for (int b = threadIdx.x; b < B; b += 256) seq_len[b] = 0;
+    __shared__ int slen[1024];
+    const bool in_lds = B <= 1024;                  // (LDS atomics: a global atomicMax per position serialises per sample)
+    int* lens = in_lds ? slen : seq_len;
+    for (int b = threadIdx.x; b < B; b += 256) lens[b] = 0;
     __syncthreads();
     for (long i = threadIdx.x; i < (long)B * T; i += 256) {
         const int b = (int)(i / T), t = (int)(i - (long)b * T);
-        if (text[i] != 0 || (labels && labels[i] >= 0)) atomicMax(&seq_len[b], t + 1);
+        if (text[i] != 0 || (labels && labels[i] >= 0)) atomicMax(&lens[b], t + 1);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < B; b += 256) seq_len[b] += n_img + 2;
+    for (int b = threadIdx.x; b < B; b += 256) seq_len[b] = lens[b] + n_img + 2;
     __syncthreads();
     if (threadIdx.x == 0) {
         int acc = 0;
