@@ -32,9 +32,17 @@ extern "C" {
 enum { MVLT_F32 = 0, MVLT_BF16 = 1 };
 enum { MVLT_OK = 0, MVLT_ERR_ARG = -1, MVLT_ERR_LAUNCH = -2, MVLT_ERR_UNSUPPORTED = -3 };
 
-/* loader checks */
-int mvlt_version(void);            /* ABI version, currently 1 */
+/* loader checks.  MVLT_ABI_VERSION is bumped on EVERY change of a struct layout or of an entry point's
+ * signature; a binding compiles / hard-codes the value it was written against and compares it with what the
+ * loaded library returns.  mvlt_sizeof(MVLT_STRUCT_*) lets a binding that mirrors the structs by hand (ctypes,
+ * cgo, JNI) prove that its mirror has the size the library was compiled with (0 for an unknown id). */
+#define MVLT_ABI_VERSION 2
+int mvlt_version(void);            /* MVLT_ABI_VERSION of the loaded library */
 const char* mvlt_arch(void);       /* "gfx950" */
+enum { MVLT_STRUCT_GEMM = 0, MVLT_STRUCT_LAYERNORM = 1, MVLT_STRUCT_LAYERNORM_BWD = 2, MVLT_STRUCT_LN_REDUCE_ITEM = 3,
+       MVLT_STRUCT_ATTN = 4, MVLT_STRUCT_SWIN_WMSA = 5, MVLT_STRUCT_EMBED = 6, MVLT_STRUCT_ATTN_CACHED = 7,
+       MVLT_STRUCT_ZERO_ITEM = 8, MVLT_STRUCT_RANGE = 9, MVLT_STRUCT_MLM_MASK = 10, MVLT_STRUCT_COUNT = 11 };
+size_t mvlt_sizeof(int struct_id);
 
 /* ------------------------------------------------------------------ GEMM
  * C[M,N] = epilogue(A[M,K] * B[K,N]).  Replaces every nn.Linear on the path:

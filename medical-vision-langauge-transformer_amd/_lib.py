@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmvlt_hip.so")
 
 F32, BF16 = 0, 1
 OK = 0
+ABI_VERSION = 2          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
 ERRORS = {-1: "MVLT_ERR_ARG", -2: "MVLT_ERR_LAUNCH", -3: "MVLT_ERR_UNSUPPORTED"}
 
 EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_DROPOUT = 1, 2, 4, 8
@@ -112,6 +113,7 @@ class MvltMlmMask(C.Structure):
 SYMBOLS = {
     "mvlt_version": (i32, []),
     "mvlt_arch": (C.c_char_p, []),
+    "mvlt_sizeof": (sz, [i32]),
     "mvlt_gemm": (i32, [C.POINTER(MvltGemm), vp]),
     "mvlt_gemm_workspace_bytes": (sz, [C.POINTER(MvltGemm)]),
     "mvlt_gemm_plan": (i32, [C.POINTER(MvltGemm), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
@@ -160,6 +162,10 @@ SYMBOLS = {
     "mvlt_mlm_mask": (i32, [C.POINTER(MvltMlmMask), vp]),
 }
 
+# ctypes mirror of every struct, in the order of the MVLT_STRUCT_* ids of the header
+STRUCTS = [MvltGemm, MvltLayerNorm, MvltLayerNormBwd, MvltLnReduceItem, MvltAttn, MvltSwinWmsa, MvltEmbed,
+           MvltAttnCached, MvltZeroItem, MvltRange, MvltMlmMask]
+
 _lib = None
 
 
@@ -175,8 +181,13 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if L.mvlt_version() != 1 or L.mvlt_arch() != b"gfx950":
-            raise RuntimeError("libmvlt_hip.so ABI/arch mismatch")
+        if L.mvlt_version() != ABI_VERSION or L.mvlt_arch() != b"gfx950":
+            raise RuntimeError(f"libmvlt_hip.so reports ABI {L.mvlt_version()} / arch {L.mvlt_arch()!r}; this binding "
+                               f"was written for ABI {ABI_VERSION} / gfx950: rebuild (make -C .../csrc)")
+        for sid, st in enumerate(STRUCTS):
+            if L.mvlt_sizeof(sid) != C.sizeof(st):
+                raise RuntimeError(f"{st.__name__}: the library was compiled with {L.mvlt_sizeof(sid)} bytes, the "
+                                   f"ctypes mirror has {C.sizeof(st)}: stale libmvlt_hip.so or stale _lib.py")
         _lib = L
     return _lib
 

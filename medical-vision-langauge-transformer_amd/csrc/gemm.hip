@@ -11,112 +11,16 @@
 // The MFMA is issued as (B-fragment, A-fragment) so each lane owns 4
 // consecutive n of one output row -> 8/16-byte epilogue loads and stores.
 #include "common.h"
+#include "gemm_dev.h"
 #include <cstdio>
 #include <cstdlib>
 
+// gemm8.hip: 8-wave ping-pong kernel; takes the filled kernel argument block, returns 1 if it launched
+extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* dev_blocks, int n, int a_kmajor, int b_kmajor, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_colsum(const void* dev_blocks, float* const* outs, int n, void* stream);
+static int g8_mode() { const char* e = getenv("MVLT_G8"); return e ? atoi(e) : 0; }
+
 namespace {
-
-struct GemmDev {
-    int M, N, K;
-    const void* A; long lda; const void* B; long ldb;
-    void* C; long ldc;
-    int epi;
-    const float* bias; void* pre; const void* residual; long ldr; const void* aux;
-    const float* rowscale; int rps; const int* rowmap;
-    uint32_t drop_thresh; float drop_scale; uint64_t seed; uint32_t tag;
-    int split_k; int k_per_split; float* ws;
-    int a_vec, b_vec, epi_vec;
-    float* a_colsum; float* ws_colsum;   // optional: column sums of a k-major A (bias gradient), fused
-    const char* pf; long pf_lines;       // optional: 128-byte lines of the next product's weights to pull towards the caches
-    const int* m_dev;                    // optional: valid storage rows of A on the device (MvltGemm.m_dev)
-    int atomic_out;                      // grouped weight gradients with in-launch split-K: f32 atomicAdd onto zeroed C
-};
-
-// Ragged batches planned on the GPU: the launch is sized for the upper bound, the kernel reads the real count.
-// k-contiguous A: M shrinks (tiles beyond it leave at once); k-major A (weight gradients): the reduction shrinks.
-template <bool AK>
-MVLT_DEV GemmDev effective(const GemmDev& p) {
-    GemmDev q = p;
-    if (p.m_dev) {
-        const int r = __builtin_amdgcn_readfirstlane(*p.m_dev);
-        if (AK) q.K = min(q.K, max(r, 0)); else q.M = min(q.M, max(r, 0));
-    }
-    return q;
-}
-
-template <typename T>
-MVLT_DEV typename TypeInfo<T>::Vec load_chunk(const T* base, long ld, int outer, int inner,
-                                              int outer_lim, int inner_lim, bool vec_ok) {
-    using Vec = typename TypeInfo<T>::Vec;
-    constexpr int E = TypeInfo<T>::E;
-    Vec v = zero_vec<T>();
-    if (outer >= outer_lim || inner >= inner_lim) return v;
-    const T* p = base + (long)outer * ld + inner;
-    if (vec_ok && inner + E <= inner_lim) return *reinterpret_cast<const Vec*>(p);
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (inner + e < inner_lim) v[e] = p[e];
-    return v;
-}
-
-template <typename T>
-MVLT_DEV void epilogue4(const GemmDev& p, int m, int n, f32x4 v) {
-    if (m >= p.M || n >= p.N) return;
-    const int epi = p.epi;
-    const int mo = (epi & MVLT_EPI_ROWMAP) ? p.rowmap[m] : m;
-    const int nv = min(4, p.N - n);
-    const bool vec = p.epi_vec && nv == 4;
-    T* Ct = reinterpret_cast<T*>(p.C);
-    float* Cf = reinterpret_cast<float*>(p.C);
-    const long co = (long)mo * p.ldc + n;
-    if (epi & MVLT_EPI_BIAS) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (j < nv) v[j] += p.bias[n + j];
-    }
-    if (epi & MVLT_EPI_GELU) {
-        if (epi & MVLT_EPI_SAVE_PRE) {
-            T* pre = reinterpret_cast<T*>(p.pre) + co;
-            if (vec) store4f(pre, v);
-            else for (int j = 0; j < nv; ++j) pre[j] = from_f<T>(v[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
-    }
-    if (epi & MVLT_EPI_DROPOUT) {
-        const uint32_t base = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            v[j] = rng_keep(p.seed, p.tag, base + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.0f;
-    }
-    if (epi & MVLT_EPI_ROWSCALE) {
-        const float s = p.rowscale[mo / p.rps];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= s;
-    }
-    if (epi & MVLT_EPI_MUL_GELU_GRAD) {
-        const T* aux = reinterpret_cast<const T*>(p.aux) + co;
-        if (vec) { f32x4 a = load4f(aux);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_f(a[j]);
-        } else for (int j = 0; j < nv; ++j) v[j] *= gelu_grad_f(to_f(aux[j]));
-    }
-    if (epi & MVLT_EPI_RESIDUAL) {
-        const T* r = reinterpret_cast<const T*>(p.residual) + (long)mo * p.ldr + n;
-        if (vec) { f32x4 a = load4f(r);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += a[j];
-        } else for (int j = 0; j < nv; ++j) v[j] += to_f(r[j]);
-    }
-    if (epi & MVLT_EPI_OUT_F32) {
-        if (epi & MVLT_EPI_ACCUM) for (int j = 0; j < nv; ++j) v[j] += Cf[co + j];
-        if (vec) store4f(Cf + co, v);
-        else for (int j = 0; j < nv; ++j) Cf[co + j] = v[j];
-    } else {
-        if (epi & MVLT_EPI_ACCUM) for (int j = 0; j < nv; ++j) v[j] += to_f(Ct[co + j]);
-        if (vec) store4f(Ct + co, v);
-        else for (int j = 0; j < nv; ++j) Ct[co + j] = from_f<T>(v[j]);
-    }
-}
 
 // k-major bf16 tiles of 64 / 96 / 128 rows are stored (96: in 128-wide rows) with their 32-byte column chunks XOR-swizzled by a function
 // of k: a ds_read_b64_tr_b16 group of 32 lanes reads 8 k-rows {k0..k0+3, k0+8..k0+11} x 32 bytes, which padding alone
@@ -219,26 +123,6 @@ MVLT_DEV typename Mma<T>::Frag tile_frag(const T* lds, int row0, int kb) {
     const int ch = (kb * 4 + (l >> 4)) ^ (row & 7);
     return *reinterpret_cast<const typename Mma<T>::Frag*>(lds + row * G::BKE + ch * G::E);
     }
-}
-
-// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
-// L2), so give every XCD one contiguous chunk of the tile list -> neighbouring tiles (same
-// A rows / B columns) hit the same L2.  Bijective for any count; speed only.
-MVLT_DEV int xcd_remap(int orig, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-}
-
-// MvltGemm.prefetch: every thread of the launch reads one dword of a few 128-byte lines of a byte range that a LATER kernel
-// will stream (the next nn.Linear's weights, evicted by the optimizer's sweep since their last use); the value is dropped.
-MVLT_DEV unsigned prefetch_lines(const GemmDev& p) {
-    unsigned acc = 0;
-    if (p.pf) {
-        const long nthr = (long)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
-        const long g = ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-        for (long l = g; l < p.pf_lines; l += nthr) acc ^= *reinterpret_cast<const unsigned*>(p.pf + (l << 7));
-    }
-    return acc;
 }
 
 // one output tile (bx, by) of one k-split bz
@@ -420,6 +304,10 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
     }
 
     // acc[i][j][r] <-> n = nb + 4*(lane>>4) + r, m = mb + (lane & 15)
+    if (!p.atomic_out && p.split_k <= 1 && p.epi_vec && (p.N & 3) == 0) {
+        tile_epilogue<T, FM, FN>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);          // loads hoisted out of the store sequence
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
@@ -531,6 +419,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
                 for (int j = 0; j < FN; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
         }
     }
+    if (p.split_k <= 1 && p.epi_vec && (p.N & 3) == 0) {
+        tile_epilogue<T, FM, FN>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);          // loads hoisted out of the store sequence
+    } else {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
@@ -547,6 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
                 epilogue4<T>(p, m, n, acc[i][j]);
             }
         }
+    }
     }
     asm volatile("" :: "v"(pfv));
 }
@@ -1034,6 +926,15 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     dim3 grid(ceil_div(p->N, pl.bn), ceil_div(p->M, pl.bm), d.split_k);
     const bool ak = p->a_kmajor != 0, bk = p->b_kmajor != 0;
     if constexpr (sizeof(T) == 2) {
+        // 8-wave ping-pong engine (gemm8.hip) for wide outputs: MVLT_G8 = 0 never / 1 wherever it is eligible
+        if (g8_mode() && !ak && d.split_k <= 1) {
+            const int rc8 = mvlt_gemm8_try(&d, 1, 0, bk ? 1 : 0, s);
+            if (rc8 < 0) return MVLT_ERR_LAUNCH;
+            if (rc8 > 0) {
+                if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
+                return MVLT_OK;
+            }
+        }
         // MVLT_GLDS: 0 = never, 1 = every tile, 2 (default) = 64-row tiles only.  Standalone the LDS-DMA loop is 5-12 %
         // faster on 128x128 tiles and 18-24 % on 64x64; inside the training step the 128x128 form (64 KB of LDS, two
         // workgroups per CU) is SLOWER than the register-staged one (three per CU, shares the CU better with the
@@ -1125,6 +1026,23 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
         MVLT_CHECK(p->a_kmajor && p->b_kmajor && p->dtype == items[0].dtype, MVLT_ERR_UNSUPPORTED);
         Plan pl{64, bn, 1};
         { const int rc = fill_dev<T>(p, pl, g.g[i]); if (rc != MVLT_OK) return rc; }
+    }
+    // 8-wave ping-pong engine: the whole group as one persistent launch of 128/256 x 256 tiles, bias gradients beside it
+    if constexpr (sizeof(T) == 2) {
+        if (g8_mode()) {
+            GemmDev tmp[GROUP_MAX];
+            float* outs[GROUP_MAX];
+            bool ok = true;
+            for (int i = 0; i < n; ++i) {
+                tmp[i] = g.g[i]; outs[i] = tmp[i].a_colsum; tmp[i].a_colsum = nullptr;
+                ok = ok && tmp[i].epi == MVLT_EPI_OUT_F32 && tmp[i].M % 4 == 0 && tmp[i].lda % 4 == 0;
+            }
+            if (ok) {
+                const int rc8 = mvlt_gemm8_try(tmp, n, 1, 1, s);
+                if (rc8 < 0) return MVLT_ERR_LAUNCH;
+                if (rc8 > 0) return mvlt_gemm8_colsum(tmp, outs, n, s) > 0 ? MVLT_OK : MVLT_ERR_LAUNCH;
+            }
+        }
     }
     // 128-row tiles when they still give every CU a workgroup (half the LDS fragment traffic per MFMA)
     int bm = 64;

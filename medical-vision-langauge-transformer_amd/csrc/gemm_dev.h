@@ -1,0 +1,245 @@
+// Device-side pieces shared by the GEMM translation units (gemm.hip, gemm8.hip): the kernel argument block, the
+// fused epilogue (order documented in include/mvlt_hip.h, MvltGemm), the XCD-aware tile order and the weight prefetch.
+#pragma once
+#include "common.h"
+
+namespace {
+
+struct GemmDev {
+    int M, N, K;
+    const void* A; long lda; const void* B; long ldb;
+    void* C; long ldc;
+    int epi;
+    const float* bias; void* pre; const void* residual; long ldr; const void* aux;
+    const float* rowscale; int rps; const int* rowmap;
+    uint32_t drop_thresh; float drop_scale; uint64_t seed; uint32_t tag;
+    int split_k; int k_per_split; float* ws;
+    int a_vec, b_vec, epi_vec;
+    float* a_colsum; float* ws_colsum;   // optional: column sums of a k-major A (bias gradient), fused
+    const char* pf; long pf_lines;       // optional: 128-byte lines of the next product's weights to pull towards the caches
+    const int* m_dev;                    // optional: valid storage rows of A on the device (MvltGemm.m_dev)
+    int atomic_out;                      // grouped weight gradients with in-launch split-K: f32 atomicAdd onto zeroed C
+};
+
+// Ragged batches planned on the GPU: the launch is sized for the upper bound, the kernel reads the real count.
+// k-contiguous A: M shrinks (tiles beyond it leave at once); k-major A (weight gradients): the reduction shrinks.
+template <bool AK>
+MVLT_DEV GemmDev effective(const GemmDev& p) {
+    GemmDev q = p;
+    if (p.m_dev) {
+        const int r = __builtin_amdgcn_readfirstlane(*p.m_dev);
+        if (AK) q.K = min(q.K, max(r, 0)); else q.M = min(q.M, max(r, 0));
+    }
+    return q;
+}
+
+template <typename T>
+MVLT_DEV typename TypeInfo<T>::Vec load_chunk(const T* base, long ld, int outer, int inner,
+                                              int outer_lim, int inner_lim, bool vec_ok) {
+    using Vec = typename TypeInfo<T>::Vec;
+    constexpr int E = TypeInfo<T>::E;
+    Vec v = zero_vec<T>();
+    if (outer >= outer_lim || inner >= inner_lim) return v;
+    const T* p = base + (long)outer * ld + inner;
+    if (vec_ok && inner + E <= inner_lim) return *reinterpret_cast<const Vec*>(p);
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (inner + e < inner_lim) v[e] = p[e];
+    return v;
+}
+
+template <typename T>
+MVLT_DEV void epilogue4(const GemmDev& p, int m, int n, f32x4 v) {
+    if (m >= p.M || n >= p.N) return;
+    const int epi = p.epi;
+    const int mo = (epi & MVLT_EPI_ROWMAP) ? p.rowmap[m] : m;
+    const int nv = min(4, p.N - n);
+    const bool vec = p.epi_vec && nv == 4;
+    T* Ct = reinterpret_cast<T*>(p.C);
+    float* Cf = reinterpret_cast<float*>(p.C);
+    const long co = (long)mo * p.ldc + n;
+    if (epi & MVLT_EPI_BIAS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < nv) v[j] += p.bias[n + j];
+    }
+    if (epi & MVLT_EPI_GELU) {
+        if (epi & MVLT_EPI_SAVE_PRE) {
+            T* pre = reinterpret_cast<T*>(p.pre) + co;
+            if (vec) store4f(pre, v);
+            else for (int j = 0; j < nv; ++j) pre[j] = from_f<T>(v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
+    }
+    if (epi & MVLT_EPI_DROPOUT) {
+        const uint32_t base = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = rng_keep(p.seed, p.tag, base + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.0f;
+    }
+    if (epi & MVLT_EPI_ROWSCALE) {
+        const float s = p.rowscale[mo / p.rps];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= s;
+    }
+    if (epi & MVLT_EPI_MUL_GELU_GRAD) {
+        const T* aux = reinterpret_cast<const T*>(p.aux) + co;
+        if (vec) { f32x4 a = load4f(aux);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_f(a[j]);
+        } else for (int j = 0; j < nv; ++j) v[j] *= gelu_grad_f(to_f(aux[j]));
+    }
+    if (epi & MVLT_EPI_RESIDUAL) {
+        const T* r = reinterpret_cast<const T*>(p.residual) + (long)mo * p.ldr + n;
+        if (vec) { f32x4 a = load4f(r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += a[j];
+        } else for (int j = 0; j < nv; ++j) v[j] += to_f(r[j]);
+    }
+    if (epi & MVLT_EPI_OUT_F32) {
+        if (epi & MVLT_EPI_ACCUM) for (int j = 0; j < nv; ++j) v[j] += Cf[co + j];
+        if (vec) store4f(Cf + co, v);
+        else for (int j = 0; j < nv; ++j) Cf[co + j] = v[j];
+    } else {
+        if (epi & MVLT_EPI_ACCUM) for (int j = 0; j < nv; ++j) v[j] += to_f(Ct[co + j]);
+        if (vec) store4f(Ct + co, v);
+        else for (int j = 0; j < nv; ++j) Ct[co + j] = from_f<T>(v[j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue of a whole wave tile (FM x FN fragments of 16 x 16; a lane owns 4 consecutive columns of one row per fragment),
+// same arithmetic and order as epilogue4, but with every LOAD hoisted out of the store sequence.
+// Why: vmcnt completes IN ORDER, loads and stores alike.  epilogue4 called fragment by fragment loads bias / residual /
+// aux behind the previous fragment's stores, inside divergent (bounds-checked) blocks, where hipcc waits vmcnt(0): every
+// fragment then waits for the previous fragment's stores to COMPLETE (~0.7 us under load): +12 us for a bias, +21 us
+// for bias + GELU + saved pre-activation on the BERT FFN-in product (gpurun_out g8_check, round 3).  Here the bias values
+// are loaded once per tile and the per-row / per-fragment operands one row block ahead, all from clamped (always valid)
+// addresses in straight-line code; only the stores are predicated.
+// Requires p.epi_vec and N % 4 == 0 (the callers fall back to epilogue4 otherwise); ACCUM keeps its in-place load.
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16_t> { using type = bf16x4; };
+template <> struct Raw4<float> { using type = f32x4; };
+MVLT_DEV f32x4 raw4_to_f(const bf16x4& v) { f32x4 r; r[0] = (float)v[0]; r[1] = (float)v[1]; r[2] = (float)v[2]; r[3] = (float)v[3]; return r; }
+MVLT_DEV f32x4 raw4_to_f(const f32x4& v) { return v; }
+
+template <typename T, int FM, int FN>
+MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base, f32x4 (&acc)[FM][FN]) {
+    using R4 = typename Raw4<T>::type;
+    const int lane = threadIdx.x & 63;
+    const int mr = lane & 15, nq = 4 * (lane >> 4);
+    const int epi = p.epi;
+    const bool has_bias = (epi & MVLT_EPI_BIAS) != 0, has_res = (epi & MVLT_EPI_RESIDUAL) != 0,
+               has_aux = (epi & MVLT_EPI_MUL_GELU_GRAD) != 0, has_map = (epi & MVLT_EPI_ROWMAP) != 0,
+               has_scale = (epi & MVLT_EPI_ROWSCALE) != 0;
+    f32x4 bias_v[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bias_v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_bias) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bias_v[j] = *reinterpret_cast<const f32x4*>(p.bias + min(n_base + j * 16 + nq, p.N - 4));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(bias_v[j]));          // waited for here, once (see above)
+    }
+    struct RowPre { int mo; float sc; R4 res[FN]; R4 aux[FN]; };
+    auto preload = [&](int i, RowPre& r) {
+        const int m = min(m_base + i * 16 + mr, p.M - 1);
+        r.mo = m; r.sc = 1.0f;
+        if (has_map) r.mo = p.rowmap[m];
+        if (has_scale) r.sc = p.rowscale[r.mo / p.rps];
+        if (has_res) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                r.res[j] = *reinterpret_cast<const R4*>(reinterpret_cast<const T*>(p.residual) + (long)r.mo * p.ldr + min(n_base + j * 16 + nq, p.N - 4));
+        }
+        if (has_aux) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                r.aux[j] = *reinterpret_cast<const R4*>(reinterpret_cast<const T*>(p.aux) + (long)r.mo * p.ldc + min(n_base + j * 16 + nq, p.N - 4));
+        }
+    };
+    auto pin = [&](RowPre& r) {
+        if (has_res) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(r.res[j]));
+        }
+        if (has_aux) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(r.aux[j]));
+        }
+        if (has_scale) asm volatile("" : "+v"(r.sc));
+        if (has_map) asm volatile("" : "+v"(r.mo));
+    };
+    const bool rowloads = has_res || has_aux || has_map || has_scale;
+    RowPre cur, nxt;
+    if (rowloads) preload(0, nxt);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m_base + i * 16 + mr;
+        if (rowloads) {
+            cur = nxt;
+            if (i + 1 < FM) preload(i + 1, nxt);          // next row block's loads go out before this one's stores
+            pin(cur);
+        } else { cur.mo = m; cur.sc = 1.0f; }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n_base + j * 16 + nq;
+            const bool live = m < p.M && n < p.N;
+            f32x4 v = acc[i][j] + bias_v[j];
+            const long co = (long)cur.mo * p.ldc + n;
+            if (epi & MVLT_EPI_GELU) {
+                if ((epi & MVLT_EPI_SAVE_PRE) && live) store4f(reinterpret_cast<T*>(p.pre) + co, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+            }
+            if (epi & MVLT_EPI_DROPOUT) {
+                const uint32_t base = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rng_keep(p.seed, p.tag, base + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.0f;
+            }
+            if (has_scale) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= cur.sc;
+            }
+            if (has_aux) {
+                const f32x4 a = raw4_to_f(cur.aux[j]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(a[e]);
+            }
+            if (has_res) v += raw4_to_f(cur.res[j]);
+            if (live) {
+                if (epi & MVLT_EPI_OUT_F32) {
+                    float* o = reinterpret_cast<float*>(p.C) + co;
+                    if (epi & MVLT_EPI_ACCUM) v += load4f(o);
+                    store4f(o, v);
+                } else {
+                    T* o = reinterpret_cast<T*>(p.C) + co;
+                    if (epi & MVLT_EPI_ACCUM) v += load4f(o);
+                    store4f(o, v);
+                }
+            }
+        }
+    }
+}
+
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
+// L2), so give every XCD one contiguous chunk of the tile list -> neighbouring tiles (same
+// A rows / B columns) hit the same L2.  Bijective for any count; speed only.
+MVLT_DEV int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// MvltGemm.prefetch: every thread of the launch reads one dword of a few 128-byte lines of a byte range that a LATER kernel
+// will stream (the next nn.Linear's weights, evicted by the optimizer's sweep since their last use); the value is dropped.
+MVLT_DEV unsigned prefetch_lines(const GemmDev& p) {
+    unsigned acc = 0;
+    if (p.pf) {
+        const long nthr = (long)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
+        const long g = ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        for (long l = g; l < p.pf_lines; l += nthr) acc ^= *reinterpret_cast<const unsigned*>(p.pf + (l << 7));
+    }
+    return acc;
+}
+
+}  // namespace

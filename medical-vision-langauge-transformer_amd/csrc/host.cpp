@@ -453,5 +453,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("side_release", &side_release);
     m.def("timer_begin", &timer_begin);
     m.def("timer_collect", &timer_collect);
-    m.def("abi_version", []() { return mvlt_version(); });
+    // the ABI this extension was COMPILED against (not what the library it happens to bind reports): ops.host()
+    // compares it with the Python mirror's constant and with libmvlt_hip.so's mvlt_version()
+    m.def("abi_version", []() { return (int)MVLT_ABI_VERSION; });
+    m.def("struct_sizes", []() {
+        return std::vector<int64_t>{(int64_t)sizeof(MvltGemm), (int64_t)sizeof(MvltLayerNorm), (int64_t)sizeof(MvltLayerNormBwd),
+                                    (int64_t)sizeof(MvltLnReduceItem), (int64_t)sizeof(MvltAttn), (int64_t)sizeof(MvltSwinWmsa),
+                                    (int64_t)sizeof(MvltEmbed), (int64_t)sizeof(MvltAttnCached), (int64_t)sizeof(MvltZeroItem),
+                                    (int64_t)sizeof(MvltRange), (int64_t)sizeof(MvltMlmMask)};
+    });
 }

@@ -651,7 +651,23 @@ __global__ __launch_bounds__(64) void mlm_mask_kernel(const MvltMlmMask p) {
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 #define BY_DTYPE(dt, CALL_F32, CALL_BF16) do { if ((dt) == MVLT_F32) { CALL_F32; } else if ((dt) == MVLT_BF16) { CALL_BF16; } else return MVLT_ERR_UNSUPPORTED; } while (0)
 
-extern "C" int mvlt_version(void) { return 1; }
+extern "C" int mvlt_version(void) { return MVLT_ABI_VERSION; }
+extern "C" size_t mvlt_sizeof(int struct_id) {
+    switch (struct_id) {
+        case MVLT_STRUCT_GEMM: return sizeof(MvltGemm);
+        case MVLT_STRUCT_LAYERNORM: return sizeof(MvltLayerNorm);
+        case MVLT_STRUCT_LAYERNORM_BWD: return sizeof(MvltLayerNormBwd);
+        case MVLT_STRUCT_LN_REDUCE_ITEM: return sizeof(MvltLnReduceItem);
+        case MVLT_STRUCT_ATTN: return sizeof(MvltAttn);
+        case MVLT_STRUCT_SWIN_WMSA: return sizeof(MvltSwinWmsa);
+        case MVLT_STRUCT_EMBED: return sizeof(MvltEmbed);
+        case MVLT_STRUCT_ATTN_CACHED: return sizeof(MvltAttnCached);
+        case MVLT_STRUCT_ZERO_ITEM: return sizeof(MvltZeroItem);
+        case MVLT_STRUCT_RANGE: return sizeof(MvltRange);
+        case MVLT_STRUCT_MLM_MASK: return sizeof(MvltMlmMask);
+        default: return 0;
+    }
+}
 extern "C" const char* mvlt_arch(void) { return "gfx950"; }
 
 extern "C" int mvlt_im2col_patch(int dtype, const float* img, void* cols, int B, int Cin, int S, int P, void* stream) {

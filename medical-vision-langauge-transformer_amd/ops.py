@@ -38,8 +38,11 @@ def host():
         spec = importlib.util.spec_from_file_location("_mvlt_host", path)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        if mod.abi_version() != L.lib().mvlt_version():
-            raise RuntimeError("_mvlt_host.so and libmvlt_hip.so disagree on the ABI version: rebuild both")
+        # abi_version() / struct_sizes() are compile-time constants of the extension: a stale _mvlt_host.so (built
+        # against an older header) fails here instead of handing truncated structs to the kernels
+        if mod.abi_version() != L.ABI_VERSION or list(mod.struct_sizes()) != [C.sizeof(s) for s in L.STRUCTS]:
+            raise RuntimeError(f"_mvlt_host.so was compiled against ABI {mod.abi_version()}, libmvlt_hip.so / _lib.py are "
+                               f"at ABI {L.ABI_VERSION} (or a struct size differs): rebuild both (make -C .../csrc)")
         _host = mod
     return _host
 

@@ -253,6 +253,28 @@ def test_layernorm_fwd_bwd(ops, dt, C):
     assert rel(dgam, gr.grad) < 1e-4 and rel(dbet, br.grad) < 1e-4
 
 
+def test_integration_md_binding_example_runs():
+    """the ctypes stub printed in INTEGRATION.md is extracted, executed as is and its function is
+    checked against torch (LayerNorm + window-order row scatter, visual_feature_extractor.py:356-367)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = md.split("<!-- cabi-example-begin")[1].split("<!-- cabi-example-end -->")[0].split("```python\n")[1].split("```")[0]
+    os.environ["MVLT_REPO"] = root
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    rows, C = 2 * 56 * 56, 96
+    x = rnd((rows, C), torch.bfloat16, 91)
+    norm = torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        norm.weight.add_(0.1 * torch.randn(C, device="cuda")); norm.bias.add_(0.1 * torch.randn(C, device="cuda"))
+    perm = torch.randperm(rows, generator=torch.Generator().manual_seed(5)).int().cuda()
+    y = ns["shifted_window_layernorm"](x, norm, perm)
+    exp = torch.empty(rows, C, device="cuda")
+    exp[perm.long()] = F.layer_norm(x.float(), (C,), norm.weight, norm.bias, norm.eps)
+    assert rel(y, exp) < tol(torch.bfloat16)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_layernorm_rowmap_gelu_merge(ops, dt):
     B, H, W, Cq = 2, 8, 8, 32
