@@ -28,8 +28,11 @@ PEAK_BF16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PER_GPU_BATCH, SEQ = 32, 80
 
 
-DOMINANT_NAME = ("gemm_group_kernel<bf16,{128|64},{128|96},kmajor,kmajor> (grouped weight-gradient GEMMs dW_i = dY_i^T X_i "
-                 "+ bias gradients of one layer per launch; side stream, beside the dgrad chain)")
+DOMINANT_NAME = ("forward + dgrad GEMM family of the Swin blocks / BertLayers: gemm_kernel<bf16,{128|64},{128|96|64},row,{row|kmajor}>, "
+                 "gemm_glds_kernel<{64|128},{64|96|128}>, gemm8_kernel (x W^T and dy W with fused epilogues; main stream) -- the "
+                 "family with the largest share of GPU time (~48 %, profiles/r3_bench_kernel_stats.csv)")
+WGRAD_NAME = ("gemm_group_kernel<bf16,{128|64},{128|96},kmajor,kmajor> (grouped weight-gradient GEMMs dW_i = dY_i^T X_i "
+              "+ bias gradients of one layer per launch; side stream, beside the dgrad chain)")
 DOMINANT = ("group", 1, 64, 128)   # gemm_group_kernel<bf16, BM=128|64, BN=128, A k-major, B k-major>: the grouped weight-
                                    # gradient GEMM (all dW of one BertLayer / Swin block per launch), the symbol with
                                    # the largest share of GPU time (profiles/r1_bench_kernel_stats.csv)
@@ -221,16 +224,34 @@ def other_configs(M):
     return res
 
 
-def profiled_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (cannot be collected
-    inside this process): profiles/r2_dominant_kernel_traffic.json, filled in from the scripts/pmc.py passes (profiles/r2_dominant_kernel_pmc.txt)."""
-    f = os.path.join(ROOT, "profiles", "r2_dominant_kernel_traffic.json")
+def profiled_traffic(key):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (cannot be collected inside this
+    process): profiles/r3_dominant_kernel_traffic.json {"family": {...}, "wgrad_group": {...}}, filled in from the
+    scripts/pmc.py passes over scripts/profile_step.py (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)."""
+    f = os.path.join(ROOT, "profiles", "r3_dominant_kernel_traffic.json")
     try:
         with open(f) as fh:
             d = json.load(fh)
-        return d.get("traffic_bytes_per_launch"), "profiles/r2_dominant_kernel_traffic.json"
+        return d[key].get("traffic_bytes_per_launch"), "profiles/r3_dominant_kernel_traffic.json"
     except Exception:
         return None, None
+
+
+def roofline_entry(samples, name, traffic_key, every):
+    """samples: [(executed flops, ms)] of launches bracketed with HIP events inside the timed region."""
+    if not samples:
+        return None
+    ms = sum(t for _, t in samples)
+    tflops = sum(f for f, _ in samples) / (ms * 1e-3) / 1e12
+    traffic, src = profiled_traffic(traffic_key)
+    return {"bound": "mfma", "kernel": name, "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tflops / PEAK_BF16_TFLOPS, 4),
+            # HBM bytes per launch: rocprofv3 PMC passes of the same step (2*FETCH_SIZE + WRITE_SIZE), read from the
+            # committed profile file named in traffic_source -- not measurable in-process
+            "traffic": traffic, "traffic_source": src,
+            "launches": len(samples), "avg_launch_us": round(1e3 * ms / len(samples), 2),
+            "flops": "executed: 2 M N K with the row count the kernels read on the device (ragged batches), not the dense bound",
+            "sampling": f"1 in {every} launches of the family inside the timed region, HIP events on the launch stream"}
 
 
 def main():
@@ -291,15 +312,18 @@ def main():
         step(batch)
     every = int(os.environ.get("MVLT_BENCH_SAMPLE", "4"))
     timer = KernelTimer(DOMINANT, every=every)
-    native_samples = None
-    if ops.NATIVE:          # the grouped launches are issued by csrc/host.cpp: it brackets them itself (same method)
-        ops.host().timer_begin(every, 64 * args.steps)
+    native_samples = fam_samples = None
+    fam_every = 8 * every          # ~9 of ~280 launches per step: every bracket costs host time and a barrier packet on the stream
+    if ops.NATIVE:          # the launches are issued by csrc/host.cpp: it brackets them itself (same method)
+        ops.host().timer_begin(0, every, 64 * args.steps)
+        ops.host().timer_begin(1, fam_every, 64 * args.steps)
     else:
         ops.GEMM_TIMER = timer
     elapsed, loss = timed_run(step, batch, args.steps, use_dist, dist)
     ops.GEMM_TIMER = None
     if ops.NATIVE:
-        native_samples = ops.host().timer_collect()          # [(flops, ms)] -- the stream is idle: timed_run synchronised
+        native_samples = ops.host().timer_collect(0)          # [(executed flops, ms)] -- the stream is idle: timed_run synchronised
+        fam_samples = ops.host().timer_collect(1)
     loss_value = float(loss.item())
 
     # EXTRA 1: the same call with config.auto_pack_rows = False -- every zero-padded caption row is computed, i.e.
@@ -315,6 +339,7 @@ def main():
                  "dense_rows_variant": "config.auto_pack_rows=False: every zero-padded caption row computed like the "
                                        "reference (reference-equivalent 132.7 GFLOP/pair executed)",
                  "dense_rows_step_tflops_per_gpu": round(PER_GPU_BATCH * args.steps / e1 * GFLOP_PER_PAIR / 1e3, 2),
+                 "dense_rows_step_mfma_frac": round(PER_GPU_BATCH * args.steps / e1 * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS, 4),
                  "dense_rows_loss": round(float(l1.item()), 4)}
         cfg.auto_pack_rows = True
     # EXTRA 2 (opt-in API, not reachable from the reference's unchanged caller): packed BERT rows via the added
@@ -339,22 +364,13 @@ def main():
         pairs = PER_GPU_BATCH * world * args.steps
         value = pairs / elapsed
         kr = timer.result()
-        if native_samples:
-            ms = sum(t for _, t in native_samples)
-            kr = dict(launches=len(native_samples), avg_us=1e3 * ms / len(native_samples),
-                      tflops=sum(f for f, _ in native_samples) / (ms * 1e-3) / 1e12)
-        roofline = None
-        if kr is not None:
-            traffic, src = profiled_traffic()
-            roofline = {"bound": "mfma", "kernel": DOMINANT_NAME,
-                        "achieved": round(kr["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(kr["tflops"] / PEAK_BF16_TFLOPS, 4),
-                        # HBM bytes per launch: rocprofv3 PMC passes of the same step (2*FETCH_SIZE + WRITE_SIZE),
-                        # read from the committed profile file named in traffic_source -- not measurable in-process
-                        "traffic": traffic, "traffic_source": src,
-                        "launches": kr["launches"], "avg_launch_us": round(kr["avg_us"], 2),
-                        "sampling": f"1 in {timer.every} launches of the kernel inside the timed region, HIP events "
-                                    "on the launch stream"}
+        roofline = roofline_entry(fam_samples, DOMINANT_NAME, "family", fam_every)
+        roofline_wgrad = roofline_entry(native_samples, WGRAD_NAME, "wgrad_group", every)
+        if roofline is None and kr is not None:          # ctypes host path (MVLT_NATIVE_HOST=0): only the grouped kernel is bracketed
+            roofline_wgrad = roofline_entry([(kr["tflops"] * 1e12 * kr["avg_us"] * 1e-6, kr["avg_us"] * 1e-3)] * kr["launches"],
+                                            WGRAD_NAME, "wgrad_group", every)
+            roofline = roofline_wgrad
+        gpp_exec = packed_gflop_per_pair(batch_full)
         out = {"metric": "image-text pairs/sec pretrain step (Swin-S+BERT, 224px, seq80)", "value": round(value, 2),
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -374,13 +390,12 @@ def main():
                                             f"RCCL all-reduce AVG, {'bf16' if comm == torch.bfloat16 else 'f32'}, 64 MiB "
                                             "buckets overlapped with backward; per-rank MLM mean over labelled tokens"),
                           "loss": round(loss_value, 4)},
-               # reference-equivalent FLOPs (132.7 GFLOP/pair) over the step time; the FLOPs actually executed on the
-               # default path (padded caption rows skipped) are in executed_gflop_per_pair
-               "step_tflops_per_gpu": round(value / world * GFLOP_PER_PAIR / 1e3, 2),
-               "step_mfma_frac": round(value / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS, 4),
-               "executed_gflop_per_pair": round(packed_gflop_per_pair(batch_full), 1),
-               "step_tflops_per_gpu_executed": round(value / world * packed_gflop_per_pair(batch_full) / 1e3, 2),
-               "roofline": roofline}
+               # FLOPs the default path EXECUTES (padded caption rows and unlabelled MLM rows skipped) over the step time; the
+               # reference-equivalent 132.7 GFLOP/pair figure is quoted only for the run that executes it (value_dense_rows)
+               "executed_gflop_per_pair": round(gpp_exec, 1),
+               "step_tflops_per_gpu": round(value / world * gpp_exec / 1e3, 2),
+               "step_mfma_frac": round(value / world * gpp_exec / 1e3 / PEAK_BF16_TFLOPS, 4),
+               "roofline": roofline, "roofline_wgrad_group": roofline_wgrad}
         if dense is not None:
             out.update(dense)
         if extra is not None:

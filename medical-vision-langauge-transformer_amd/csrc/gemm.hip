@@ -16,9 +16,12 @@
 #include <cstdlib>
 
 // gemm8.hip: 8-wave ping-pong kernel; takes the filled kernel argument block, returns 1 if it launched
-extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* dev_blocks, int n, int a_kmajor, int b_kmajor, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* dev_blocks, int n, int a_kmajor, int b_kmajor, int big_only, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_colsum(const void* dev_blocks, float* const* outs, int n, void* stream);
-static int g8_mode() { const char* e = getenv("MVLT_G8"); return e ? atoi(e) : 0; }
+// MVLT_G8: unset / 2 = automatic (single products that fill the chip with 256 x 256 tiles: MLM decoder, large batches),
+// 0 = never, 1 = wherever it is eligible, weight-gradient groups included (experiments: slower than the 4-wave kernels on
+// the B=32 step's mid-size products)
+static int g8_mode() { const char* e = getenv("MVLT_G8"); return e ? atoi(e) : 2; }
 
 namespace {
 
@@ -354,10 +357,15 @@ MVLT_DEV void glds_fill(const bf16_t* const (&src)[R / 32], bf16_t* lds_tile, in
     }
 }
 
-template <int BM, int BN>
+// BKM: the B operand is k-major (dgrad: dx = dy W reads the [N_out, K_in] weight along its rows).  Its tile image is
+// [64 k][BN] with the 32-byte units XOR-swizzled by kswz<BN>(k) (the layout tile_frag<T, BN, true> transposes out of with
+// ds_read_b64_tr_b16); one LDS-DMA instruction covers 1 KB = 8 (BN = 64) / 4 (BN = 128) k-rows, the swizzle again on the
+// source side.  With transposing reads in the loop the DMA is issued through inline asm (glds16_asm, gemm_dev.h).
+template <int BM, int BN, bool BKM>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     using T = bf16_t;
     constexpr int BKE = 64, FM = BM / 32, FN = BN / 32;
+    static_assert(!BKM || BN == 64 || BN == 128, "k-major B tiles: 64 or 128 columns");
     __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * BKE];
     const GemmDev p = effective<false>(p_in);
     const unsigned pfv = prefetch_lines(p_in);
@@ -371,7 +379,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     const int ks = bz * p.k_per_split;
     const int ke = min(p.K, ks + p.k_per_split);
     const int nkt = (ke - ks) / BKE;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wm = wave >> 1, wn = wave & 1;
     const T* A = reinterpret_cast<const T*>(p.A);
     const T* B = reinterpret_cast<const T*>(p.B);
@@ -387,23 +396,36 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     }
 #pragma unroll
     for (int j = 0; j < BN / 32; ++j) {
-        const int row = min(n0 + (wave * (BN / 32) + j) * 8 + rin, p.N - 1);
-        srcB[j] = B + (long)row * p.ldb + ks + chs * 8;
+        if constexpr (BKM) {
+            constexpr int KPI = 512 / BN;                                    // k-rows per instruction (1 KB / (BN * 2 B))
+            constexpr int XM = BN / 8 - 1;                                   // 16-byte positions per k-row - 1
+            const int krow = (wave * (BN / 32) + j) * KPI + lane / (BN / 8), x = lane & XM;
+            const int ch = (((x >> 1) ^ kswz<BN>(krow)) << 1) | (x & 1);
+            srcB[j] = B + (long)(ks + krow) * p.ldb + min(n0 + ch * 8, max(p.N - 8, 0));
+        } else {
+            const int row = min(n0 + (wave * (BN / 32) + j) * 8 + rin, p.N - 1);
+            srcB[j] = B + (long)row * p.ldb + ks + chs * 8;
+        }
     }
+    const long kstep_b = BKM ? (long)BKE * p.ldb : (long)BKE;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)smem;
+    auto fill = [&](int stage, int kt) {
+        const unsigned sa = lds0 + (unsigned)(stage * STAGE) * 2u, sb = sa + (unsigned)(BM * BKE) * 2u;
+#pragma unroll
+        for (int j = 0; j < BM / 32; ++j) glds16_asm(srcA[j] + (long)kt * BKE, sa + (wave * (BM / 32) + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) glds16_asm(srcB[j] + kt * kstep_b, sb + (wave * (BN / 32) + j) * 1024);
+    };
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nkt > 0) { glds_fill<BM>(srcA, smem, wave, 0); glds_fill<BN>(srcB, smem + BM * BKE, wave, 0); }
+    if (nkt > 0) fill(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt has landed
         __syncthreads();                                       // everybody's has; everybody is done reading tile kt-1
-        if (kt + 1 < nkt) {
-            T* nxt = smem + ((kt + 1) & 1) * STAGE;
-            glds_fill<BM>(srcA, nxt, wave, (long)(kt + 1) * BKE);
-            glds_fill<BN>(srcB, nxt + BM * BKE, wave, (long)(kt + 1) * BKE);
-        }
+        if (kt + 1 < nkt) fill((kt + 1) & 1, kt + 1);
         const T* a = smem + (kt & 1) * STAGE;
         const T* b = a + BM * BKE;
 #pragma unroll
@@ -412,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) fa[i] = tile_frag<T, BM, false>(a, wm * (BM / 2) + i * 16, kb);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) fb[j] = tile_frag<T, BN, false>(b, wn * (BN / 2) + j * 16, kb);
+            for (int j = 0; j < FN; ++j) fb[j] = tile_frag<T, BN, BKM>(b, wn * (BN / 2) + j * 16, kb);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -928,7 +950,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // 8-wave ping-pong engine (gemm8.hip) for wide outputs: MVLT_G8 = 0 never / 1 wherever it is eligible
         if (g8_mode() && !ak && d.split_k <= 1) {
-            const int rc8 = mvlt_gemm8_try(&d, 1, 0, bk ? 1 : 0, s);
+            const int rc8 = mvlt_gemm8_try(&d, 1, 0, bk ? 1 : 0, g8_mode() == 2, s);
             if (rc8 < 0) return MVLT_ERR_LAUNCH;
             if (rc8 > 0) {
                 if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
@@ -956,13 +978,20 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
         static const int glds_mode = [] { const char* e = getenv("MVLT_GLDS"); return e ? atoi(e) : 2; }();
         const bool glds_on = glds_mode == 1 || (glds_mode == 2 && pl.bm == 64);
         const int kspan = d.split_k > 1 ? d.k_per_split : p->K;
-        if (glds_on && !ak && !bk && p->K % 64 == 0 && kspan % 64 == 0 && d.a_vec && d.b_vec) {
+        const bool bkm_ok = !bk || ((pl.bn == 64 || pl.bn == 128) && p->N % 8 == 0 && p->N >= 8);
+        if (glds_on && !ak && bkm_ok && p->K % 64 == 0 && kspan % 64 == 0 && d.a_vec && d.b_vec) {
             bool done = true;
-            if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<128, 128>), grid, dim3(256), 0, s, d);
-            else if (pl.bm == 128 && pl.bn == 96) hipLaunchKernelGGL((gemm_glds_kernel<128, 96>), grid, dim3(256), 0, s, d);
-            else if (pl.bm == 64 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<64, 128>), grid, dim3(256), 0, s, d);
-            else if (pl.bm == 64 && pl.bn == 96) hipLaunchKernelGGL((gemm_glds_kernel<64, 96>), grid, dim3(256), 0, s, d);
-            else if (pl.bm == 64 && pl.bn == 64) hipLaunchKernelGGL((gemm_glds_kernel<64, 64>), grid, dim3(256), 0, s, d);
+            if (bk) {
+                if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, true>), grid, dim3(256), 0, s, d);
+                else if (pl.bm == 64 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<64, 128, true>), grid, dim3(256), 0, s, d);
+                else if (pl.bm == 64 && pl.bn == 64) hipLaunchKernelGGL((gemm_glds_kernel<64, 64, true>), grid, dim3(256), 0, s, d);
+                else done = false;
+            }
+            else if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, false>), grid, dim3(256), 0, s, d);
+            else if (pl.bm == 128 && pl.bn == 96) hipLaunchKernelGGL((gemm_glds_kernel<128, 96, false>), grid, dim3(256), 0, s, d);
+            else if (pl.bm == 64 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<64, 128, false>), grid, dim3(256), 0, s, d);
+            else if (pl.bm == 64 && pl.bn == 96) hipLaunchKernelGGL((gemm_glds_kernel<64, 96, false>), grid, dim3(256), 0, s, d);
+            else if (pl.bm == 64 && pl.bn == 64) hipLaunchKernelGGL((gemm_glds_kernel<64, 64, false>), grid, dim3(256), 0, s, d);
             else done = false;
             if (done) {
                 MVLT_LAUNCH_CHECK();
@@ -1029,7 +1058,7 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
     }
     // 8-wave ping-pong engine: the whole group as one persistent launch of 128/256 x 256 tiles, bias gradients beside it
     if constexpr (sizeof(T) == 2) {
-        if (g8_mode()) {
+        if (g8_mode() == 1) {
             GemmDev tmp[GROUP_MAX];
             float* outs[GROUP_MAX];
             bool ok = true;
@@ -1038,7 +1067,7 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
                 ok = ok && tmp[i].epi == MVLT_EPI_OUT_F32 && tmp[i].M % 4 == 0 && tmp[i].lda % 4 == 0;
             }
             if (ok) {
-                const int rc8 = mvlt_gemm8_try(tmp, n, 1, 1, s);
+                const int rc8 = mvlt_gemm8_try(tmp, n, 1, 1, 0, s);
                 if (rc8 < 0) return MVLT_ERR_LAUNCH;
                 if (rc8 > 0) return mvlt_gemm8_colsum(tmp, outs, n, s) > 0 ? MVLT_OK : MVLT_ERR_LAUNCH;
             }

@@ -503,7 +503,7 @@ int g8_choose(const GemmDev* d, int n, long* tiles_out) {
     }
     int mode = 0;
     if (const char* e = getenv("MVLT_G8_TILE")) mode = atoi(e);          // experiments: 22 / 12 force a shape
-    else if (t22 >= 200) mode = 22;
+    else if (t22 >= 400) mode = 22;          // (by the host-side bound of M: a ragged batch fills ~3/4 of it)
     else if (t12 >= 96) mode = 12;
     *tiles_out = mode == 22 ? t22 : t12;
     return mode;
@@ -569,7 +569,7 @@ extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_colsum(const voi
 // aligned epilogue operands, an epilogue flag set that has an instantiation, and K a multiple of 64 unless both
 // operands are k-major (weight gradients: the reduction runs over activation rows, any count, also read from m_dev).
 extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* dev_blocks, int n, int a_kmajor, int b_kmajor,
-                                                                    void* stream) {
+                                                                    int big_only, void* stream) {
     const GemmDev* d = reinterpret_cast<const GemmDev*>(dev_blocks);
     if (n < 1 || n > G8_GROUP_MAX) return 0;
     G8Group gp{};
@@ -586,6 +586,7 @@ extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* 
     if (a_kmajor && !gp.zero_page) return 0;
     long tiles = 0;
     const int mode = g8_choose(d, n, &tiles);
+    if (big_only && mode != 22) return 0;                 // automatic mode: only products that fill the chip with 256 x 256 tiles
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (mode == 22) return g8_dispatch<2, 2>(gp, a_kmajor != 0, b_kmajor != 0, d[0].epi, tiles, s);
     if (mode == 12) return g8_dispatch<1, 2>(gp, a_kmajor != 0, b_kmajor != 0, d[0].epi, tiles, s);

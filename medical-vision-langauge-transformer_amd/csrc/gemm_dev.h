@@ -222,6 +222,16 @@ MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base
     }
 }
 
+// LDS-DMA as inline asm (16 bytes per lane to wave-uniform lds_dst + lane * 16): hipcc must NOT know that an LDS-DMA is
+// in flight -- knowing it, it puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 (the intrinsic carries no alias
+// information), which serialises the DMA of tile t+1 with the fragment reads of tile t.  Callers count their vmcnt by
+// hand.  M0 (the LDS destination) is compiler-reserved: saved and restored inside the statement.
+MVLT_DEV void glds16_asm(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
 // L2), so give every XCD one contiguous chunk of the tile list -> neighbouring tiles (same
 // A rows / B columns) hit the same L2.  Bijective for any count; speed only.

@@ -69,6 +69,50 @@ void* workspace(Scratch& s, size_t need, const Tensor& like) {
     return s.buf.data_ptr();
 }
 
+// optional timing of sampled launches (bench.py roofline): HIP events on the launch stream around 1 in `every` launches
+// of a kernel family.  FLOPs are counted with the row count the kernels EXECUTE: ragged batches keep it on the device
+// (MvltGemm.m_dev), so the sample copies it to a pinned host slot on the same stream (no sync) and the FLOPs are
+// evaluated in timer_collect -- counting the dense upper bound overstated the round-2 roofline by 13 %.
+struct KernelTimer {
+    bool on = false; int every = 4, count = 0;
+    std::vector<hipEvent_t> ev;
+    std::vector<double> mn2;          // per sample: 2 * sum_i (the two dimensions that are not ragged)
+    std::vector<int> bound;           // per sample: host-known upper bound of the ragged dimension
+    int* dev_rows = nullptr;          // pinned host: ragged dimension read from the device (-1: none, use the bound)
+    size_t used = 0, cap = 0;
+    bool sample() { return on && (count++ % every) == 0 && used < cap; }
+    void begin(void* stream, double mn2_, int bound_, const int32_t* rows_dev) {
+        mn2.push_back(mn2_); bound.push_back(bound_);
+        dev_rows[used] = -1;
+        if (rows_dev) (void)hipMemcpyAsync(&dev_rows[used], rows_dev, sizeof(int), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+        (void)hipEventRecord(ev[2 * used], static_cast<hipStream_t>(stream));
+    }
+    void end(void* stream) { (void)hipEventRecord(ev[2 * used + 1], static_cast<hipStream_t>(stream)); ++used; }
+    void reset(int every_, size_t cap_) {
+        for (auto e : ev) (void)hipEventDestroy(e);
+        if (dev_rows) (void)hipHostFree(dev_rows);
+        ev.clear(); mn2.clear(); bound.clear(); dev_rows = nullptr; used = 0; count = 0;
+        on = cap_ > 0; every = std::max(1, every_); cap = cap_;
+        if (!on) return;
+        ev.resize(2 * cap);
+        for (auto& e : ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate");
+        TORCH_CHECK(hipHostMalloc(reinterpret_cast<void**>(&dev_rows), cap * sizeof(int), hipHostMallocDefault) == hipSuccess, "hipHostMalloc");
+    }
+    std::vector<std::pair<double, double>> collect() {          // [(executed flops, milliseconds)]; call after a device synchronize
+        std::vector<std::pair<double, double>> out;
+        for (size_t i = 0; i < used; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) continue;
+            const int rows = dev_rows[i] >= 0 ? std::min(dev_rows[i], bound[i]) : bound[i];
+            out.emplace_back(mn2[i] * rows, (double)ms);
+        }
+        on = false;
+        return out;
+    }
+};
+KernelTimer g_timer;        // grouped weight-gradient launches (gemm_group_kernel)
+KernelTimer g_timer_fam;    // forward / dgrad products of the layers (gemm_kernel, gemm_glds_kernel, gemm8_kernel)
+
 // ----------------------------------------------------------------------------------------------- GEMM
 struct Epi {
     const void* pf = nullptr; int64_t pf_bytes = 0;      // MvltGemm.prefetch: the weights of the product that runs next
@@ -109,7 +153,10 @@ void gemm(int dtype, int M, int N, int K, const void* A, int64_t lda, bool ak, c
     fill_gemm(p, dtype, M, N, K, A, lda, ak, B, ldb, bk, C, ldc, e);
     const size_t need = mvlt_gemm_workspace_bytes(&p);
     if (need) { p.workspace = workspace(ws, need, like); p.workspace_bytes = (size_t)ws.buf.numel(); }
+    const bool timed = !ak && g_timer_fam.sample();          // forward / dgrad products: rows (M) may be ragged
+    if (timed) g_timer_fam.begin(stream, 2.0 * N * K, M, e.m_dev);
     ck(mvlt_gemm(&p, stream), "mvlt_gemm");
+    if (timed) g_timer_fam.end(stream);
 }
 
 // y = x W^T (+ epilogue): x [rows, K] contiguous, W [N, K]
@@ -122,10 +169,6 @@ inline void dgrad(const Tensor& dy, int64_t W, int K, Tensor& out, const Epi& e,
     gemm(dtype_of(dy), (int)dy.size(0), K, (int)dy.size(1), dp(dy), dy.size(1), false, P(W), K, true, dp(out), out.size(1),
          e, stream, g_ws_main, dy);
 }
-
-// optional timing of the grouped weight-gradient launches (bench.py roofline): HIP events on the launch stream
-struct GroupTimer { bool on = false; int every = 4, count = 0; std::vector<hipEvent_t> ev; std::vector<double> flops; size_t used = 0; };
-GroupTimer g_timer;
 
 struct WItem { const Tensor* dy; const Tensor* x; int64_t dw; int64_t db; };
 // weight gradients of one layer: dW_i = dY_i^T X_i, db_i = colsum(dY_i)  (ops.wgrad_group)
@@ -150,26 +193,19 @@ void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws, con
         return;
     }
     MvltGemm arr[8];
-    double flops = 0;
+    double mn2 = 0;
     for (int i = 0; i < n; ++i) {
         const auto& it = items[i];
         Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db); e.m_dev = k_dev;
         fill_gemm(arr[i], dtype, (int)it.dy->size(1), (int)it.x->size(1), (int)it.dy->size(0), dp(*it.dy), it.dy->size(1), true,
                   dp(*it.x), it.x->size(1), true, P(it.dw), it.x->size(1), e);
         arr[i].split_k = 1;
-        flops += 2.0 * arr[i].M * arr[i].N * arr[i].K;
+        mn2 += 2.0 * arr[i].M * arr[i].N;          // the reduction length (activation rows) is the ragged dimension here
     }
-    bool timed = false;
-    if (g_timer.on && (g_timer.count++ % g_timer.every) == 0 && g_timer.used + 2 <= g_timer.ev.size()) {
-        timed = true;
-        (void)hipEventRecord(g_timer.ev[g_timer.used], static_cast<hipStream_t>(stream));
-    }
+    const bool timed = g_timer.sample();
+    if (timed) g_timer.begin(stream, mn2, arr[0].K, k_dev);
     ck(mvlt_gemm_group(arr, n, stream), "mvlt_gemm_group");
-    if (timed) {
-        (void)hipEventRecord(g_timer.ev[g_timer.used + 1], static_cast<hipStream_t>(stream));
-        g_timer.used += 2;
-        g_timer.flops.push_back(flops);
-    }
+    if (timed) g_timer.end(stream);
 }
 
 // ----------------------------------------------------------------------------------------------- LayerNorm
@@ -422,23 +458,12 @@ void lnq_flush(int64_t stream) { g_lnq.flush(P(stream)); }
 int64_t lnq_pending() { return (int64_t)g_lnq.items.size(); }
 void side_release() { g_side_keepalive.clear(); g_ws_side.retired.clear(); g_ws_main.retired.clear(); }
 
-void timer_begin(int64_t every, int64_t capacity) {
-    for (auto e : g_timer.ev) (void)hipEventDestroy(e);
-    g_timer = GroupTimer{};
-    g_timer.on = true; g_timer.every = (int)std::max<int64_t>(1, every);
-    g_timer.ev.resize((size_t)capacity * 2);
-    for (auto& e : g_timer.ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate");
+// which: 0 = grouped weight-gradient launches, 1 = forward / dgrad products issued by the layer calls
+void timer_begin(int64_t which, int64_t every, int64_t capacity) {
+    (which == 0 ? g_timer : g_timer_fam).reset((int)every, (size_t)capacity);
 }
-// -> [(flops, milliseconds)] of the sampled grouped launches; call after a device synchronize
-std::vector<std::pair<double, double>> timer_collect() {
-    std::vector<std::pair<double, double>> out;
-    for (size_t i = 0; i + 1 < g_timer.used; i += 2) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_timer.ev[i], g_timer.ev[i + 1]) == hipSuccess) out.emplace_back(g_timer.flops[i / 2], (double)ms);
-    }
-    g_timer.on = false;
-    return out;
-}
+// -> [(executed flops, milliseconds)] of the sampled launches; call after a device synchronize
+std::vector<std::pair<double, double>> timer_collect(int64_t which) { return (which == 0 ? g_timer : g_timer_fam).collect(); }
 
 }  // namespace
 
