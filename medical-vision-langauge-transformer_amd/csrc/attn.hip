@@ -315,6 +315,8 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
     for (int t = 0; t < KT; ++t) dbacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* qkv_g = reinterpret_cast<const T*>(p.qkv);
     Stager<T, HD, KT * 16> gq, gk, gv, gd;
+    float lse_pre = 0.f;          // lse of the staged sequence, rows threadIdx.x (+256 ...) -- loaded WITH the operands: a load
+                                  // issued behind the previous window's dQ/dK/dV stores would wait for them (vmcnt is in order)
     auto issue = [&](int sq) {
         const long r0 = seq_row0(p, sq);
         const int ln = seq_length(p, sq);
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
         gk.load(base + C, 3 * C, 0, p.rows_alloc, ln);
         gv.load(base + 2 * C, 3 * C, 0, p.rows_alloc, ln);
         gd.load(dout + r0 * C + h * HD, C, 0, p.rows_alloc, ln);
+        if (p.rows_alloc <= 256) lse_pre = (int)threadIdx.x < ln ? p.lse[((long)sq * p.nH + h) * p.L + threadIdx.x] : 0.f;
     };
     if (SWIN && (int)blockIdx.x < p.nseq) issue(blockIdx.x);
     // Swin: window-invariant per-lane bias values of both orientations go to LDS once (registers are full),
@@ -360,7 +363,8 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
         gd.store(s.d, p.ld, p.rows_alloc);
         if (!SWIN) stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, seq, h, true);
         // lse_q (delta_q = rowsum(P .* dP) is produced by phase A in registers: no O / dO pre-pass)
-        for (int q = threadIdx.x; q < p.rows_alloc; q += 256)
+        if (p.rows_alloc <= 256) { if ((int)threadIdx.x < p.rows_alloc) s.lse[threadIdx.x] = lse_pre; }
+        else for (int q = threadIdx.x; q < p.rows_alloc; q += 256)
             s.lse[q] = q < Ls ? p.lse[((long)seq * p.nH + h) * p.L + q] : 0.f;
         __syncthreads();
         if (SWIN && seq + (int)gridDim.x < p.nseq) issue(seq + gridDim.x);      // next window in flight

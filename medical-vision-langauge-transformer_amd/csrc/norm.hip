@@ -49,15 +49,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnDev p) {
     const int r = (blockIdx.x * 4 + wave) * RPW + lane / LPR;
     const bool rv = r < ln_rows(p);
     const T* x = reinterpret_cast<const T*>(p.x);
-    f32x4 v[NV];
+    f32x4 v[NV], gm[NV], bt[NV];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = 4 * (sl + LPR * j);
         v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (rv && c < p.C) v[j] = load4f(x + in_offset<MERGE>(p, r, c));
-        s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
     }
+    // gamma / beta are loaded HERE, with the row: vmcnt completes in order, so a load issued between the stores below
+    // would wait for the store in front of it
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = min(4 * (sl + LPR * j), p.C - 4);
+        gm[j] = load4f(p.gamma + c); bt[j] = load4f(p.beta + c);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
     const float mean = group_sum<LPR>(s) / p.C;
     float q = 0.f;
 #pragma unroll
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnDev p) {
     for (int j = 0; j < NV; ++j) {
         const int c = 4 * (sl + LPR * j);
         if (c < p.C) {
-            const f32x4 g = load4f(p.gamma + c), b = load4f(p.beta + c);
+            const f32x4 g = gm[j], b = bt[j];
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * g[e] + b[e];
@@ -112,13 +120,24 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnDev p) {
     for (int j = 0; j < NV; ++j) { ag[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[j] = ag[j]; }
     const float invC = 1.0f / p.C;
     const int nrows = ln_rows(p);
+    f32x4 gmv[NV];                                   // gamma: the same for every row
+#pragma unroll
+    for (int j = 0; j < NV; ++j) gmv[j] = load4f(p.gamma + min(4 * (sl + LPR * j), p.C - 4));
     for (int r0 = (blockIdx.x * nwave + wave) * RPW; r0 < nrows; r0 += gridDim.x * nwave * RPW) {
         const int r = r0 + lane / LPR;
         const bool rv = r < nrows;
         const float mean = rv ? p.mean[r] : 0.f, rstd = rv ? p.rstd[r] : 0.f;
         const int rd = (rv && p.rowmap) ? p.rowmap[r] : r;
-        f32x4 xh[NV], g[NV];
+        f32x4 xh[NV], g[NV], rs[NV];
         float s1 = 0.f, s2 = 0.f;
+        // the residual-path gradient is loaded with the row (a load issued between the stores below would wait for the
+        // store in front of it: vmcnt completes in order)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * (sl + LPR * j);
+            rs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (dres && rv && c < p.C) rs[j] = load4f(dres + in_offset<MERGE>(p, r, c));
+        }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = 4 * (sl + LPR * j);
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnDev p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[e] *= gelu_grad_f(yp[e]);
                 }
-                const f32x4 gm = load4f(p.gamma + c);
+                const f32x4 gm = gmv[j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     xh[j][e] = (xv[e] - mean) * rstd;
@@ -152,9 +171,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnDev p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = rstd * (g[j][e] - s1 - xh[j][e] * s2);
                     const long off = in_offset<MERGE>(p, r, c);
-                    if (dres) { f32x4 a = load4f(dres + off);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += a[e]; }
+                    o += rs[j];
                     store4f(dx + off, o);
                     if (!MERGE && p.dz) {           // branch gradient for the residual branch that consumed this tensor
                         if (p.zthresh) {

@@ -19,6 +19,13 @@ exchange step BASELINE.json asks for.  Design for 8 x MI355X on one node
   outstanding handles; AdamW divides by world_size (grad_scale);
 * parameters without a gradient this step (idle MLM head, unused modules) are
   not communicated;
+* the MLM loss of the reference is a mean over the labelled tokens of the WHOLE
+  batch (model.py:410).  Ranks hold different numbers of labelled tokens, so the
+  rank-average of per-rank means is a different number; ``global_label_mean``
+  (default on) all-reduces the 4-byte label count in the forward pass and every
+  rank divides its summed loss by N_global / world instead of its own count:
+  the averaged loss and gradients then equal the single-process global-batch
+  step exactly (the ITM loss is a mean over samples, equal per rank: unchanged);
 * the seq2seq/bidirectional coin flip of MVLBertForPretraining is drawn from
   Python's ``random``: ``seed_coin_flip`` gives all ranks the same stream so
   the same MLM head is active everywhere (otherwise buckets would diverge).
@@ -39,10 +46,15 @@ def seed_coin_flip(seed: int) -> None:
     random.seed(seed)
 
 
-def plan_ranges(arena: Arena, lo: int, hi: int, done: set) -> List[Tuple[int, int]]:
+GAP_ELEMS = 2 << 20      # ranges of one bucket separated by less than this (8 MB of f32) leave as ONE collective
+
+
+def plan_ranges(arena: Arena, lo: int, hi: int, done: set, gap_elems: int = GAP_ELEMS) -> List[Tuple[int, int]]:
     """Contiguous element ranges inside [lo, hi) covered by parameters that
     received a gradient this step and have not been reduced yet (``done`` is
-    updated)."""
+    updated).  Ranges separated only by a SMALL run of parameters without a gradient (the never-used Swin classifier
+    head, resnet_fc, embedding_LayerNorm: 9 MB in all) are merged, so a bucket is one collective; the gap's stale
+    gradient slots are reduced along (nobody reads them: p.grad is None there).  The idle MLM head (96 MB) stays a gap."""
     out: List[List[int]] = []
     for p in arena.params_between(lo, hi):
         o = arena.offset[id(p)]
@@ -50,7 +62,7 @@ def plan_ranges(arena: Arena, lo: int, hi: int, done: set) -> List[Tuple[int, in
         if not arena.has_grad[id(p)] or id(p) in done:
             continue
         done.add(id(p))
-        if out and out[-1][1] == o:
+        if out and 0 <= o - out[-1][1] <= gap_elems:
             out[-1][1] = e
         else:
             out.append([o, e])
@@ -59,18 +71,28 @@ def plan_ranges(arena: Arena, lo: int, hi: int, done: set) -> List[Tuple[int, in
 
 class GradReducer:
     def __init__(self, model, bucket_bytes: int = 64 << 20, process_group=None, allow_cpu: bool = False,
-                 comm_dtype: torch.dtype = torch.float32, average: bool = True):
+                 comm_dtype: torch.dtype = torch.float32, average: bool = True, global_label_mean: bool = True,
+                 fork_stream: bool | None = None, merge_gap_elems: int = GAP_ELEMS):
         """average=True (default): p.grad ends up as the MEAN over ranks, like torch DDP, so a stock torch
         optimizer / clip_grad_norm_ on the drop-in sees what it would see on one GPU (RCCL's AVG reduction: no
         extra pass; other backends: SUM + one in-place scale).  average=False leaves the SUM (pair it with
         FusedAdamW(grad_scale=1/world)).
         comm_dtype=torch.bfloat16: buckets are cast to bf16 for the exchange and back afterwards (half the xGMI
         bytes; the cross-rank sum is then rounded to bf16 -- PyTorch DDP's bf16_compress_hook trade-off).  The
-        default keeps the reference-equivalent f32 sum."""
+        default keeps the reference-equivalent f32 sum.
+        fork_stream: issue the buckets from a helper stream that waits for the main AND the weight-gradient stream, so
+        the main stream is not stalled at bucket boundaries.  Default (None): the MVLT_DDP_FORK environment switch, off
+        -- the main stream joins the weight-gradient stream before each bucket (the ordering every test covers); the
+        helper-stream form has only ever run over gloo / one rank and stays opt-in until a multi-GPU RCCL run has
+        covered it."""
         if comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("comm_dtype must be float32 or bfloat16")
+        import os
         self.comm_dtype = comm_dtype
         self.average = average
+        self.use_fork = (os.environ.get("MVLT_DDP_FORK", "0") == "1") if fork_stream is None else bool(fork_stream)
+        self.global_label_mean = global_label_mean
+        self.gap_elems = merge_gap_elems      # plan_ranges: small runs of gradient-less parameters do not split a bucket
         self.comm_buf = None
         self.pending_casts = []
         self.model = model
@@ -101,7 +123,18 @@ class GradReducer:
             ar._on_watermark = self._on_watermark
             ar._on_backward_begin = self._begin
             dist.broadcast(ar.flat, src=0, group=self.pg)        # identical replicas (bumps flat._version -> bf16 copy refreshed)
+        if self.global_label_mean and self.world > 1:
+            self.model.__dict__["_mvlt_label_sync"] = self.label_sync
+        else:
+            self.model.__dict__.pop("_mvlt_label_sync", None)
         return ar
+
+    def label_sync(self, count: torch.Tensor) -> torch.Tensor:
+        """count: f32 [1] on this rank's device = labelled tokens of this rank's shard.  Returns N_global / world (f32 [1]):
+        one 4-byte SUM all-reduce, enqueued on the current stream (no host sync)."""
+        g = count.detach().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+        return g / float(self.world)
 
     # ---- hooks called by the engines (runtime.backward_begin / arena.watermark / backward_end)
     def _begin(self, arena: Arena) -> None:
@@ -123,27 +156,32 @@ class GradReducer:
             # side stream into the MAIN stream here would stall the backward pass at every bucket; instead a
             # helper stream waits for both and the collective is issued from it (RCCL's own stream then waits
             # for the helper), so the main stream keeps running ahead.
-            fork = self.__dict__.get("_fork_stream")
-            if fork is None:
-                fork = self._fork_stream = torch.cuda.Stream(device=arena.flat.device)
-            fork.wait_stream(torch.cuda.current_stream())
-            fork.wait_stream(ops.side_stream(arena.flat.device))
-        ranges = plan_ranges(arena, lo, hi, self.done)
+            if self.use_fork:
+                fork = self.__dict__.get("_fork_stream")
+                if fork is None:
+                    fork = self._fork_stream = torch.cuda.Stream(device=arena.flat.device)
+                fork.wait_stream(torch.cuda.current_stream())
+                fork.wait_stream(ops.side_stream(arena.flat.device))
+        ranges = plan_ranges(arena, lo, hi, self.done, self.gap_elems)
         op = dist.ReduceOp.AVG if (self.average and self._avg_op) else dist.ReduceOp.SUM
+
+        def reduce_ranges(rs):
+            return [dist.all_reduce(arena.grad[a:b], op=op, group=self.pg, async_op=True) for a, b in rs]
+
         if self.comm_dtype == torch.float32 and fork is not None and self.on_bucket is None:
             with torch.cuda.stream(fork):
-                hs = [dist.all_reduce(arena.grad[a:b], op=op, group=self.pg, async_op=True) for a, b in ranges]
+                hs = reduce_ranges(ranges)
         elif self.comm_dtype == torch.float32:
-            if fork is not None:
+            if arena.flat.is_cuda:
                 torch.cuda.current_stream().wait_stream(ops.side_stream(arena.flat.device))
-            hs = [dist.all_reduce(arena.grad[a:b], op=op, group=self.pg, async_op=True) for a, b in ranges]
+            hs = reduce_ranges(ranges)
         else:
             if self.on_bucket is not None:
                 raise RuntimeError("compressed gradient exchange cannot feed the overlapped optimizer")
             if self.comm_buf is None or self.comm_buf.numel() != arena.total:
                 self.comm_buf = torch.empty(arena.total, dtype=self.comm_dtype, device=arena.grad.device)
             hs = []
-            if fork is not None:
+            if arena.flat.is_cuda:
                 torch.cuda.current_stream().wait_stream(ops.side_stream(arena.flat.device))
             for a, b in ranges:
                 buf = self.comm_buf[a:b]

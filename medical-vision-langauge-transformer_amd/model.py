@@ -264,13 +264,18 @@ class _MlmLossFn(torch.autograd.Function):
     logits stay in one padded [rows, ld] buffer, CE backward overwrites it in place."""
 
     @staticmethod
-    def forward(ctx, token, x, head, labels, save, rd=None):
+    def forward(ctx, token, x, head, labels, save, rd=None, label_sync=None):
         ar = Arena.of(head, x.dtype)
         ar.refresh_shadow()
         with ops.pin_stream():
             pre, t1, t2, mean, rstd = head._transform(ar, x, save, rd)
             logits, V = head._logits(ar, t2, rd)
             acc, lse = ops.ce_fwd(logits, V, labels, rows_dev=rd)
+        if label_sync is not None:
+            # data parallel: model.py:410 is a mean over the labelled tokens of the WHOLE batch.  label_sync all-reduces
+            # the 4-byte label count and returns N_global / world; dividing this rank's nll sum by it makes the rank
+            # average of the per-rank losses (and of their gradients: GradReducer averages) the global-batch mean.
+            acc = torch.cat([acc[:1], label_sync(acc[1:2])])
         loss = acc[0] / acc[1]          # mean over labelled positions (nan if none, as in torch)
         ctx.head = head
         ctx.saved = (ar, V, x, pre, t1, t2, mean, rstd, logits, labels, lse, acc, rd) if save else None
@@ -285,7 +290,7 @@ class _MlmLossFn(torch.autograd.Function):
             dlogits = ops.ce_bwd(logits, V, labels, lse, acc, grad_scale=1.0, grad_scale_dev=gs, rows_dev=rd)
             dx = ctx.head._backward_from_dlogits(ar, dlogits, V, x, pre, t1, t2, mean, rstd, rd)
         ctx.saved = None
-        return None, dx, None, None, None, None
+        return None, dx, None, None, None, None, None
 
 
 class _GatherRowsFn(torch.autograd.Function):
@@ -515,7 +520,8 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
             else:
                 x = text_out.reshape(B * T, H)
             mlm_loss = _MlmLossFn.apply(_token(head, dev), x.contiguous(), head,
-                                        sel_labels if (compact or lab_first) else labels, torch.is_grad_enabled(), rd)
+                                        sel_labels if (compact or lab_first) else labels, torch.is_grad_enabled(), rd,
+                                        self.__dict__.get("_mvlt_label_sync"))
             if compact:
                 mlm_loss = torch.where(valid.sum() > cap * B, torch.full_like(mlm_loss, float("nan")), mlm_loss)
             if packed:

@@ -3,8 +3,7 @@
 Two worker processes (tests/ddp_gpu_worker.py), one per GPU over RCCL when the box has >= 2 GPUs; on a one-GPU box
 the same two ranks share cuda:0 and exchange through gloo (RCCL refuses two ranks on one device), which still
 drives the real arena, the bucket launches during backward, the side-stream joins and the deferred LayerNorm
-reductions.  Expected value: the SUM over ranks of the per-rank gradients == one process running the two
-half-batches one after the other with gradient accumulation."""
+reductions.  Expected value: ONE process running the whole batch (global-batch loss semantics, model.py:410)."""
 import os
 import random
 import socket
@@ -20,21 +19,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_sum_equals_single_process_accumulation(tmp_path):
+def _run_two_ranks(tmp_path, average, overlap):
     ndev = torch.cuda.device_count()
     backend = "nccl" if ndev >= 2 else "gloo"
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    out = str(tmp_path / "grads.pt")
+    out = str(tmp_path / f"grads_{int(average)}{int(overlap)}.pt")
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), backend,
-                                       str(rank if ndev >= 2 else 0), out], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT, text=True))
+                                       str(rank if ndev >= 2 else 0), out, "1" if average else "0", "1" if overlap else "0"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
         try:
@@ -44,24 +43,40 @@ def test_two_ranks_sum_equals_single_process_accumulation(tmp_path):
             o, _ = p.communicate()
         logs.append(o)
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
-    ddp = torch.load(out)
-    # single process: the two half-batches one after the other, gradients accumulate like autograd
+    return torch.load(out)
+
+
+@pytest.mark.parametrize("average,overlap", [(False, False), (True, False), (True, True)])
+def test_two_ranks_equal_the_single_process_global_batch(tmp_path, monkeypatch, average, overlap):
+    """VERDICT r2 item 7 / ADVICE r2: the data-parallel step (per-rank shards of 2 samples, label-count all-reduce,
+    bucketed exchange with AVG or SUM, optionally the optimizer overlapped with the backward pass) equals ONE process
+    running the whole batch of 4: same loss (model.py:410 is a mean over the labelled tokens of the whole batch), same
+    gradients, same parameters after one AdamW step."""
+    ddp = _run_two_ranks(tmp_path, average, overlap)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import mvlt_amd as M
     from ddp_gpu_worker import build_model
     model = build_model(M)
     image, ids, labels, itm = synth_batch(4, 24, seed=71, vocab=3000)
-    random.random = lambda: 0.9
-    try:
-        for r in range(2):
-            sl = slice(2 * r, 2 * r + 2)
-            model(image[sl].cuda(), ids[sl].cuda(), labels[sl].cuda(), itm[sl].cuda()).backward()
-    finally:
-        import importlib
-        importlib.reload(random)
+    monkeypatch.setattr(random, "random", lambda: 0.9)
+    batch = (image.cuda(), ids.cuda(), labels.cuda(), itm.cuda())
+    if overlap:
+        from mvlt_amd.train import PretrainStep
+        loss = PretrainStep(model, lr=1e-3)(batch)
+    else:
+        loss = model(*batch)
+        loss.backward()
     torch.cuda.synchronize()
     ref = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
-    assert ref.keys() == ddp.keys() and len(ref) > 150
-    bad = [(k, rel_err(ddp[k], ref[k])) for k in ref
-           if rel_err(ddp[k], ref[k]) > 2e-4 and not k.endswith("key.bias") and ref[k].abs().max() > 1e-9]
+    scale = 1.0 if average else 2.0          # SUM over 2 ranks of gradients of (W S_r / N) = 2 x the global-batch gradient
+    # rank 0's loss is W S_0 / N; the rank average is the global value -- here only its finiteness and scale are checkable
+    assert ddp["loss"] == ddp["loss"] and abs(ddp["loss"]) < 50
+    g = ddp["grads"]
+    assert ref.keys() == g.keys() and len(ref) > 150
+    bad = [(k, rel_err(g[k], ref[k] * scale)) for k in ref
+           if rel_err(g[k], ref[k] * scale) > 2e-4 and not k.endswith("key.bias") and ref[k].abs().max() > 1e-9]
     assert not bad, bad[:10]
+    if overlap:
+        after = {k: p.detach().cpu() for k, p in model.named_parameters()}
+        badp = [(k, rel_err(ddp["params_after"][k], after[k])) for k in after if rel_err(ddp["params_after"][k], after[k]) > 1e-5]
+        assert not badp, badp[:10]
