@@ -1084,14 +1084,17 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
     long tiles = 0;
     int kmin = items[0].K;
     for (int i = 0; i < n; ++i) { tiles += (long)ceil_div(items[i].M, bm) * ceil_div(items[i].N, bn); kmin = items[i].K < kmin ? items[i].K : kmin; }
-    // In-launch split-K (experiment, MVLT_GROUP_SPLIT=n, or 0 = automatic): the output tiles are cut into k-slices that
-    // meet in the zeroed f32 output through atomicAdd.  OFF by default: measured on the B=32 step it does not shorten
-    // the stage-2 groups in situ (160 us either way -- beside the dgrad chain their duration is set by the CU share
-    // they get, not by their own k-depth) and the zeroing launch + atomics cost 1 ms per step (17.1 vs 15.9 ms).
+    // In-launch split-K: groups with fewer than 200 tiles (Swin stages 0/1: 21 / 72 tiles, 100k / 25k reduction rows) are
+    // cut into k-slices AUTOMATICALLY (MVLT_GROUP_SPLIT=n forces n slices for any group); the slices meet in the zeroed f32
+    // output through atomicAdd.  Groups with >= 200 tiles are never split: measured on the B=32 step it does not shorten
+    // the stage-2 groups in situ and the zeroing launch + atomics cost 1 ms per step (17.1 vs 15.9 ms).
     const int bke = 128 / (int)sizeof(T);
     int split = 1;
     const char* ov_split = getenv("MVLT_GROUP_SPLIT");
-    if (ov_split || tiles < 200) {
+    // the k-slices meet through f32 atomicAdd: the order of the 7-24 additions per element is not fixed, so the result is
+    // not bit-reproducible run to run.  Never in the exact-f32 mode (the parity path), never under MVLT_DETERMINISTIC=1.
+    static const bool deterministic = [] { const char* e = getenv("MVLT_DETERMINISTIC"); return e && e[0] == '1'; }();
+    if ((ov_split || tiles < 200) && sizeof(T) == 2 && !deterministic) {
         const int v = ov_split ? atoi(ov_split) : 0;
         if (v >= 1) split = v;
         else if (tiles < (ov_split ? 384 : 200)) {

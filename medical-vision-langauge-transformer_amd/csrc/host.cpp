@@ -183,8 +183,12 @@ void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws, con
     if (bn) for (auto& it : items) tiles += ((it.dy->size(1) + 63) / 64) * ((it.x->size(1) + bn - 1) / bn);
     const int dtype = dtype_of(*items[0].dy);
     static const long long_k = [] { const char* e = getenv("MVLT_GROUP_LONG_K"); return e ? atol(e) : 8192L; }();
-    // few tiles but a long reduction (Swin stages 0/1): still one launch, cut into k-slices inside mvlt_gemm_group
-    if (!(n > 1 && n <= 8 && bn && (tiles >= 200 || items[0].dy->size(0) >= long_k))) {
+    // few tiles but a long reduction (Swin stages 0/1): still one launch, cut into k-slices inside mvlt_gemm_group -- bf16
+    // only and not under MVLT_DETERMINISTIC=1 (the slices meet through float atomics; the exact-f32 parity mode and the
+    // deterministic mode take split-K slabs + the deterministic reduce kernel, one product at a time)
+    static const bool deterministic = [] { const char* e = getenv("MVLT_DETERMINISTIC"); return e && e[0] == '1'; }();
+    const bool slices_ok = dtype == MVLT_BF16 && !deterministic;
+    if (!(n > 1 && n <= 8 && bn && (tiles >= 200 || (slices_ok && items[0].dy->size(0) >= long_k)))) {
         for (auto& it : items) {
             Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db); e.m_dev = k_dev;
             gemm(dtype, (int)it.dy->size(1), (int)it.x->size(1), (int)it.dy->size(0), dp(*it.dy), it.dy->size(1), true,

@@ -339,6 +339,9 @@ def layernorm_acc_fwd(acc, bias, residual, gamma, beta, eps, dtype, out=None):
 
 
 _GROUP_LONG_K = int(os.environ.get("MVLT_GROUP_LONG_K", "8192"))
+# MVLT_DETERMINISTIC=1: no float atomics on the training / decoding path (Swin stage-0/1 weight gradients take split-K
+# slabs + the deterministic reduce instead of atomic k-slices; greedy decoding does not split its reductions)
+DETERMINISTIC = os.environ.get("MVLT_DETERMINISTIC", "0") == "1"
 
 
 def wgrad_group(items):
@@ -356,7 +359,8 @@ def wgrad_group(items):
     bn = 128 if all(x.shape[1] % 128 == 0 for _, x, _, _ in items) else (96 if all(x.shape[1] % 96 == 0 for _, x, _, _ in items) else 0)
     tiles = sum(((dy.shape[1] + 63) // 64) * ((x.shape[1] + bn - 1) // bn) for dy, x, _, _ in items) if bn else 0
     # few tiles but a long reduction (Swin stages 0/1): still one launch, cut into k-slices inside mvlt_gemm_group
-    if not (1 < n <= 8 and bn and (tiles >= 200 or items[0][0].shape[0] >= _GROUP_LONG_K)):
+    slices_ok = items[0][0].dtype == torch.bfloat16 and not DETERMINISTIC      # k-slices meet through float atomics
+    if not (1 < n <= 8 and bn and (tiles >= 200 or (slices_ok and items[0][0].shape[0] >= _GROUP_LONG_K))):
         for dy, x, dw, db in items:
             gemm(dy, x, a_kmajor=True, b_kmajor=True, out=dw, out_f32=True, a_colsum=db, m_dev=m_dev)
         return
