@@ -582,7 +582,9 @@ constexpr int SKINNY_WAVES = 8, SKINNY_UNROLL = 3;
 // finishes the rows.  The maximum is taken over the f32 accumulators (+ bias).
 struct ArgmaxOut { float* part_val; int* part_idx; };
 template <typename T, bool ARGMAX = false>
-__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const GemmDev p, const ArgmaxOut am) {
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const GemmDev p_in, const ArgmaxOut am) {
+    const GemmDev p = effective<false>(p_in);          // ragged row counts (m_dev): rows beyond it are neither read nor written
+    if (p.M <= 0) return;
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
     constexpr int KB = M_::KB, E = TypeInfo<T>::E;
@@ -774,7 +776,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDev p_in) {
     __shared__ f32x4 red[4][64];
     GemmDev p = p_in;
-    if (p.m_dev && p.rowmap == nullptr && !p_in.a_colsum) p.M = min(p.M, max(*p.m_dev, 0));   // (never for weight gradients)
+    // m_dev counts the rows of a k-contiguous A (= rows of the output): slab rows beyond it were never written.  For a k-major
+    // A (weight gradients) it is the reduction length and the output keeps all M rows.
+    if (p.m_dev && !p.a_kmajor) p.M = min(p.M, max(*p.m_dev, 0));
     const int nq = (p.N + 3) / 4;
     const long total = (long)p.M * nq;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -918,6 +922,7 @@ static int fill_dev(const MvltGemm* p, const Plan& pl, GemmDev& d) {
     d.pf = (p->prefetch && p->prefetch_bytes >= 128) ? reinterpret_cast<const char*>(p->prefetch) : nullptr;
     d.pf_lines = d.pf ? (long)(p->prefetch_bytes >> 7) : 0;
     d.m_dev = p->m_dev;
+    d.a_kmajor = p->a_kmajor != 0;
     d.atomic_out = 0;
     d.ws_colsum = d.ws ? d.ws + (size_t)d.split_k * p->M * p->N : nullptr;
     d.a_vec = (p->lda % E == 0) && aligned16(p->A);
@@ -976,7 +981,8 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
             }
         }
         static const int glds_mode = [] { const char* e = getenv("MVLT_GLDS"); return e ? atoi(e) : 2; }();
-        const bool glds_on = glds_mode == 1 || (glds_mode == 2 && pl.bm == 64);
+        // 3: as 2, plus the 128 x 128 tiles of k-major-B products (wide dgrads)
+        const bool glds_on = glds_mode == 1 || (glds_mode >= 2 && pl.bm == 64) || (glds_mode == 3 && bk);
         const int kspan = d.split_k > 1 ? d.k_per_split : p->K;
         const bool bkm_ok = !bk || ((pl.bn == 64 || pl.bn == 128) && p->N % 8 == 0 && p->N >= 8);
         if (glds_on && !ak && bkm_ok && p->K % 64 == 0 && kspan % 64 == 0 && d.a_vec && d.b_vec) {

@@ -494,16 +494,24 @@ int g8_dispatch(const G8Group& gp, bool akm, bool bkm, int epi, long tiles, hipS
     return 0;
 }
 
-// tile shape for a list of products: 0 = not worth it (the 4-wave kernels of gemm.hip take it)
-int g8_choose(const GemmDev* d, int n, long* tiles_out) {
+// tile shape for a list of products: 0 = not worth it (the 4-wave kernels of gemm.hip take it).
+// big_only (the automatic mode): 256 x 256 tiles for products that fill the chip with them AND either have a long
+// reduction (>= 24 K-tiles: the ~16 us of launch + first loads + store tail are amortised; 4096^3: 1.3 PFLOP/s against
+// 0.78 for the 4-wave kernel) or several tiles per CU.  The B = 32 step's own mid-size products (BERT FFN: 156-204 tiles,
+// 12 K-tiles) stay on the 4-wave kernels: standalone the engine is 15 % faster there, inside the step it is slower --
+// one 8-wave workgroup owns a CU's whole LDS, so the weight-gradient stream cannot share the CU with it.
+int g8_choose(const GemmDev* d, int n, bool big_only, long* tiles_out) {
     long t22 = 0, t12 = 0;
+    int kmin = d[0].K;
     for (int i = 0; i < n; ++i) {
         t22 += (long)ceil_div(d[i].M, 256) * ceil_div(d[i].N, 256);
         t12 += (long)ceil_div(d[i].M, 128) * ceil_div(d[i].N, 256);
+        kmin = d[i].K < kmin ? d[i].K : kmin;
     }
     int mode = 0;
     if (const char* e = getenv("MVLT_G8_TILE")) mode = atoi(e);          // experiments: 22 / 12 force a shape
-    else if (t22 >= 400) mode = 22;          // (by the host-side bound of M: a ragged batch fills ~3/4 of it)
+    else if (big_only) mode = (t22 >= 400 || (t22 >= 200 && kmin >= 1536)) ? 22 : 0;
+    else if (t22 >= 200) mode = 22;
     else if (t12 >= 96) mode = 12;
     *tiles_out = mode == 22 ? t22 : t12;
     return mode;
@@ -585,8 +593,7 @@ extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* 
     gp.zero_page = g8_zero_ptr();
     if (a_kmajor && !gp.zero_page) return 0;
     long tiles = 0;
-    const int mode = g8_choose(d, n, &tiles);
-    if (big_only && mode != 22) return 0;                 // automatic mode: only products that fill the chip with 256 x 256 tiles
+    const int mode = g8_choose(d, n, big_only != 0, &tiles);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (mode == 22) return g8_dispatch<2, 2>(gp, a_kmajor != 0, b_kmajor != 0, d[0].epi, tiles, s);
     if (mode == 12) return g8_dispatch<1, 2>(gp, a_kmajor != 0, b_kmajor != 0, d[0].epi, tiles, s);

@@ -19,6 +19,7 @@ struct GemmDev {
     const char* pf; long pf_lines;       // optional: 128-byte lines of the next product's weights to pull towards the caches
     const int* m_dev;                    // optional: valid storage rows of A on the device (MvltGemm.m_dev)
     int atomic_out;                      // grouped weight gradients with in-launch split-K: f32 atomicAdd onto zeroed C
+    int a_kmajor;                        // A is k-major (weight gradients): m_dev then limits the reduction, not the rows
 };
 
 // Ragged batches planned on the GPU: the launch is sized for the upper bound, the kernel reads the real count.

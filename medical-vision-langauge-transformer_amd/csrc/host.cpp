@@ -21,6 +21,17 @@ namespace {
 using at::Tensor;
 using Ptrs = std::vector<int64_t>;
 
+// The scratch buffers, the deferred LayerNorm queue, the event pool and the keep-alive list below are process-global, i.e.
+// they belong to ONE device (one process per GPU): a second device in the same process would share
+// them.  Every native entry point checks that it is still on the device the first call ran on.
+int g_device = -1;
+inline void check_device(const at::Tensor& t) {
+    const int d = (int)t.get_device();
+    if (g_device < 0) g_device = d;
+    TORCH_CHECK(d == g_device, "mvlt_amd: the native host path holds per-process scratch for cuda:", g_device,
+                " but was called with a tensor on cuda:", d, " (one process per GPU; MVLT_NATIVE_HOST=0 has no such state)");
+}
+
 inline void ck(int rc, const char* what) { TORCH_CHECK(rc == MVLT_OK, "mvlt_amd: ", what, " failed with status ", rc); }
 inline int dtype_of(const Tensor& t) {
     if (t.scalar_type() == at::kFloat) return MVLT_F32;
@@ -282,6 +293,7 @@ void fill_attn(MvltAttn& p, const Tensor& qkv, const AttnArgs& a, int H, void* o
 std::vector<Tensor> bert_layer_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f, int64_t H, int64_t I, double eps,
                                    const Ptrs& attn, double p_h, double p_a, int64_t seed, int64_t layer, bool save,
                                    int64_t stream_) {
+    check_device(x);
     void* st = P(stream_);
     const int64_t rows = x.size(0);
     AttnArgs a{(int)attn[0], (int)attn[1], (int)attn[2], (int)attn[3], attn[4], (int)attn[5], attn[6], (int)attn[7], attn[8], attn[9]};
@@ -317,6 +329,7 @@ std::vector<Tensor> bert_layer_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f
 Tensor bert_layer_bwd(const Tensor& dx, const std::vector<Tensor>& sv, const Ptrs& w, const Ptrs& f, const Ptrs& g, int64_t H,
                       int64_t I, const Ptrs& attn, double p_h, double p_a, int64_t seed, int64_t layer, int64_t stream_,
                       int64_t side_) {
+    check_device(dx);
     Streams ss{P(stream_), P(side_)};
     void* st = ss.main;
     const Tensor &x = sv[0], &qkv = sv[1], &ctx = sv[2], &lse = sv[3], &y1 = sv[4], &st1 = sv[5], &x1 = sv[6], &h = sv[7],
@@ -361,6 +374,7 @@ Tensor bert_layer_bwd(const Tensor& dx, const std::vector<Tensor>& sv, const Ptr
 // geo: [B, H(res), C, nH, shift, fused]; maps: [w2n, n2w] int32 device pointers; s1/s2: DropPath scales f32 [B] or 0
 std::vector<Tensor> swin_block_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f, const Ptrs& geo, const Ptrs& maps, double scale,
                                    double eps, int64_t s1, int64_t s2, bool save, int64_t stream_) {
+    check_device(x);
     void* st = P(stream_);
     const int B = (int)geo[0], res = (int)geo[1], C = (int)geo[2], nH = (int)geo[3], shift = (int)geo[4];
     const bool fused = geo[5] != 0;
@@ -414,6 +428,7 @@ std::vector<Tensor> swin_block_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f
 // sv = [x, stat1, xn1w, qkv, ao, lse, x1, stat2, xn2, h, act]
 Tensor swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>& sv, const Ptrs& w, const Ptrs& f, const Ptrs& g, const Ptrs& geo,
                       const Ptrs& maps, double scale, int64_t s1, int64_t s2, int64_t stream_, int64_t side_) {
+    check_device(dx2);
     Streams ss{P(stream_), P(side_)};
     void* st = ss.main;
     const Tensor &x = sv[0], &stat1 = sv[1], &xn1w = sv[2], &qkv = sv[3], &ao = sv[4], &lse = sv[5], &x1 = sv[6], &stat2 = sv[7],

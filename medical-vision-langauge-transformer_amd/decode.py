@@ -48,6 +48,8 @@ def _layers_cached(mv, ar, x, kc, vc, past, n_new):
         acc = ar._views.get(key)
         if acc is None:
             acc = ar._views[key] = torch.zeros((rows, H), dtype=torch.float32, device=x.device)
+        elif not torch.cuda.is_current_stream_capturing():
+            acc.zero_()          # a step that aborted between an accumulate and its LayerNorm left partial sums behind
     for i, layer in enumerate(mv.encoder.layer):
         sa, so = layer.attention.self, layer.attention.output
         qkv = ops.gemm(x, ar.compute(sa.query.weight, 3 * H), bias=ar.master_span(sa.query.bias, 3 * H))

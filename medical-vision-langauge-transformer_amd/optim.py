@@ -51,6 +51,7 @@ class FusedAdamW:
                         ar.steps[pid] = old.steps[pid]
                 old.exp_avg = old.exp_avg_sq = None
             self._arena = ar
+            self.__dict__["_plans"] = {}          # cached (lo, hi) sweep ranges are offsets into the OLD arena layout
             if self._overlap is not None:
                 self._hook(ar)
         return ar

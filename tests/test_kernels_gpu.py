@@ -76,6 +76,110 @@ def test_gemm_splitk_wgrad_shape(ops, dt, split):
     assert rel(out2, 2 * ref) < (1e-5 if dt == torch.float32 else 2e-3)
 
 
+# ------------------------------------------------------------------ 8-wave ping-pong engine (csrc/gemm8.hip)
+def _g8(monkeypatch, tile):
+    """MVLT_G8=1: every eligible product goes to the engine; MVLT_G8_TILE forces the tile shape (22 = 256 x 256,
+    12 = 128 x 256).  Both are read per call by the library."""
+    monkeypatch.setenv("MVLT_G8", "1")
+    monkeypatch.setenv("MVLT_G8_TILE", str(tile))
+
+
+@pytest.mark.parametrize("tile", [22, 12])
+@pytest.mark.parametrize("bk", [False, True])
+@pytest.mark.parametrize("M,N,K", [(700, 520, 192), (257, 256, 128), (1000, 1032, 320)])
+def test_gemm8_layouts_and_ragged_edges(ops, monkeypatch, tile, bk, M, N, K):
+    """x W^T (forward) and dy W (dgrad: k-major B through transposing LDS reads) on shapes whose edges cut tiles, several
+    tiles per workgroup list, vs torch in f32; plus the device-side row count (rows beyond it are not written)."""
+    _g8(monkeypatch, tile)
+    A = rnd((M, K), torch.bfloat16, 1, 0.5)
+    B = rnd((K, N) if bk else (N, K), torch.bfloat16, 2, 0.5)
+    ref = A.float() @ (B.float() if bk else B.float().t())
+    out = ops.gemm(A, B, b_kmajor=bk)
+    assert rel(out, ref) < tol(torch.bfloat16)
+    m_dev = torch.tensor([M - 133], dtype=torch.int32, device="cuda")
+    o2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(A, B, b_kmajor=bk, out=o2, m_dev=m_dev)
+    assert rel(o2[: M - 133], ref[: M - 133]) < tol(torch.bfloat16) and float(o2[M - 133:].abs().max()) == 0.0
+
+
+def test_gemm8_asymmetric_integer_exact(ops, monkeypatch):
+    """A = I-like, asymmetric B: catches row <-> column swaps and k-slot permutations of either operand path."""
+    _g8(monkeypatch, 22)
+    M, N, K = 256, 256, 128
+    A = torch.zeros(M, K)
+    A[torch.arange(M), torch.arange(M) % K] = 1.0
+    B = (torch.arange(N * K).reshape(N, K) % 7 - 3).float() + (torch.arange(N)[:, None] % 5).float()
+    out = ops.gemm(A.bfloat16().cuda(), B.bfloat16().cuda())
+    assert torch.equal(out.float().cpu(), A @ B.t())
+    out = ops.gemm(A.bfloat16().cuda(), B.t().contiguous().bfloat16().cuda(), b_kmajor=True)
+    assert torch.equal(out.float().cpu(), A @ B.t())
+
+
+@pytest.mark.parametrize("tile", [22, 12])
+def test_gemm8_epilogue_classes(ops, monkeypatch, tile):
+    """Every epilogue flag set the engine instantiates (forward: bias / + GELU / + saved pre-activation; dgrad: GELU'
+    or residual), against torch; any other flag set must fall back to the 4-wave kernels with the same result."""
+    _g8(monkeypatch, tile)
+    dt = torch.bfloat16
+    M, N, K = 600, 512, 192
+    A, W = rnd((M, K), dt, 5, 0.5), rnd((N, K), dt, 6, 0.2)
+    bias = rnd((N,), torch.float32, 7)
+    res = rnd((M, N), dt, 8)
+    base = A.float() @ W.float().t() + bias
+    assert rel(ops.gemm(A, W, bias=bias), base) < tol(dt)
+    assert rel(ops.gemm(A, W, bias=bias, gelu=True), F.gelu(base)) < tol(dt)
+    pre = torch.empty((M, N), dtype=dt, device="cuda")
+    out = ops.gemm(A, W, bias=bias, gelu=True, save_pre=pre)
+    assert rel(pre, base) < tol(dt) and rel(out, F.gelu(base)) < tol(dt)
+    # fallback class (dropout + residual is not instantiated in the engine)
+    out = ops.gemm(A, W, bias=bias, dropout=(0.1, 1234, 77), residual=res)
+    keep = ops.dropout_mask(M * N, 0.1, 1234, 77, A.device).view(M, N).float()
+    assert rel(out, res.float() + base * keep / 0.9) < tol(dt)
+    # dgrad classes
+    h = rnd((M, K), dt, 9)
+    dY = rnd((M, N), dt, 10, 0.5)
+    Wk = rnd((N, K), dt, 12, 0.2)                  # [K_red = N, K] k-major B
+    out = ops.gemm(dY, Wk, b_kmajor=True, mul_gelu_grad=h)
+    hf = h.float().requires_grad_(True)
+    F.gelu(hf).backward(dY.float() @ Wk.float())
+    assert rel(out, hf.grad) < tol(dt)
+    r2 = rnd((M, K), dt, 13)
+    assert rel(ops.gemm(dY, Wk, b_kmajor=True, residual=r2), dY.float() @ Wk.float() + r2.float()) < tol(dt)
+
+
+@pytest.mark.parametrize("tile", [22, 12])
+def test_gemm8_weight_gradient_group_with_stale_rows(ops, monkeypatch, tile):
+    """All dW_i = dY_i^T X_i of one BertLayer as ONE persistent launch of the engine (both operands k-major, f32 output,
+    bias gradients by the grouped column-sum kernel), with the reduction length on the device and NaN / Inf in the rows
+    beyond it (the activation buffers are allocated for the dense bound: stale rows must not matter)."""
+    _g8(monkeypatch, tile)
+    dt = torch.bfloat16
+    R, valid = 1400, 1237
+    widths = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    k_dev = torch.tensor([valid], dtype=torch.int32, device="cuda")
+    items, refs = [], []
+    for i, (no, ni) in enumerate(widths):
+        dy, x = rnd((R, no), dt, 10 + i, 0.5), rnd((R, ni), dt, 20 + i, 0.5)
+        dy[valid:] = float("nan"); x[valid:] = float("inf")
+        dw, db = torch.zeros(no, ni, device="cuda"), torch.zeros(no, device="cuda")
+        items.append((dy, x, dw, db, k_dev))
+        refs.append((dy[:valid].float().t() @ x[:valid].float(), dy[:valid].float().sum(0)))
+    ops.wgrad_group(items)
+    for (dy, x, dw, db, _), (rw, rb) in zip(items, refs):
+        assert rel(dw, rw) < 2e-5 and rel(db, rb) < 2e-5
+
+
+def test_gemm8_automatic_mode_takes_only_big_products(ops, monkeypatch):
+    """Default (MVLT_G8 unset): mvlt_gemm_plan-independent check through results -- a 4096^3 product and a step-sized
+    one both come out right whichever kernel family the heuristic picks (the choice itself is printed by
+    scripts/g8_check.py; DESIGN.md section 3 says why the step's own products stay on the 4-wave kernels)."""
+    monkeypatch.delenv("MVLT_G8", raising=False)
+    monkeypatch.delenv("MVLT_G8_TILE", raising=False)
+    for M, N, K in [(4096, 4096, 2048), (3090, 3072, 768)]:
+        A, B = rnd((M, K), torch.bfloat16, 3, 0.5), rnd((N, K), torch.bfloat16, 4, 0.5)
+        assert rel(ops.gemm(A, B), A.float() @ B.float().t()) < tol(torch.bfloat16)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_epilogues(ops, dt):
     M, N, K = 300, 192, 96
