@@ -303,7 +303,8 @@ def main():
     seed_coin_flip(5678)                            # seq2seq/bidir flip identical on all ranks
     # MVLT_DDP_BF16=1: bf16-compressed gradient exchange (non-default; the reference-equivalent sum is f32)
     comm = torch.bfloat16 if os.environ.get("MVLT_DDP_BF16") == "1" else torch.float32
-    reducer = GradReducer(model, comm_dtype=comm) if use_dist else None
+    bucket_mb = int(os.environ.get("MVLT_DDP_BUCKET_MB", "64"))
+    reducer = GradReducer(model, comm_dtype=comm, bucket_bytes=bucket_mb << 20) if use_dist else None
     step = PretrainStep(model, reducer=reducer, world_size=world)
     batch_full = synthetic_batch(PER_GPU_BATCH, SEQ, "cuda", 1234 + rank, with_lengths=True)
     batch = batch_full[:4]                          # the reference signature: no caption lengths

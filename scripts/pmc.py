@@ -24,12 +24,18 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--match", default="")
     ap.add_argument("--passes", default="sq1,fetch,write")
+    ap.add_argument("--family", action="append", default=[], help="name=regex: also print launch-weighted means over all "
+                    "kernels whose name matches (e.g. family='gemm_kernel|gemm_glds_kernel|gemm8_kernel')")
+    ap.add_argument("--json", default="", help="write the family aggregates to this file")
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
     os.makedirs(a.out, exist_ok=True)
     dur = collections.defaultdict(list)
     ctr = collections.defaultdict(lambda: collections.defaultdict(list))
+    fams = [f.split("=", 1) for f in a.family]
+    fam_ctr = {n: collections.defaultdict(list) for n, _ in fams}
+    fam_dur = {n: [] for n, _ in fams}
     for name in a.passes.split(","):
         d = os.path.join(a.out, name)
         r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", *PASSES[name].split(), "--output-format", "csv",
@@ -50,6 +56,12 @@ def main():
                 key = (re.sub(r"_ZN12_GLOBAL__N_1\d+", "", kn)[:70], int(row["Grid_Size"]) if "Grid_Size" in row else 0)
                 ctr[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
                 did = row["Dispatch_Id"]
+                for fn, rx in fams:
+                    if re.search(rx, kn):
+                        fam_ctr[fn][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                        if did in disp and (name, fn, did) not in seen:
+                            seen.add((name, fn, did))
+                            fam_dur[fn].append(disp[did][1])
                 if did in disp and (name, did) not in seen:
                     seen.add((name, did))
                     dur[key].append(disp[did][1])
@@ -64,6 +76,31 @@ def main():
         mf = ctr[key].get("SQ_VALU_MFMA_BUSY_CYCLES")
         if mf and med > 0:
             print(f"   MFMA-busy fraction = {sum(mf) / len(mf) / (1024 * med * 1e-6 * 2.4e9):.4f}")
+    out = {}
+    for fn, rx in fams:
+        c = fam_ctr[fn]
+        n = max((len(v) for v in c.values()), default=0)
+        if not n:
+            continue
+        mean = {k: sum(v) / len(v) for k, v in c.items()}
+        ds = fam_dur[fn]
+        avg_us = sum(ds) / len(ds) if ds else 0.0
+        # MI355X_MICROARCH.md, HBM: FETCH_SIZE counts 64 B per 128-B request of wide streaming reads on gfx950 -> x2;
+        # WRITE_SIZE is exact for 16-B-per-lane streaming stores and float atomics.  rocprofv3 reports both in KiB.
+        fetch = mean.get("FETCH_SIZE"); write = mean.get("WRITE_SIZE")
+        traffic = None
+        if fetch is not None and write is not None:
+            traffic = int(2 * fetch * 1024 + write * 1024)
+        out[fn] = {"regex": rx, "profiled_launches": n, "avg_launch_us_profiled": round(avg_us, 2),
+                   "counters_mean_per_launch": {k: round(v, 1) for k, v in mean.items()},
+                   "traffic_bytes_per_launch": traffic,
+                   "traffic_formula": "2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 correction of MI355X_MICROARCH.md"}
+        print(f"== FAMILY {fn} ({rx}): {n} launches, mean {avg_us:.1f} us, " + ", ".join(f"{k}={v:.1f}" for k, v in mean.items())
+              + (f", traffic {traffic / 1e6:.1f} MB/launch" if traffic else ""))
+    if a.json and out:
+        import json
+        with open(a.json, "w") as fh:
+            json.dump(out, fh, indent=1)
 
 
 if __name__ == "__main__":
