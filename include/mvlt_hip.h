@@ -36,7 +36,7 @@ enum { MVLT_OK = 0, MVLT_ERR_ARG = -1, MVLT_ERR_LAUNCH = -2, MVLT_ERR_UNSUPPORTE
  * signature; a binding compiles / hard-codes the value it was written against and compares it with what the
  * loaded library returns.  mvlt_sizeof(MVLT_STRUCT_*) lets a binding that mirrors the structs by hand (ctypes,
  * cgo, JNI) prove that its mirror has the size the library was compiled with (0 for an unknown id). */
-#define MVLT_ABI_VERSION 2
+#define MVLT_ABI_VERSION 3
 int mvlt_version(void);            /* MVLT_ABI_VERSION of the loaded library */
 const char* mvlt_arch(void);       /* "gfx950" */
 enum { MVLT_STRUCT_GEMM = 0, MVLT_STRUCT_LAYERNORM = 1, MVLT_STRUCT_LAYERNORM_BWD = 2, MVLT_STRUCT_LN_REDUCE_ITEM = 3,
@@ -108,6 +108,10 @@ int mvlt_gemm_plan(const MvltGemm* p, int* bm, int* bn, int* split_k);
  * lists are concatenated (gemm_group_kernel<dtype,64,bn>), no split-K, no workspace.
  * MVLT_ERR_UNSUPPORTED if the items do not qualify (launch them one by one then). */
 int mvlt_gemm_group(const MvltGemm* items, int n, void* stream);
+/* Optional workspace of a grouped launch: put it into items[0].workspace / workspace_bytes.  With it, groups with fewer
+ * output tiles than CUs (every weight-gradient group of the B = 32 step) are cut into k-slices that meet through f32
+ * slabs inside the one launch (the last arriver of a tile sums the slices in slice order: deterministic, no atomics). */
+size_t mvlt_gemm_group_workspace_bytes(const MvltGemm* items, int n);
 /* Last-row MLM head fused with the greedy pick (model.py:896-900): out_idx[m] = argmax_n (A W^T + bias)[m, n]
  * (first index on ties), out_val[m] = that maximum (f32, may be NULL); the logits are never stored.  M <= 64,
  * both operands k-contiguous (MVLT_ERR_UNSUPPORTED otherwise); only MVLT_EPI_BIAS is honoured; C is unused.

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmvlt_hip.so")
 
 F32, BF16 = 0, 1
 OK = 0
-ABI_VERSION = 2          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
+ABI_VERSION = 3          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
 ERRORS = {-1: "MVLT_ERR_ARG", -2: "MVLT_ERR_LAUNCH", -3: "MVLT_ERR_UNSUPPORTED"}
 
 EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_DROPOUT = 1, 2, 4, 8
@@ -118,6 +118,7 @@ SYMBOLS = {
     "mvlt_gemm_workspace_bytes": (sz, [C.POINTER(MvltGemm)]),
     "mvlt_gemm_plan": (i32, [C.POINTER(MvltGemm), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "mvlt_gemm_group": (i32, [C.POINTER(MvltGemm), i32, vp]),
+    "mvlt_gemm_group_workspace_bytes": (sz, [C.POINTER(MvltGemm), i32]),
     "mvlt_gemm_argmax": (i32, [C.POINTER(MvltGemm), vp, vp, vp, vp, vp]),
     "mvlt_gemm_skinny_accum": (i32, [C.POINTER(MvltGemm), vp, i32, vp]),
     "mvlt_layernorm_acc_fwd": (i32, [i32, vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]),

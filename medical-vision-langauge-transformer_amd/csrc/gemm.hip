@@ -16,8 +16,9 @@
 #include <cstdlib>
 
 // gemm8.hip: 8-wave ping-pong kernel; takes the filled kernel argument block, returns 1 if it launched
-extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* dev_blocks, int n, int a_kmajor, int b_kmajor, int big_only, void* stream);
-extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_colsum(const void* dev_blocks, float* const* outs, int n, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* dev_blocks, int n, int a_kmajor, int b_kmajor, int big_only,
+                                                                    float* const* colsum, void* ws, size_t ws_bytes, void* stream);
+extern "C" __attribute__((visibility("hidden"))) size_t mvlt_gemm8_group_workspace(const void* dev_blocks, int n);
 // MVLT_G8: unset / 2 = automatic (single products that fill the chip with 256 x 256 tiles: MLM decoder, large batches),
 // 0 = never, 1 = wherever it is eligible, weight-gradient groups included (experiments: slower than the 4-wave kernels on
 // the B=32 step's mid-size products)
@@ -955,7 +956,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // 8-wave ping-pong engine (gemm8.hip) for wide outputs: MVLT_G8 = 0 never / 1 wherever it is eligible
         if (g8_mode() && !ak && d.split_k <= 1) {
-            const int rc8 = mvlt_gemm8_try(&d, 1, 0, bk ? 1 : 0, g8_mode() == 2, s);
+            const int rc8 = mvlt_gemm8_try(&d, 1, 0, bk ? 1 : 0, g8_mode() == 2, nullptr, nullptr, 0, s);
             if (rc8 < 0) return MVLT_ERR_LAUNCH;
             if (rc8 > 0) {
                 if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
@@ -1062,23 +1063,6 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
         Plan pl{64, bn, 1};
         { const int rc = fill_dev<T>(p, pl, g.g[i]); if (rc != MVLT_OK) return rc; }
     }
-    // 8-wave ping-pong engine: the whole group as one persistent launch of 128/256 x 256 tiles, bias gradients beside it
-    if constexpr (sizeof(T) == 2) {
-        if (g8_mode() == 1) {
-            GemmDev tmp[GROUP_MAX];
-            float* outs[GROUP_MAX];
-            bool ok = true;
-            for (int i = 0; i < n; ++i) {
-                tmp[i] = g.g[i]; outs[i] = tmp[i].a_colsum; tmp[i].a_colsum = nullptr;
-                ok = ok && tmp[i].epi == MVLT_EPI_OUT_F32 && tmp[i].M % 4 == 0 && tmp[i].lda % 4 == 0;
-            }
-            if (ok) {
-                const int rc8 = mvlt_gemm8_try(tmp, n, 1, 1, 0, s);
-                if (rc8 < 0) return MVLT_ERR_LAUNCH;
-                if (rc8 > 0) return mvlt_gemm8_colsum(tmp, outs, n, s) > 0 ? MVLT_OK : MVLT_ERR_LAUNCH;
-            }
-        }
-    }
     // 128-row tiles when they still give every CU a workgroup (half the LDS fragment traffic per MFMA)
     int bm = 64;
     if (bn == 128) {
@@ -1109,6 +1093,28 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
             if (split > nkt / 8) split = nkt / 8;
             if (split > 64) split = 64;
             if (split < 1) split = 1;
+        }
+    }
+    // 8-wave ping-pong engine (gemm8.hip) for the groups this kernel would cut into ATOMIC k-slices (few tiles, tens of
+    // thousands of reduction rows: Swin stages 0 / 1): one persistent launch of 128 x 128 tiles, k-slices that meet through
+    // f32 slabs (the last arriver of a tile sums them in slice order: deterministic, no float atomics), bias gradients as
+    // dY^T . 1 on the matrix pipe -- 100 vs 137 us (stage 0) and 78 vs 91 us (stage 1) per group.  MVLT_G8=1 sends every
+    // group there (experiments: the BertLayer / stage-2 groups tie with this kernel), MVLT_G8_GROUP=0 none.
+    if constexpr (sizeof(T) == 2) {
+        static const bool g8_groups = [] { const char* e = getenv("MVLT_G8_GROUP"); return !(e && e[0] == '0'); }();
+        if (g8_groups && g8_mode() && (g8_mode() == 1 || split > 1 || (tiles < 200 && !ov_split))) {
+            GemmDev tmp[GROUP_MAX];
+            float* outs[GROUP_MAX];
+            bool ok = true;
+            for (int i = 0; i < n; ++i) {
+                tmp[i] = g.g[i]; outs[i] = tmp[i].a_colsum; tmp[i].a_colsum = nullptr;
+                ok = ok && tmp[i].epi == MVLT_EPI_OUT_F32;
+            }
+            if (ok) {
+                const int rc8 = mvlt_gemm8_try(tmp, n, 1, 1, 0, outs, items[0].workspace, items[0].workspace_bytes, s);
+                if (rc8 < 0) return MVLT_ERR_LAUNCH;
+                if (rc8 > 0) return MVLT_OK;
+            }
         }
     }
     g.split = split;
@@ -1152,6 +1158,21 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
 #undef GROUP_LAUNCH
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
+}
+
+// Workspace a grouped launch can use (items[0].workspace / workspace_bytes; 0 = none needed): room for the k-slice slabs of
+// the 8-wave engine.  Without it the group still runs (unsliced, or on the 4-wave grouped kernel).
+extern "C" size_t mvlt_gemm_group_workspace_bytes(const MvltGemm* items, int n) {
+    if (!items || n < 1 || n > GROUP_MAX || items[0].dtype != MVLT_BF16) return 0;
+    GemmDev tmp[GROUP_MAX];
+    for (int i = 0; i < n; ++i) {
+        if (check_gemm_args(items + i) != MVLT_OK || !items[i].a_kmajor || !items[i].b_kmajor) return 0;
+        Plan pl{64, 128, 1};
+        MvltGemm it = items[i];
+        it.workspace = nullptr; it.workspace_bytes = 0;
+        if (fill_dev<bf16_t>(&it, pl, tmp[i]) != MVLT_OK) return 0;
+    }
+    return mvlt_gemm8_group_workspace(tmp, n);
 }
 
 extern "C" int mvlt_gemm_group(const MvltGemm* items, int n, void* stream) {

@@ -201,7 +201,14 @@ MVLT_DEV void g8_tile_epilogue(const GemmDev& p, const int m_base, const int n_b
 }
 
 constexpr int G8_GROUP_MAX = 8;
-struct G8Group { int n; GemmDev g[G8_GROUP_MAX]; const void* zero_page; };
+struct G8Group {
+    int n; GemmDev g[G8_GROUP_MAX]; const void* zero_page;
+    // split-K (weight gradients with too few output tiles for 256 CUs): every tile is cut into `split` k-slices = units;
+    // a unit writes its partial tile to slabs[tile][slice] (f32, fragment order), draws a ticket from counters[tile], and
+    // the LAST arriver sums the slices in slice order (deterministic, no float atomics) and runs the epilogue.
+    int split; float* slabs; float* cs_slabs; int* counters;
+    float* colsum[G8_GROUP_MAX];          // weight gradients: bias gradient of product i (column sums of its k-major A), or null
+};
 
 template <int MH, int NH> struct G8Cfg {
     static constexpr int HPK = MH + NH;                                 // half-tiles per K-tile
@@ -214,9 +221,9 @@ template <int MH, int NH> struct G8Issue {
     const bf16_t* pa[MH][2];    // [half][instruction]: this lane's source of the A half at k = 0 of the product
     const bf16_t* pb[NH][2];
     long ka, kb;                // element step per k (1 for a k-contiguous operand, ld for a k-major one)
-    int nk, K;                  // K-tiles / reduction length of the issue tile's product
-    int kt;                     // K-tile (within the issue tile) the next A0 belongs to
-    int ord;                    // ordinal of the issue tile in this workgroup's list
+    int K;                      // reduction length of the issue unit's product
+    int kt, kt_end;             // K-tile the next A0 belongs to / end of the issue unit's K-tile range
+    int ord;                    // ordinal of the issue unit in this workgroup's list
 };
 
 template <int MH, int NH, bool AKM, bool BKM, int EPI>
@@ -253,27 +260,43 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
         return q;
     };
     const int ntiles = start[G8_GROUP_MAX];
-    if (b >= ntiles) return;
-    const int nt_wg = (ntiles - b + G - 1) / G;
+    const int S = gp.split > 1 ? gp.split : 1;
+    const int nunits = ntiles * S;                                        // unit = (tile, k-slice)
+    if (b >= nunits) return;
+    const int nt_wg = (nunits - b + G - 1) / G;
 
-    // tile ordinal -> (product, by, bx); past the end of the list: the last tile (never multiplied, only re-loaded)
-    auto locate = [&](int ord, int& item, int& by, int& bx) {
-        const int t = xcd_remap(min(b + ord * G, ntiles - 1), ntiles);
-        item = 0;
+    // unit ordinal -> (product, by, bx, tile, slice, K-tile range); past the end of the list: the last unit (only re-loaded)
+    struct Unit { int item, by, bx, tile, slice, kt0, kt1; };
+    auto locate = [&](int ord) {
+        Unit u;
+        const int un = xcd_remap(min(b + ord * G, nunits - 1), nunits);   // slices of a tile are neighbours: same XCD chunk
+        const int t = un / S;
+        u.tile = t; u.slice = un - t * S;
+        int item = 0;
 #pragma unroll
         for (int i = 1; i < G8_GROUP_MAX; ++i) if (i < gp.n && t >= start[i]) item = i;
         const int gx = (gp.g[item].N + BN - 1) / BN;
         const int local = t - start[item];
-        by = local / gx; bx = local - by * gx;
-        item = __builtin_amdgcn_readfirstlane(item); by = __builtin_amdgcn_readfirstlane(by); bx = __builtin_amdgcn_readfirstlane(bx);
+        const int by = local / gx;
+        u.item = __builtin_amdgcn_readfirstlane(item); u.by = __builtin_amdgcn_readfirstlane(by);
+        u.bx = __builtin_amdgcn_readfirstlane(local - by * gx);
+        const int kdim = AKM ? __builtin_amdgcn_readfirstlane(eff_lds[u.item]) : gp.g[u.item].K;
+        const int nk = (kdim + 63) >> 6;
+        const int per = (nk + S - 1) / S;
+        u.kt0 = min(u.slice * per, nk); u.kt1 = min(u.kt0 + per, nk);
+        return u;
     };
 
     G8Issue<MH, NH> is;
     const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(gp.zero_page);
     auto set_tile = [&](int ord) {
-        int item, by, bx;
-        locate(ord, item, by, bx);
-        const GemmDev q = product(item);
+        // units with an empty K-tile range (fewer K-tiles than slices) multiply nothing and are skipped by the issue
+        // stream as they are by the K loop; past the end of the list any unit serves (its loads are never read)
+        Unit u = locate(ord);
+        while (u.kt0 >= u.kt1 && ord < nt_wg) { ++ord; u = locate(ord); }
+        if (ord >= nt_wg) { u.kt0 = 0; u.kt1 = 1; }
+        const int by = u.by, bx = u.bx;
+        const GemmDev q = product(u.item);
         const bf16_t* A = reinterpret_cast<const bf16_t*>(q.A);
         const bf16_t* B = reinterpret_cast<const bf16_t*>(q.B);
 #pragma unroll
@@ -306,7 +329,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
             }
         }
         is.ka = AKM ? q.lda : 1; is.kb = BKM ? q.ldb : 1;
-        is.K = q.K; is.nk = (q.K + 63) >> 6;
+        is.K = q.K; is.kt = u.kt0; is.kt_end = u.kt1;
         is.ord = ord;
     };
     // half-tile `typ` (0 A0, 1 B0, 2 B1, 3 A1) of K-tile `kt` of the issue tile into ring buffer `d`
@@ -331,14 +354,17 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
                     else src = k < is.K ? src : src - (long)(k - max(is.K - 1, 0)) * is.kb;
                 }
             }
+#ifndef G8_NO_GLDS          /* ablation build: no LDS-DMA (stale LDS is multiplied; outputs wrong) */
             g8_glds16(src, slot + j * 1024);
+#else
+            asm volatile("" :: "v"(src), "s"(slot));
+#endif
         }
     };
-    auto advance = [&]() { if (++is.kt >= is.nk) { is.kt = 0; set_tile(is.ord + 1); } };
+    auto advance = [&]() { if (++is.kt >= is.kt_end) set_tile(is.ord + 1); };
 
     // ---- prologue
     set_tile(0);
-    is.kt = 0;
     if constexpr (HPK == 4) {                  // the whole K-tile 0 and A0 of K-tile 1; 3 half-tiles stay in flight
         issue(0, is.kt, 0); issue(1, is.kt, 0); issue(2, is.kt, 0); issue(3, is.kt, 0);
         advance();
@@ -359,11 +385,11 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
     if (wr == 1) G8_BARRIER();                                            // group 1 runs one barrier behind
 
     int g = 0;                                                            // flat K-tile index over the tile list
+    const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
     for (int ord = 0; ord < nt_wg; ++ord) {
-        int item, by, bx;
-        locate(ord, item, by, bx);
-        const GemmDev p = product(item);
-        const int nk = (p.K + 63) >> 6;
+        const Unit un = locate(ord);
+        const int by = un.by, bx = un.bx;
+        const GemmDev p = product(un.item);
         // bias values of this lane's 2 NH column groups: loaded now, used after the K loop (a load issued in the epilogue
         // would queue behind the ring's in-flight LDS-DMA: vmcnt completes in order)
         f32x4 bias_v[NH][2];
@@ -377,8 +403,13 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[a][c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // weight gradients: the bias gradient db[m] = sum_k dY[k][m] rides along as dY^T . 1 -- wave wc multiplies the A
+        // fragment of its row block wc with a fragment of ones (2 extra MFMAs per A half and K-tile, +3-6 %)
+        f32x4 cs[MH];
+#pragma unroll
+        for (int a = 0; a < MH; ++a) cs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int kt = 0; kt < nk; ++kt, ++g) {
+        for (int kt = un.kt0; kt < un.kt1; ++kt, ++g) {
             const int d = g % RING_KT;
             const char* base = smem + d * HPK * HT_BYTES;
             bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
@@ -386,30 +417,41 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
                 fa[i][kb] = g8_frag<AKM>(base + (HALF_SLOT) * HT_BYTES, wr * 64 + i * 16, kb, lane)
 #define G8_READ_B(DST, HALF_SLOT) _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) \
                 DST[j][kb] = g8_frag<BKM>(base + (HALF_SLOT) * HT_BYTES, wc * 32 + j * 16, kb, lane)
+#ifdef G8_NO_MMA          /* ablation build: LDS reads kept alive, no MFMA (outputs wrong) */
+#define G8_MMA(C_, FB_) do { \
+                _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) { \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(fa[i][kb])); \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(FB_[j][kb])); } } while (0)
+#else
 #define G8_MMA(C_, FB_) do { \
                 __builtin_amdgcn_s_setprio(1); \
                 _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j) Mma<bf16_t>::mma(C_[i][j], FB_[j][kb], fa[i][kb]); \
                 __builtin_amdgcn_s_setprio(0); } while (0)
+#endif
+#define G8_CS(A_) do { if constexpr (AKM && BKM) { \
+                _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) { \
+                    if (wc == 0) Mma<bf16_t>::mma(cs[A_], ones, fa[0][kb]); else if (wc == 1) Mma<bf16_t>::mma(cs[A_], ones, fa[1][kb]); \
+                    else if (wc == 2) Mma<bf16_t>::mma(cs[A_], ones, fa[2][kb]); else Mma<bf16_t>::mma(cs[A_], ones, fa[3][kb]); } } } while (0)
             if constexpr (MH == 2 && NH == 2) {
                 // slots A0 B0 B1 A1; phases (0,0) (0,1) (1,1) (1,0); one half-tile issued per phase, 5 half-tiles ahead
                 G8_READ_B(fb0, 1); G8_READ_A(0);
                 G8_FENCE(); issue(1, is.kt, (g + 1) % RING_KT); G8_VMCNT(6);
-                G8_BARRIER(); G8_MMA(acc[0][0], fb0); G8_BARRIER();
+                G8_BARRIER(); G8_MMA(acc[0][0], fb0); G8_CS(0); G8_BARRIER();
                 G8_READ_B(fb1, 2);
                 G8_FENCE(); issue(2, is.kt, (g + 1) % RING_KT); G8_VMCNT(6);
                 G8_BARRIER(); G8_MMA(acc[0][1], fb1); G8_BARRIER();
                 G8_READ_A(3);
                 G8_FENCE(); issue(3, is.kt, (g + 1) % RING_KT); G8_VMCNT(6);
-                G8_BARRIER(); G8_MMA(acc[1][1], fb1); G8_BARRIER();
+                G8_BARRIER(); G8_MMA(acc[1][1], fb1); G8_CS(MH - 1); G8_BARRIER();
                 advance(); issue(0, is.kt, d); G8_VMCNT(6);
                 G8_BARRIER(); G8_MMA(acc[1][0], fb0); G8_BARRIER();
             } else if constexpr (MH == 1 && NH == 2) {
                 // slots A0 B0 B1; phases (0,0) (0,1); K-tile g+2 is issued while K-tile g is multiplied
                 G8_READ_B(fb0, 1); G8_READ_A(0);
                 G8_FENCE(); advance(); issue(0, is.kt, (g + 2) % RING_KT); issue(1, is.kt, (g + 2) % RING_KT); G8_VMCNT(10);
-                G8_BARRIER(); G8_MMA(acc[0][0], fb0); G8_BARRIER();
+                G8_BARRIER(); G8_MMA(acc[0][0], fb0); G8_CS(0); G8_BARRIER();
                 G8_READ_B(fb1, 2);
                 G8_FENCE(); issue(2, is.kt, (g + 2) % RING_KT); G8_VMCNT(8);
                 G8_BARRIER(); G8_MMA(acc[0][1], fb1); G8_BARRIER();
@@ -417,16 +459,17 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
                 // slots A0 B0 A1; phases (0,0) (1,0)
                 G8_READ_B(fb0, 1); G8_READ_A(0);
                 G8_FENCE(); advance(); issue(0, is.kt, (g + 2) % RING_KT); issue(1, is.kt, (g + 2) % RING_KT); G8_VMCNT(10);
-                G8_BARRIER(); G8_MMA(acc[0][0], fb0); G8_BARRIER();
+                G8_BARRIER(); G8_MMA(acc[0][0], fb0); G8_CS(0); G8_BARRIER();
                 G8_READ_A(2);
                 G8_FENCE(); issue(3, is.kt, (g + 2) % RING_KT); G8_VMCNT(8);
-                G8_BARRIER(); G8_MMA(acc[1][0], fb0); G8_BARRIER();
+                G8_BARRIER(); G8_MMA(acc[1][0], fb0); G8_CS(MH - 1); G8_BARRIER();
             } else {
                 // slots A0 B0; one phase; K-tile g+2 is issued while K-tile g is multiplied (ring of 4)
                 G8_READ_B(fb0, 1); G8_READ_A(0);
                 G8_FENCE(); advance(); issue(0, is.kt, (g + 2) % RING_KT); issue(1, is.kt, (g + 2) % RING_KT); G8_VMCNT(4);
-                G8_BARRIER(); G8_MMA(acc[0][0], fb0); G8_BARRIER();
+                G8_BARRIER(); G8_MMA(acc[0][0], fb0); G8_CS(0); G8_BARRIER();
             }
+#undef G8_CS
 #undef G8_READ_A
 #undef G8_READ_B
 #undef G8_MMA
@@ -434,7 +477,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
             // not know about the LDS-DMA in flight and waits vmcnt(0)): by now the previous tile's stores have completed and
             // only ring traffic that the next phases need anyway is outstanding; at the epilogue the values are just there
             if constexpr ((EPI & MVLT_EPI_BIAS) != 0) {
-                if (kt == 0) {
+                if (kt == un.kt0) {
 #pragma unroll
                     for (int c = 0; c < NH; ++c)
 #pragma unroll
@@ -442,9 +485,94 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
                 }
             }
         }
-        // ---- epilogue of this tile; the next tile's first half-tiles are already on their way
+        // ---- epilogue of this unit; the next unit's first half-tiles are already on their way
         // acc[r] <-> n = nb + 4 * (lane >> 4) + r, m = mb + (lane & 15)   (MFMA issued as (B fragment, A fragment))
-        g8_tile_epilogue<MH, NH, EPI>(p, by * BM + wr * 64, bx * BN + wc * 32, lane, acc, bias_v);
+        bool finish = true;
+        if (S > 1) {
+            // k-slices of one tile meet through f32 slabs; the LAST arriver sums them in slice order and stores the tile
+            // (cdna_hip_programming.md, in-launch split-K: plain stores -> every wave's vmcnt(0) -> workgroup barrier ->
+            // lane 0: agent release, vmcnt(0), relaxed ticket; last arriver: agent acquire, vmcnt(0), barrier, plain loads).
+            // The two wave groups run one barrier apart: group 0 takes one extra barrier here so that the barriers below
+            // mean the same program point for all 8 waves; group 1 takes one behind the epilogue to fall back again.
+            if (wr == 0) G8_BARRIER();
+            constexpr int TILE_F = BM * BN;
+            float* slab = gp.slabs + ((long)un.tile * S + un.slice) * TILE_F + wave * (TILE_F / 8);
+#pragma unroll
+            for (int a = 0; a < MH; ++a)
+#pragma unroll
+                for (int c = 0; c < NH; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            store4f(slab + ((((a * NH + c) * 4 + i) * 2 + j) * 64 + lane) * 4, acc[a][c][i][j]);
+            if constexpr (AKM && BKM) {
+                if (lane < 16) {
+#pragma unroll
+                    for (int a = 0; a < MH; ++a)
+                        gp.cs_slabs[((long)un.tile * S + un.slice) * BM + a * 128 + wr * 64 + wc * 16 + lane] = cs[a][0];
+                }
+            }
+            G8_VMCNT(0);
+            G8_BARRIER();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                G8_VMCNT(0);
+                eff_lds[8] = __hip_atomic_fetch_add(gp.counters + un.tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            G8_BARRIER();
+            finish = __builtin_amdgcn_readfirstlane(eff_lds[8]) == S - 1;
+            if (finish) {
+                if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); G8_VMCNT(0); }
+                G8_BARRIER();
+#pragma unroll
+                for (int a = 0; a < MH; ++a)
+#pragma unroll
+                    for (int c = 0; c < NH; ++c)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[a][c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int sl = 0; sl < S; ++sl) {
+                    const float* src = gp.slabs + ((long)un.tile * S + sl) * TILE_F + wave * (TILE_F / 8);
+#pragma unroll
+                    for (int a = 0; a < MH; ++a)
+#pragma unroll
+                        for (int c = 0; c < NH; ++c)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+                                    acc[a][c][i][j] += load4f(src + ((((a * NH + c) * 4 + i) * 2 + j) * 64 + lane) * 4);
+                }
+                if constexpr (AKM && BKM) {
+#pragma unroll
+                    for (int a = 0; a < MH; ++a) {
+                        float t = 0.f;
+                        if (lane < 16)
+                            for (int sl = 0; sl < S; ++sl)
+                                t += gp.cs_slabs[((long)un.tile * S + sl) * BM + a * 128 + wr * 64 + wc * 16 + lane];
+                        cs[a][0] = t;
+                    }
+                }
+            }
+        }
+        if (finish) {
+            g8_tile_epilogue<MH, NH, EPI>(p, by * BM + wr * 64, bx * BN + wc * 32, lane, acc, bias_v);
+            if constexpr (AKM && BKM) {
+                float* db = gp.colsum[0];
+#pragma unroll
+                for (int i = 1; i < G8_GROUP_MAX; ++i) if (i == un.item) db = gp.colsum[i];
+                if (db && bx == 0 && lane < 16) {
+#pragma unroll
+                    for (int a = 0; a < MH; ++a) {
+                        const int m = by * BM + a * 128 + wr * 64 + wc * 16 + lane;
+                        if (m < p.M) db[m] = cs[a][0];
+                    }
+                }
+            }
+        }
+        if (S > 1 && wr == 1) G8_BARRIER();
     }
     if (wr == 0) G8_BARRIER();                                            // balance group 1's extra barrier
     G8_VMCNT(0);                                                          // the overrun issues land before the LDS is released
@@ -454,12 +582,12 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
 __device__ __attribute__((aligned(256))) unsigned char g8_zero_page[512];
 
 template <int MH, int NH, bool AKM, bool BKM, int EPI>
-int g8_launch(const G8Group& gp, long tiles, hipStream_t s) {
-    constexpr int sh = G8Cfg<MH, NH>::LDS + 64;                           // ring + the products' effective sizes
+int g8_launch(const G8Group& gp, long units, hipStream_t s) {
+    constexpr int sh = G8Cfg<MH, NH>::LDS + 64;                           // ring + the products' effective sizes + ticket
     static const bool attr = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel<MH, NH, AKM, BKM, EPI>),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, sh) == hipSuccess; }();
     if (!attr) return -1;
-    const int grid = tiles < 256 ? (int)tiles : 256;
+    const int grid = units < 256 ? (int)units : 256;
     hipLaunchKernelGGL((gemm8_kernel<MH, NH, AKM, BKM, EPI>), dim3(grid), dim3(512), sh, s, gp);
     return hipGetLastError() == hipSuccess ? 1 : -1;
 }
@@ -470,31 +598,33 @@ const void* g8_zero_ptr() {
 }
 
 template <int MH, int NH>
-int g8_dispatch(const G8Group& gp, bool akm, bool bkm, int epi, long tiles, hipStream_t s) {
+int g8_dispatch(const G8Group& gp, bool akm, bool bkm, int epi, long units, hipStream_t s) {
     constexpr int B_ = MVLT_EPI_BIAS, G_ = MVLT_EPI_GELU, P_ = MVLT_EPI_SAVE_PRE, X_ = MVLT_EPI_MUL_GELU_GRAD,
                   R_ = MVLT_EPI_RESIDUAL, F_ = MVLT_EPI_OUT_F32;
-    if (!akm && !bkm) {
-        switch (epi) {
-            case 0: return g8_launch<MH, NH, false, false, 0>(gp, tiles, s);
-            case B_: return g8_launch<MH, NH, false, false, B_>(gp, tiles, s);
-            case B_ | G_: return g8_launch<MH, NH, false, false, B_ | G_>(gp, tiles, s);
-            case B_ | G_ | P_: return g8_launch<MH, NH, false, false, B_ | G_ | P_>(gp, tiles, s);
-            default: return 0;
+    if (akm && bkm && epi == F_) return g8_launch<MH, NH, true, true, F_>(gp, units, s);
+    if constexpr (MH + NH > 2) {
+        if (!akm && !bkm) {
+            switch (epi) {
+                case 0: return g8_launch<MH, NH, false, false, 0>(gp, units, s);
+                case B_: return g8_launch<MH, NH, false, false, B_>(gp, units, s);
+                case B_ | G_: return g8_launch<MH, NH, false, false, B_ | G_>(gp, units, s);
+                case B_ | G_ | P_: return g8_launch<MH, NH, false, false, B_ | G_ | P_>(gp, units, s);
+                default: return 0;
+            }
+        }
+        if (!akm && bkm) {
+            switch (epi) {
+                case 0: return g8_launch<MH, NH, false, true, 0>(gp, units, s);
+                case X_: return g8_launch<MH, NH, false, true, X_>(gp, units, s);
+                case R_: return g8_launch<MH, NH, false, true, R_>(gp, units, s);
+                default: return 0;
+            }
         }
     }
-    if (!akm && bkm) {
-        switch (epi) {
-            case 0: return g8_launch<MH, NH, false, true, 0>(gp, tiles, s);
-            case X_: return g8_launch<MH, NH, false, true, X_>(gp, tiles, s);
-            case R_: return g8_launch<MH, NH, false, true, R_>(gp, tiles, s);
-            default: return 0;
-        }
-    }
-    if (akm && bkm && epi == F_) return g8_launch<MH, NH, true, true, F_>(gp, tiles, s);
     return 0;
 }
 
-// tile shape for a list of products: 0 = not worth it (the 4-wave kernels of gemm.hip take it).
+// tile shape for a list of forward / dgrad products: 0 = not worth it (the 4-wave kernels of gemm.hip take it).
 // big_only (the automatic mode): 256 x 256 tiles for products that fill the chip with them AND either have a long
 // reduction (>= 24 K-tiles: the ~16 us of launch + first loads + store tail are amortised; 4096^3: 1.3 PFLOP/s against
 // 0.78 for the 4-wave kernel) or several tiles per CU.  The B = 32 step's own mid-size products (BERT FFN: 156-204 tiles,
@@ -516,6 +646,41 @@ int g8_choose(const GemmDev* d, int n, bool big_only, long* tiles_out) {
     *tiles_out = mode == 22 ? t22 : t12;
     return mode;
 }
+
+// Weight-gradient groups (both operands k-major, reduction over the activation rows): tile shape AND number of k-slices.
+// Few output tiles, thousands of reduction rows: without k-slices a BertLayer group has 108 tiles of 256 x 256 for 256
+// CUs.  Model per unit: K-tiles x time per K-tile of the shape (1.5 / 0.7 / 0.45 us for 256x256 / 128x256 / 128x128,
+// measured in gpurun_out g8_check) x rounds of 256 units, plus the last arriver's slab sum.
+struct G8Plan { int mode, split; long tiles, units; double est_us; size_t ws_bytes; };
+G8Plan g8_plan_kk(const GemmDev* d, int n) {
+    G8Plan best{0, 1, 0, 0, 1e30, 0};
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) kmax = d[i].K > kmax ? d[i].K : kmax;
+    const int nk = ceil_div(kmax, 64);
+    const int forced = [] { const char* e = getenv("MVLT_G8_TILE"); return e ? atoi(e) : 0; }();
+    const int forced_s = [] { const char* e = getenv("MVLT_G8_SPLIT"); return e ? atoi(e) : 0; }();
+    const struct { int mode, bm, bn; double tk, red; } shapes[3] = {{22, 256, 256, 1.5, 2.6}, {12, 128, 256, 0.7, 1.3}, {11, 128, 128, 0.45, 0.65}};
+    for (const auto& sh : shapes) {
+        if (forced && forced != sh.mode) continue;
+        long tiles = 0;
+        for (int i = 0; i < n; ++i) tiles += (long)ceil_div(d[i].M, sh.bm) * ceil_div(d[i].N, sh.bn);
+        for (int S = 1; S <= 32; ++S) {
+            if (forced_s && forced_s != S) continue;
+            if (S > 1 && nk / S < 6) break;
+            const long units = tiles * S;
+            const double est = (double)ceil_div(units, 256) * ceil_div(nk, S) * sh.tk + (S > 1 ? 5.0 + sh.red * S : 0.0) + 7.0;
+            if (est < best.est_us) {
+                best = G8Plan{sh.mode, S, tiles, units, est, 0};
+                if (S > 1) best.ws_bytes = (size_t)units * sh.bm * sh.bn * 4 + (size_t)units * sh.bm * 4 + (size_t)tiles * 4 + 1024;
+            }
+        }
+    }
+    return best;
+}
+
+}  // namespace (first part)
+
+namespace {
 
 // Bias gradients of a weight-gradient group: out_i[m] = sum_{k < K_i} dY_i[k][m] (dY_i k-major: the A operands of the
 // group).  One workgroup = 64 columns x all rows of one product: 16 row lanes x 16 lanes of 4 columns (8-byte loads, a
@@ -573,11 +738,19 @@ extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_colsum(const voi
 }
 
 // Launchers used by gemm.hip's dispatch: return 1 when the product(s) were taken, 0 when not eligible (the caller then
-// uses the 4-wave kernels), -1 on a launch error.  Eligible: bf16, 16-byte aligned operand rows, no split-K, 8-byte
-// aligned epilogue operands, an epilogue flag set that has an instantiation, and K a multiple of 64 unless both
-// operands are k-major (weight gradients: the reduction runs over activation rows, any count, also read from m_dev).
+// uses the 4-wave kernels), -1 on a launch error.  Eligible: bf16, 16-byte aligned operand rows, no split-K requested,
+// 8-byte aligned epilogue operands, N a multiple of 4, an epilogue flag set that has an instantiation, and K a multiple
+// of 64 unless both operands are k-major (weight gradients: the reduction runs over activation rows, any count, also
+// read from m_dev).  Weight-gradient groups: `colsum[i]` (may be null) receives the bias gradient of product i;
+// `ws` / `ws_bytes`: workspace for the k-slices (mvlt_gemm8_group_workspace says how much; too little: no slices).
+extern "C" __attribute__((visibility("hidden"))) size_t mvlt_gemm8_group_workspace(const void* dev_blocks, int n) {
+    if (n < 1 || n > G8_GROUP_MAX) return 0;
+    return g8_plan_kk(reinterpret_cast<const GemmDev*>(dev_blocks), n).ws_bytes;
+}
+
 extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* dev_blocks, int n, int a_kmajor, int b_kmajor,
-                                                                    int big_only, void* stream) {
+                                                                    int big_only, float* const* colsum, void* ws, size_t ws_bytes,
+                                                                    void* stream) {
     const GemmDev* d = reinterpret_cast<const GemmDev*>(dev_blocks);
     if (n < 1 || n > G8_GROUP_MAX) return 0;
     G8Group gp{};
@@ -589,12 +762,32 @@ extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* 
         if (a_kmajor && (d[i].M % 8 != 0)) return 0;
         if (b_kmajor && (d[i].N % 8 != 0)) return 0;
         gp.g[i] = d[i];
+        gp.colsum[i] = colsum ? colsum[i] : nullptr;
     }
     gp.zero_page = g8_zero_ptr();
     if (a_kmajor && !gp.zero_page) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a_kmajor && b_kmajor) {
+        G8Plan pl = g8_plan_kk(d, n);
+        if (pl.split > 1 && (!ws || ws_bytes < pl.ws_bytes)) {          // no room for the slabs: unsliced plan of the same shape
+            pl.split = 1; pl.units = pl.tiles;
+        }
+        gp.split = pl.split;
+        if (pl.split > 1) {
+            const int bm = pl.mode == 22 ? 256 : 128, bn = pl.mode == 11 ? 128 : 256;
+            char* w = reinterpret_cast<char*>(ws);
+            gp.slabs = reinterpret_cast<float*>(w);
+            gp.cs_slabs = reinterpret_cast<float*>(w + (size_t)pl.units * bm * bn * 4);
+            gp.counters = reinterpret_cast<int*>(w + (size_t)pl.units * bm * bn * 4 + (size_t)pl.units * bm * 4);
+            if (hipMemsetAsync(gp.counters, 0, (size_t)pl.tiles * 4, s) != hipSuccess) return -1;          // tickets: re-initialised every call
+        }
+        if (pl.mode == 22) return g8_dispatch<2, 2>(gp, true, true, d[0].epi, pl.units, s);
+        if (pl.mode == 12) return g8_dispatch<1, 2>(gp, true, true, d[0].epi, pl.units, s);
+        if (pl.mode == 11) return g8_dispatch<1, 1>(gp, true, true, d[0].epi, pl.units, s);
+        return 0;
+    }
     long tiles = 0;
     const int mode = g8_choose(d, n, big_only != 0, &tiles);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (mode == 22) return g8_dispatch<2, 2>(gp, a_kmajor != 0, b_kmajor != 0, d[0].epi, tiles, s);
     if (mode == 12) return g8_dispatch<1, 2>(gp, a_kmajor != 0, b_kmajor != 0, d[0].epi, tiles, s);
     return 0;

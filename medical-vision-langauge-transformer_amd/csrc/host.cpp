@@ -194,11 +194,10 @@ void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws, con
     if (bn) for (auto& it : items) tiles += ((it.dy->size(1) + 63) / 64) * ((it.x->size(1) + bn - 1) / bn);
     const int dtype = dtype_of(*items[0].dy);
     static const long long_k = [] { const char* e = getenv("MVLT_GROUP_LONG_K"); return e ? atol(e) : 8192L; }();
-    // few tiles but a long reduction (Swin stages 0/1): still one launch, cut into k-slices inside mvlt_gemm_group -- bf16
-    // only and not under MVLT_DETERMINISTIC=1 (the slices meet through float atomics; the exact-f32 parity mode and the
-    // deterministic mode take split-K slabs + the deterministic reduce kernel, one product at a time)
-    static const bool deterministic = [] { const char* e = getenv("MVLT_DETERMINISTIC"); return e && e[0] == '1'; }();
-    const bool slices_ok = dtype == MVLT_BF16 && !deterministic;
+    // few tiles but a long reduction (Swin stages 0/1): still one launch, cut into k-slices inside mvlt_gemm_group (bf16: the
+    // 8-wave engine's slab reduce, deterministic; the exact-f32 parity mode takes split-K slabs + the reduce kernel, one
+    // product at a time)
+    const bool slices_ok = dtype == MVLT_BF16;
     if (!(n > 1 && n <= 8 && bn && (tiles >= 200 || (slices_ok && items[0].dy->size(0) >= long_k)))) {
         for (auto& it : items) {
             Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db); e.m_dev = k_dev;
@@ -217,6 +216,8 @@ void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws, con
         arr[i].split_k = 1;
         mn2 += 2.0 * arr[i].M * arr[i].N;          // the reduction length (activation rows) is the ragged dimension here
     }
+    const size_t need = mvlt_gemm_group_workspace_bytes(arr, n);          // k-slice slabs of the 8-wave engine
+    if (need) { arr[0].workspace = workspace(ws, need, *items[0].dy); arr[0].workspace_bytes = (size_t)ws.buf.numel(); }
     const bool timed = g_timer.sample();
     if (timed) g_timer.begin(stream, mn2, arr[0].K, k_dev);
     ck(mvlt_gemm_group(arr, n, stream), "mvlt_gemm_group");

@@ -359,7 +359,7 @@ def wgrad_group(items):
     bn = 128 if all(x.shape[1] % 128 == 0 for _, x, _, _ in items) else (96 if all(x.shape[1] % 96 == 0 for _, x, _, _ in items) else 0)
     tiles = sum(((dy.shape[1] + 63) // 64) * ((x.shape[1] + bn - 1) // bn) for dy, x, _, _ in items) if bn else 0
     # few tiles but a long reduction (Swin stages 0/1): still one launch, cut into k-slices inside mvlt_gemm_group
-    slices_ok = items[0][0].dtype == torch.bfloat16 and not DETERMINISTIC      # k-slices meet through float atomics
+    slices_ok = items[0][0].dtype == torch.bfloat16      # bf16: k-slices through the 8-wave engine's deterministic slab reduce
     if not (1 < n <= 8 and bn and (tiles >= 200 or (slices_ok and items[0][0].shape[0] >= _GROUP_LONG_K))):
         for dy, x, dw, db in items:
             gemm(dy, x, a_kmajor=True, b_kmajor=True, out=dw, out_f32=True, a_colsum=db, m_dev=m_dev)
@@ -382,6 +382,10 @@ def wgrad_group(items):
             assert db.dtype == torch.float32 and db.numel() == dy.shape[1]
             p.a_colsum = _p(db)
         flops += 2.0 * p.M * p.N * p.K
+    need = lib.mvlt_gemm_group_workspace_bytes(arr, n)          # k-slice slabs of the 8-wave engine (0: none)
+    if need:
+        ws = workspace("gemm_group", need, items[0][0].device)
+        arr[0].workspace, arr[0].workspace_bytes = ws.data_ptr(), ws.numel()
     evs = GEMM_TIMER(flops, ("group", arr[0].dtype, 64, bn)) if GEMM_TIMER is not None else None
     st = None
     if evs is not None:

@@ -79,9 +79,9 @@ def run_group(widths, R, mdev=None):
         items.append((dy, x, dw, db) if mdev is None else (dy, x, dw, db, torch.tensor([mdev], dtype=torch.int32, device="cuda")))
     fl = sum(2.0 * R * no * ni for no, ni in widths)
     line = f"group {widths} R={R} mdev={mdev}: "
-    for name, g8, tile in [("old", 0, None), ("g8/22", 1, 22), ("g8/12", 1, 12), ("g8/auto", 1, None)]:
+    for name, g8, tile in [("old", 0, None), ("g8/22", 1, 22), ("g8/12", 1, 12), ("g8/11", 1, 11), ("g8/auto", 1, None)]:
         setmode(g8, tile)
-        for it in items: it[2].zero_(); it[3].zero_()
+        for it in items: it[2].fill_(float("nan")); it[3].fill_(float("nan"))
         ops.wgrad_group(items); torch.cuda.synchronize()
         e = max(max(rel(it[2], r[0]), rel(it[3], r[1])) for it, r in zip(items, refs))
         us = timeit(lambda: ops.wgrad_group(items))
@@ -115,4 +115,13 @@ if which in ("all", "wgrad"):
     run_group([(768, 3072), (3072, 768), (768, 768), (2304, 768)], 4192)
     run_group([(384, 1536), (1536, 384), (384, 384), (1152, 384)], 6272)
     run_group([(768, 3072), (3072, 768), (768, 768), (2304, 768)], 1573)
+if which in ("all", "wgrad", "wgrad01"):
+    run_group([(96, 384), (384, 96), (288, 96), (96, 96)], 100352)
+    run_group([(192, 768), (768, 192), (576, 192), (192, 192)], 25088)
+    for sp in (8, 16, 24, 32):
+        os.environ["MVLT_G8_SPLIT"] = str(sp)
+        print("forced split", sp)
+        run_group([(96, 384), (384, 96), (288, 96), (96, 96)], 100352)
+        run_group([(192, 768), (768, 192), (576, 192), (192, 192)], 25088)
+    os.environ.pop("MVLT_G8_SPLIT", None)
 print("g8_check OK")
