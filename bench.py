@@ -314,7 +314,9 @@ def main():
     every = int(os.environ.get("MVLT_BENCH_SAMPLE", "4"))
     timer = KernelTimer(DOMINANT, every=every)
     native_samples = fam_samples = None
-    fam_every = 8 * every          # ~9 of ~280 launches per step: every bracket costs host time and a barrier packet on the stream
+    # ~10 of ~280 launches per step (every bracket costs host time and a barrier packet on the stream); a PRIME period, so
+    # the sample does not alias with the 4-6 products per layer (a period of 32 kept hitting the same product of every layer)
+    fam_every = 29
     if ops.NATIVE:          # the launches are issued by csrc/host.cpp: it brackets them itself (same method)
         ops.host().timer_begin(0, every, 64 * args.steps)
         ops.host().timer_begin(1, fam_every, 64 * args.steps)

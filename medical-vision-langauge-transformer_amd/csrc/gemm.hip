@@ -955,8 +955,9 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     const bool ak = p->a_kmajor != 0, bk = p->b_kmajor != 0;
     if constexpr (sizeof(T) == 2) {
         // 8-wave ping-pong engine (gemm8.hip) for wide outputs: MVLT_G8 = 0 never / 1 wherever it is eligible
-        if (g8_mode() && !ak && d.split_k <= 1) {
-            const int rc8 = mvlt_gemm8_try(&d, 1, 0, bk ? 1 : 0, g8_mode() == 2, nullptr, nullptr, 0, s);
+        const int g8m = g8_mode();
+        if (g8m && !ak && d.split_k <= 1) {
+            const int rc8 = mvlt_gemm8_try(&d, 1, 0, bk ? 1 : 0, g8m == 2, nullptr, nullptr, 0, s);
             if (rc8 < 0) return MVLT_ERR_LAUNCH;
             if (rc8 > 0) {
                 if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
@@ -1102,7 +1103,8 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
     // group there (experiments: the BertLayer / stage-2 groups tie with this kernel), MVLT_G8_GROUP=0 none.
     if constexpr (sizeof(T) == 2) {
         static const bool g8_groups = [] { const char* e = getenv("MVLT_G8_GROUP"); return !(e && e[0] == '0'); }();
-        if (g8_groups && g8_mode() && (g8_mode() == 1 || split > 1 || (tiles < 200 && !ov_split))) {
+        const int g8m = g8_groups ? g8_mode() : 0;
+        if (g8m && (g8m == 1 || split > 1 || (tiles < 200 && !ov_split))) {
             GemmDev tmp[GROUP_MAX];
             float* outs[GROUP_MAX];
             bool ok = true;

@@ -639,8 +639,8 @@ int g8_choose(const GemmDev* d, int n, bool big_only, long* tiles_out) {
         kmin = d[i].K < kmin ? d[i].K : kmin;
     }
     int mode = 0;
-    if (const char* e = getenv("MVLT_G8_TILE")) mode = atoi(e);          // experiments: 22 / 12 force a shape
-    else if (big_only) mode = (t22 >= 400 || (t22 >= 200 && kmin >= 1536)) ? 22 : 0;
+    if (big_only) mode = (t22 >= 400 || (t22 >= 200 && kmin >= 1536)) ? 22 : 0;          // (the default path: no getenv per call)
+    else if (const char* e = getenv("MVLT_G8_TILE")) mode = atoi(e);          // experiments (MVLT_G8=1): 22 / 12 force a shape
     else if (t22 >= 200) mode = 22;
     else if (t12 >= 96) mode = 12;
     *tiles_out = mode == 22 ? t22 : t12;
@@ -678,64 +678,7 @@ G8Plan g8_plan_kk(const GemmDev* d, int n) {
     return best;
 }
 
-}  // namespace (first part)
-
-namespace {
-
-// Bias gradients of a weight-gradient group: out_i[m] = sum_{k < K_i} dY_i[k][m] (dY_i k-major: the A operands of the
-// group).  One workgroup = 64 columns x all rows of one product: 16 row lanes x 16 lanes of 4 columns (8-byte loads, a
-// wave covers 4 rows x 128 B), f32 sums, one LDS reduction.  Deterministic (no atomics); runs beside the MFMA kernel.
-struct G8ColsumItem { const bf16_t* a; long lda; int M, K; const int* k_dev; float* out; int blk0; };
-struct G8Colsum { int n; G8ColsumItem it[G8_GROUP_MAX]; };
-__global__ __launch_bounds__(256) void g8_colsum_kernel(const G8Colsum cs) {
-    __shared__ f32x4 red[16][16];
-    int i = 0;
-#pragma unroll
-    for (int j = 1; j < G8_GROUP_MAX; ++j) if (j < cs.n && (int)blockIdx.x >= cs.it[j].blk0) i = j;
-    const G8ColsumItem it = cs.it[i];
-    int K = it.K;
-    if (it.k_dev) K = min(K, max(__builtin_amdgcn_readfirstlane(*it.k_dev), 0));
-    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int col = ((int)blockIdx.x - it.blk0) * 64 + cg * 4;
-    f32x4 s{0.f, 0.f, 0.f, 0.f};
-    if (col + 4 <= it.M) {
-        const bf16_t* p = it.a + col;
-        int k = rl;
-        for (; k + 48 < K; k += 64) {          // 4 rows in flight per thread
-            const f32x4 a0 = load4f(p + (long)k * it.lda), a1 = load4f(p + (long)(k + 16) * it.lda),
-                        a2 = load4f(p + (long)(k + 32) * it.lda), a3 = load4f(p + (long)(k + 48) * it.lda);
-            s += (a0 + a1) + (a2 + a3);
-        }
-        for (; k < K; k += 16) s += load4f(p + (long)k * it.lda);
-    }
-    red[rl][cg] = s;
-    __syncthreads();
-    if (rl == 0 && col + 4 <= it.M) {
-        f32x4 t = red[0][cg];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) t += red[r][cg];
-        store4f(it.out + col, t);
-    }
-}
-
 }  // namespace
-
-extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_colsum(const void* dev_blocks, float* const* outs, int n, void* stream) {
-    const GemmDev* d = reinterpret_cast<const GemmDev*>(dev_blocks);
-    G8Colsum cs{};
-    int blocks = 0;
-    for (int i = 0; i < n; ++i) {
-        if (!outs[i]) continue;
-        if (d[i].M % 4 != 0 || d[i].lda % 4 != 0) return 0;
-        G8ColsumItem& it = cs.it[cs.n++];
-        it.a = reinterpret_cast<const bf16_t*>(d[i].A); it.lda = d[i].lda; it.M = d[i].M; it.K = d[i].K; it.k_dev = d[i].m_dev;
-        it.out = outs[i]; it.blk0 = blocks;
-        blocks += (d[i].M + 63) / 64;
-    }
-    if (cs.n == 0) return 1;
-    hipLaunchKernelGGL(g8_colsum_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), cs);
-    return hipGetLastError() == hipSuccess ? 1 : -1;
-}
 
 // Launchers used by gemm.hip's dispatch: return 1 when the product(s) were taken, 0 when not eligible (the caller then
 // uses the 4-wave kernels), -1 on a launch error.  Eligible: bf16, 16-byte aligned operand rows, no split-K requested,
