@@ -21,6 +21,7 @@
 // text ids; the seq2seq mask from (row, col, obj_end).
 #include "common.h"
 #include "attn_frag.h"
+#include <cstdlib>
 
 namespace {
 using namespace mvlt_attn;
@@ -557,6 +558,273 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
 }
 
 
+// ------------------------------------------------------------------ Swin backward, scores computed once
+// attn_bwd_kernel above evaluates the scores, the probabilities and dS twice -- keys on the accumulator rows for dQ,
+// queries on the rows for dK / dV -- and that softmax arithmetic (10 vector instructions per element and orientation)
+// is what the kernel spends its time on.  Here phase A (one query tile per wave) also leaves P and dS in LDS as bf16
+// images [query][key]; phase B (one key tile per wave) reads them back through the transposing LDS read as the
+// key-indexed operand of dK^T = Q^T dS and dV^T = dO^T P: 8 MFMAs and 24 LDS reads per wave, no vector arithmetic.
+//   * V is only ever a row-major operand: its four fragments go from global memory straight into registers, the LDS
+//     holds Q, K, dO, P, dS and the per-lane bias values of ONE orientation (52 KB: three workgroups per CU).
+//   * exp(x) = exp2(x log2 e): log2 e is folded into the scale, the bias values, the mask constant and the saved lse.
+//   * 1/sqrt(hd) is applied to the dQ / dK accumulators (8 values per lane) instead of the 16 dS values.
+constexpr int SW2_LD = 40;                                   // row stride of the [64][32] images (elements)
+constexpr int SW2_LDP = 72;                                  // row stride of the [64][64] P / dS images
+constexpr int SW2_IMG = 64 * SW2_LD * 2, SW2_PIMG = 64 * SW2_LDP * 2;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr size_t SW2_SMEM = 3 * SW2_IMG + 2 * SW2_PIMG + 4 * 256 * sizeof(f32x4) + 64 * 4;
+
+// relative-position index of accumulator element (t, j) of thread tid (keys-on-rows orientation: query 16 (tid / 64) +
+// (tid & 15), key 16 t + 4 ((tid & 63) / 16) + j); 255 = outside the 49 x 49 window.  The same for every launch.
+struct RelIdxTable { uint8_t v[256][16]; };
+constexpr RelIdxTable make_relidx() {
+    RelIdxTable r{};
+    for (int tid = 0; tid < 256; ++tid) {
+        const int q = 16 * (tid >> 6) + (tid & 15), g = (tid & 63) >> 4;
+        for (int e = 0; e < 16; ++e) {
+            const int k = 16 * (e >> 2) + 4 * g + (e & 3);
+            r.v[tid][e] = (q < 49 && k < 49) ? (uint8_t)((q / 7 - k / 7 + 6) * 13 + (q % 7 - k % 7 + 6)) : (uint8_t)255;
+        }
+    }
+    return r;
+}
+__device__ const RelIdxTable SW_RELIDX = make_relidx();
+
+#ifdef SW2_TRACE
+#define SW2_T(i) do { if (p.delta_ws && threadIdx.x == 0) reinterpret_cast<long long*>(p.delta_ws)[((long)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define SW2_T(i) do { } while (0)
+#endif
+template <bool SHIFT>
+__global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using T = bf16_t;
+    using M = Mma<T>;
+    const int h = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c15 = lane & 15;
+    const int C = p.nH * 32;
+    T* qi = reinterpret_cast<T*>(smem_raw);
+    T* ki = reinterpret_cast<T*>(smem_raw + SW2_IMG);
+    T* di = reinterpret_cast<T*>(smem_raw + 2 * SW2_IMG);
+    T* pi = reinterpret_cast<T*>(smem_raw + 3 * SW2_IMG);
+    T* si = reinterpret_cast<T*>(smem_raw + 3 * SW2_IMG + SW2_PIMG);
+    f32x4* lbA = reinterpret_cast<f32x4*>(smem_raw + 3 * SW2_IMG + 2 * SW2_PIMG);        // [4 key tiles][256 threads]
+    float* lse_s = reinterpret_cast<float*>(lbA + 4 * 256);
+    const T* qkv_g = reinterpret_cast<const T*>(p.qkv);
+    const T* dout = reinterpret_cast<const T*>(p.dout);
+    T* dqkv = reinterpret_cast<T*>(p.dqkv);
+    SW2_T(0);
+#ifdef SW2_TRACE
+    if (p.delta_ws && threadIdx.x == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        reinterpret_cast<long long*>(p.delta_ws)[((long)blockIdx.y * gridDim.x + blockIdx.x) * 16 + 12] = ((long long)xcc << 32) | hw;
+    }
+#endif
+
+    // Loads of the next window are in flight while the current one is multiplied.  vmcnt completes in order and the
+    // compiler can only count what is issued on every path, so everything here is straight-line: rows are clamped instead
+    // of predicated, the window index is clamped instead of the issue being skipped, nothing USES a loaded value before
+    // the loop top, and the stores further down are buffer stores whose out-of-range lanes are dropped by the hardware.
+    const int srow = min((int)threadIdx.x >> 2, 48), sch = (threadIdx.x & 3) * 8;
+    bf16x8 gq, gk, gd;            // this thread's 16-byte chunk of the Q / K / dO rows
+    bf16x8 fv[4];                 // V fragments: rows = keys 16t + c15, k-slots = d 8g..8g+7 (clamped row: P is 0 beyond key 48)
+    float lse_pre = 0.f;
+    auto issue = [&](int sq) {
+        const long r0 = (long)sq * 49;
+        const T* src = qkv_g + (r0 + srow) * 3 * C + h * 32 + sch;
+        gq = *reinterpret_cast<const bf16x8*>(src);
+        gk = *reinterpret_cast<const bf16x8*>(src + C);
+        gd = *reinterpret_cast<const bf16x8*>(dout + (r0 + srow) * C + h * 32 + sch);
+        lse_pre = p.lse[((long)sq * p.nH + h) * p.L + min((int)threadIdx.x, 48)];
+    };
+    auto issue_v = [&](int sq) {
+        const T* base = qkv_g + (long)sq * 49 * 3 * C + h * 32 + 2 * C + g * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fv[t] = *reinterpret_cast<const bf16x8*>(base + (long)min(16 * t + c15, 48) * 3 * C);
+    };
+    { const int first = min((int)blockIdx.x, p.nseq - 1); issue(first); issue_v(first); }
+    const __amdgpu_buffer_rsrc_t dq_rsrc = __builtin_amdgcn_make_buffer_rsrc(dqkv, 0, (int)((long)p.nseq * 49 * 3 * C * 2), 0x00020000);
+    auto store_rows = [&](int tok, bool valid, int col, const f32x4& v) {     // 4 bf16 at dqkv[tok][col..col+3]
+        bf16x4 r; r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
+        const uint32_t off = valid ? (uint32_t)(((long)tok * 3 * C + col) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, r), dq_rsrc, off, 0, 0);
+    };
+
+    // ---- once per workgroup: the bias values of this thread's 16 accumulator elements (times log2 e), gathered from the
+    // table column of this head through the constant index table; the shift-mask bit sets (wave w owns query tile w)
+    SW2_T(1);
+    {
+        const u32x4 idx4 = *reinterpret_cast<const u32x4*>(SW_RELIDX.v[threadIdx.x]);
+        float bv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int idx = (idx4[e >> 2] >> (8 * (e & 3))) & 255;
+            bv[e] = p.bias_table[min(idx, 168) * p.nH + h];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = (idx4[t] >> (8 * j)) & 255;
+                o[j] = idx < 169 ? bv[4 * t + j] * LOG2E : NEG_BIG;
+            }
+            lbA[t * 256 + threadIdx.x] = o;
+        }
+    }
+    SW2_T(2);
+    uint32_t rowA = 0, colA = 0;
+    if (SHIFT) {
+        const int qc = min(16 * wave + c15, 48), oy = div7(qc), ox = qc - 7 * oy;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int tok = 16 * (e >> 2) + 4 * g + (e & 3);
+            const bool valid = tok < 49 && 16 * wave + c15 < 49;
+            const int tc = min(tok, 48), ty = div7(tc), tx = tc - 7 * ty;
+            // last window row: image rows >= res-7, split at res-shift  <=>  token row < 7-shift or not
+            if (valid && ((ty < 7 - p.shift) != (oy < 7 - p.shift))) rowA |= 1u << e;
+            if (valid && ((tx < 7 - p.shift) != (ox < 7 - p.shift))) colA |= 1u << e;
+        }
+    }
+    f32x4 dbacc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dbacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float sc2 = p.scale * LOG2E;
+    const float MASKL2 = -100.0f * LOG2E;
+    const int nwx = p.res / 7;
+    SW2_T(3);
+
+    for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
+        const long rs = (long)seq * 49;
+        __syncthreads();                       // phase B of the previous window has read the images
+        if (seq == (int)blockIdx.x) SW2_T(4);
+        {
+            const int row = threadIdx.x >> 2;
+            const bool ok = row < 49;
+            const bf16x8 z = zero_vec<T>();
+            *reinterpret_cast<bf16x8*>(qi + row * SW2_LD + sch) = ok ? gq : z;
+            *reinterpret_cast<bf16x8*>(ki + row * SW2_LD + sch) = ok ? gk : z;
+            *reinterpret_cast<bf16x8*>(di + row * SW2_LD + sch) = ok ? gd : z;
+        }
+        if (threadIdx.x < 64) lse_s[threadIdx.x] = threadIdx.x < 49 ? lse_pre * LOG2E : 0.f;
+        __syncthreads();
+        if (seq == (int)blockIdx.x) SW2_T(5);
+        const int nxt = seq + (int)gridDim.x < p.nseq ? seq + (int)gridDim.x : seq;      // last window: re-read (harmless)
+        issue(nxt);                                                        // next window in flight
+        uint32_t mb = 0;
+        if (SHIFT) { const int w = seq % p.nW; mb = ((w / nwx) == nwx - 1 ? rowA : 0u) | ((w % nwx) == nwx - 1 ? colA : 0u); }
+
+        // ---- phase A: keys on accumulator rows, query tile `wave` on the columns -> dQ, dBias, P and dS images
+        {
+            const int tq = wave;
+            f32x4 sc[4], dp[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = sc[t]; }
+            const bf16x8 fq = frag_rowmajor<T>(qi, SW2_LD, 16 * tq, 0);
+            const bf16x8 fd = frag_rowmajor<T>(di, SW2_LD, 16 * tq, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                M::mma(sc[t], frag_rowmajor<T>(ki, SW2_LD, 16 * t, 0), fq);
+                M::mma(dp[t], fv[t], fd);
+            }
+            issue_v(nxt);                                                  // the V registers are free again
+            const int q = 16 * tq + c15;
+            const float lse_q = lse_s[q];
+            float dl = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 bia = lbA[t * 256 + threadIdx.x];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lg = fmaf(sc[t][j], sc2, bia[j]);
+                    if (SHIFT) lg += (mb & (1u << (4 * t + j))) ? MASKL2 : 0.f;
+                    const float pr = __builtin_amdgcn_exp2f(lg - lse_q);
+                    dl = fmaf(pr, dp[t][j], dl);
+                    sc[t][j] = pr;
+                }
+            }
+            dl += __shfl_xor(dl, 16, 64);
+            dl += __shfl_xor(dl, 32, 64);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                store4f(pi + q * SW2_LDP + 16 * t + 4 * g, sc[t]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float ds = sc[t][j] * (dp[t][j] - dl);
+                    dbacc[t][j] += ds;
+                    sc[t][j] = ds;
+                }
+                store4f(si + q * SW2_LDP + 16 * t + 4 * g, sc[t]);
+            }
+            f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 fs = frag_acc<4>(sc, kb, T());
+#pragma unroll
+                for (int td = 0; td < 2; ++td) M::mma(dq[td], frag_tok(ki, SW2_LD, 16 * td, kb), fs);
+            }
+#pragma unroll
+            for (int td = 0; td < 2; ++td) store_rows((int)rs + q, q < 49, h * 32 + 16 * td + 4 * g, dq[td] * p.scale);
+        }
+        if (seq == (int)blockIdx.x) SW2_T(6);
+        __syncthreads();                       // P and dS of every query tile are in LDS
+        if (seq == (int)blockIdx.x) SW2_T(7);
+
+        // ---- phase B: key tile `wave`: dK^T[d, key] = sum_q Q[q, d] dS[q, key], dV^T[d, key] = sum_q dO[q, d] P[q, key]
+        {
+            const int tk = wave;
+            f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dv[2] = {dk[0], dk[0]};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 fs = frag_tok(si, SW2_LDP, 16 * tk, kb);
+                const bf16x8 fp = frag_tok(pi, SW2_LDP, 16 * tk, kb);
+#pragma unroll
+                for (int td = 0; td < 2; ++td) {
+                    M::mma(dk[td], frag_tok(qi, SW2_LD, 16 * td, kb), fs);
+                    M::mma(dv[td], frag_tok(di, SW2_LD, 16 * td, kb), fp);
+                }
+            }
+            const int k = 16 * tk + c15;
+#pragma unroll
+            for (int td = 0; td < 2; ++td) {
+                store_rows((int)rs + k, k < 49, C + h * 32 + 16 * td + 4 * g, dk[td] * p.scale);
+                store_rows((int)rs + k, k < 49, 2 * C + h * 32 + 16 * td + 4 * g, dv[td]);
+            }
+        }
+        if (seq == (int)blockIdx.x) SW2_T(8);
+    }
+    SW2_T(9);
+    if (p.dbias) {
+        // dBias[rel(q, k)] = sum of dS[q, k] over the windows of this workgroup: the per-lane sums go to LDS as a [q][k]
+        // matrix (over the P / dS images), then one thread per table entry adds up its diagonal (LDS float atomics run at
+        // about a lane per cycle per CU: 3 us for this with three workgroups on the CU)
+        float* mat = reinterpret_cast<float*>(pi);                 // [64][68] f32 = 17,408 B <= 2 * SW2_PIMG
+        __syncthreads();
+        const int q = 16 * wave + c15;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(mat + q * 68 + 16 * t + 4 * g) = dbacc[t];
+        __syncthreads();
+        SW2_T(10);
+        if (threadIdx.x < 169) {
+            const int dy = (int)threadIdx.x / 13 - 6, dx = (int)threadIdx.x % 13 - 6;
+            // 49 independent, clamped LDS reads (a loop over the valid range only would wait out every read in turn)
+            const int shiftk = dy * 7 + dx;
+            float sum = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 49; ++qq) {
+                const int qy = qq / 7, qx = qq % 7;
+                const bool ok = qy - dy >= 0 && qy - dy <= 6 && qx - dx >= 0 && qx - dx <= 6;
+                const float v = mat[qq * 68 + min(max(qq - shiftk, 0), 48)];
+                sum += ok ? v : 0.f;
+            }
+            atomicAdd(&p.dbias[threadIdx.x * p.nH + h], sum);
+        }
+    }
+    SW2_T(11);
+}
+
 // ------------------------------------------------------------------ backward, split in two launches (MVLBert)
 // PHASE 0 (dQ + delta): K,V staged in full, Q,dO only the 4 query tiles of this workgroup.
 // PHASE 1 (dK, dV)    : Q,dO staged in full, K,V only the 4 key tiles of this workgroup.
@@ -758,7 +1026,8 @@ int launch(const AttnDev& d, bool bwd, int dtype, hipStream_t s) {
     if (SWIN) {   // several windows per workgroup: the LDS bias-gradient table is flushed once
         // backward: ~512 workgroups in total, each walking several windows of one head, so the LDS
         // bias-gradient table is flushed with 169 global atomics per workgroup instead of per window
-        const int target = (bwd ? 512 : 2048) / (d.nH > 0 ? d.nH : 1);
+        static int fwd_target = [] { const char* e = getenv("MVLT_SWF_TARGET"); return e ? atoi(e) : 2048; }();
+        const int target = (bwd ? 512 : fwd_target) / (d.nH > 0 ? d.nH : 1);
         if (gx > target) gx = target < 1 ? 1 : target;
     }
     dim3 grid(gx, d.nH);
@@ -775,6 +1044,37 @@ int launch(const AttnDev& d, bool bwd, int dtype, hipStream_t s) {
     return MVLT_OK;
 }
 
+// Swin backward, bf16, no attention dropout: the scores-once kernel; MVLT_SWIN_BWD=wg keeps attn_bwd_kernel
+static int swin_bwd_form() {
+    static int v = [] { const char* e = getenv("MVLT_SWIN_BWD"); return (e && e[0] == 'w' && e[1] == 'g') ? 0 : 1; }();
+    return v;
+}
+static int cu_count() {
+    static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev);
+                        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+                        return v; }();
+    return n;
+}
+static int launch_swin_bwd2(const AttnDev& d, hipStream_t s) {
+    // three workgroups per CU are resident; each walks several windows of one head, so the per-lane bias values are
+    // set up and the bias-gradient table is flushed once per workgroup
+    int gx = d.nseq;
+    // measured (B = 32, us at 1 / 2 / 3 workgroups per CU): stage 0 45.8 / 43.1 / 45.3, stage 1 28.9 / 32.8 / 35.2,
+    // stage 2 20.9 / 25.2 / 29.8, stage 3 13.8 / 16.2 / 21.4 -- the set-up of a workgroup costs more than a second
+    // resident workgroup hides, except where every workgroup walks dozens of windows
+    static int forced = [] { const char* e = getenv("MVLT_SW2_WGS"); return e ? atoi(e) : 0; }();
+    const int per_cu = forced > 0 ? forced : ((long)d.nseq * d.nH > 16L * cu_count() ? 2 : 1);
+    const int cap = per_cu * cu_count() / d.nH;
+    if (gx > cap) gx = cap < 1 ? 1 : cap;
+    dim3 grid(gx, d.nH);
+    auto k0 = swin_attn_bwd2_kernel<false>;
+    auto k1 = swin_attn_bwd2_kernel<true>;
+    if (d.shift != 0) hipLaunchKernelGGL(k1, grid, dim3(256), SW2_SMEM, s, d);
+    else hipLaunchKernelGGL(k0, grid, dim3(256), SW2_SMEM, s, d);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
 template <typename T>
 int dispatch(AttnDev d, bool bwd, int dtype, hipStream_t s) {
     constexpr int TPB = Tok<T>::TPB;
@@ -783,6 +1083,8 @@ int dispatch(AttnDev d, bool bwd, int dtype, hipStream_t s) {
     d.ld = d.hd + (sizeof(T) == 2 ? 8 : 4);
     if (d.mode == MVLT_ATTN_SWIN) {
         if (d.hd != 32 || d.L != 49) return MVLT_ERR_UNSUPPORTED;
+        if (bwd && sizeof(T) == 2 && d.drop_thresh == 0 && swin_bwd_form() &&
+            (double)d.nseq * 49 * 3 * d.nH * 32 * 2 < 2147483648.0) return launch_swin_bwd2(d, s);     // buffer-store range check: < 2 GB
         return launch<T, 32, 4, true>(d, bwd, dtype, s);
     }
     if (d.hd != 64) return MVLT_ERR_UNSUPPORTED;

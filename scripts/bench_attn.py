@@ -1,4 +1,5 @@
-"""Attention kernel microbenchmark at the pre-training step's shapes (B=32, bf16)."""
+"""Attention kernel microbenchmark at the pre-training step's shapes (B=32, bf16).
+    python scripts/bench_attn.py [stage]      # stage 0..3: only that Swin stage (for counter runs), no BERT part"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +20,10 @@ def timeit(f, n=20):
 
 
 tot = 0.0
+ONLY = int(sys.argv[1]) if len(sys.argv) > 1 else None
 for st, (res, C, nH, nblk) in enumerate([(56, 96, 3, 2), (28, 192, 6, 2), (14, 384, 12, 18), (7, 768, 24, 2)]):
+    if ONLY is not None and st != ONLY:
+        continue
     nW = (res // 7) ** 2
     nseq = B * nW
     qkv = (torch.randn(nseq * 49, 3 * C, device="cuda") * 0.5).to(dt)
@@ -36,6 +40,8 @@ for st, (res, C, nH, nblk) in enumerate([(56, 96, 3, 2), (28, 192, 6, 2), (14, 3
         cnt = nblk / (2 if res > 7 else 1)
         tot += (tf + tb) * cnt
         print(f"swin s{st} res={res} C={C} nH={nH} shift={shift}: fwd {tf:6.1f} us ({byt_f/tf/1e6:5.2f} TB/s)  bwd {tb:6.1f} us ({byt_b/tb/1e6:5.2f} TB/s)  x{cnt:g}", flush=True)
+if ONLY is not None:
+    sys.exit(0)
 Lq, H, nH = 131, 768, 12
 qkv = (torch.randn(B * Lq, 3 * H, device="cuda") * 0.5).to(dt)
 ids = torch.randint(1000, 30000, (B, 80), device="cuda"); ids[:, 50:] = 0

@@ -451,6 +451,35 @@ def test_swin_attention(ops, dt, res, nH, shift):
     assert rel(dtab, tr.grad) < (1e-4 if dt == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("res,nH,shift,B", [(14, 12, 3, 24), (14, 12, 0, 32), (28, 6, 3, 12), (56, 3, 3, 6), (56, 3, 0, 32),
+                                            (7, 24, 0, 32), (14, 16, 3, 8)])
+def test_swin_attention_backward_full_batches(ops, res, nH, shift, B):
+    """bf16 Swin attention backward (the scores-once kernel) at the step's batch sizes: several windows per workgroup,
+    every window kind of a shifted block, fewer windows than workgroup slots; against the fp32 torch statement of
+    visual_feature_extractor.py:224-251, globally and per window."""
+    from mvlt_amd._lib import ATTN_SWIN
+    dt = torch.bfloat16
+    nW = (res // 7) ** 2
+    B_ = B * nW
+    qkv = rnd((B_ * 49, 3 * nH * 32), dt, 43)
+    table = (0.5 * torch.randn(169, nH, generator=torch.Generator().manual_seed(44))).cuda()
+    scale = 32 ** -0.5
+    kw = dict(bias_table=table, nW=nW, win_res=res, shift=shift)
+    out, lse = ops.attn_fwd(qkv, ATTN_SWIN, B_, 49, nH, 32, scale, **kw)
+    qr = qkv.float().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    ref = swin_ref(qr, tr, nW, res, shift, nH, scale)
+    dout = rnd(out.shape, dt, 45)
+    ref.backward(dout.float())
+    dtab = torch.zeros_like(table)
+    dqkv = ops.attn_bwd(dout, qkv, out, lse, ATTN_SWIN, B_, 49, nH, 32, scale, dbias_table=dtab, **kw)
+    assert rel(dqkv, qr.grad) < tol(dt) * 3
+    # per window: a wave that mixed up two windows would still have a small global error at B = 32
+    e = (dqkv.float() - qr.grad).view(B_, -1).norm(dim=1) / (qr.grad.view(B_, -1).norm(dim=1) + 1e-30)
+    assert float(e.max()) < tol(dt) * 4, int(e.argmax())
+    assert rel(dtab, tr.grad) < 2e-2
+
+
 def wmsa_ref(x, w2n, nW, res, shift, nH, g1, b1, wqkv, bqkv, wproj, bproj, table, scale, rowscale):
     """Attention half of SwinTransformerBlock.forward as plain fp32 torch (visual_feature_extractor.py:356-384)."""
     C_ = x.shape[1]
