@@ -427,8 +427,12 @@ std::vector<Tensor> swin_block_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f
 }
 
 // sv = [x, stat1, xn1w, qkv, ao, lse, x1, stat2, xn2, h, act]
-Tensor swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>& sv, const Ptrs& w, const Ptrs& f, const Ptrs& g, const Ptrs& geo,
-                      const Ptrs& maps, double scale, int64_t s1, int64_t s2, int64_t stream_, int64_t side_) {
+// s2_next: DropPath scales of the MLP branch of the block that consumes dx0 (the previous block of the stage), or 0: the
+// last LayerNorm backward then also writes dx0 * s2_next, which that block takes as `dy2_pre` instead of launching a
+// row-scale pass of its own.  Returns {dx0} or {dx0, dx0 * s2_next}.
+std::vector<Tensor> swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>& sv, const Ptrs& w, const Ptrs& f, const Ptrs& g, const Ptrs& geo,
+                                   const Ptrs& maps, double scale, int64_t s1, int64_t s2, int64_t s2_next, const c10::optional<Tensor>& dy2_pre,
+                                   int64_t stream_, int64_t side_) {
     check_device(dx2);
     Streams ss{P(stream_), P(side_)};
     void* st = ss.main;
@@ -441,7 +445,10 @@ Tensor swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>& sv, const Pt
     const int32_t* w2n = P<const int32_t>(maps[0]); const int32_t* n2w = P<const int32_t>(maps[1]);
     (void)w2n;
     Tensor dy2 = dx2;
-    if (s2) {
+    if (s2 && dy2_pre.has_value()) {
+        dy2 = *dy2_pre;
+        TORCH_CHECK(dy2.sizes() == dx2.sizes() && dy2.scalar_type() == dx2.scalar_type() && dy2.is_contiguous(), "dy2_pre");
+    } else if (s2) {
         dy2 = empty2(rows, C, x);
         ck(mvlt_rows_transform(dtype, dp(dx2), dp(dy2), (int)rows, C, nullptr, P<float>(s2), Lt, 0.f, 0, 0, st), "mvlt_rows_transform");
     }
@@ -464,13 +471,16 @@ Tensor swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>& sv, const Pt
       ck(mvlt_attn_bwd(&p, st), "mvlt_attn_bwd"); }
     Tensor dxn1w = empty2(rows, C, x);
     { Epi e; if (nb) { e.pf = P(w[6]); e.pf_bytes = w[7]; } dgrad(dqkv, w[0], C, dxn1w, e, st); }
-    Tensor dx0 = empty2(rows, C, x);
-    { LnBranch br; ln_bwd(dxn1w, n2w, x, fp(stat1), fp(stat1) + rows, (int)rows, C, f[0], g[0], g[1], dp(dx1), dx0, br, st); }
+    Tensor dx0 = empty2(rows, C, x), dy2n;
+    { LnBranch br;
+      if (s2_next) { dy2n = empty2(rows, C, x); br.dz = dp(dy2n); br.rowscale = P<float>(s2_next); br.rps = Lt; }
+      ln_bwd(dxn1w, n2w, x, fp(stat1), fp(stat1) + rows, (int)rows, C, f[0], g[0], g[1], dp(dx1), dx0, br, st); }
     fork_side(ss);
     for (const Tensor* t : std::initializer_list<const Tensor*>{&dy2, &act, &dh, &xn2, &dyw, &ao, &dqkv, &xn1w}) g_side_keepalive.push_back(*t);
     wgrad_group({{&dy2, &act, g[11], g[12]}, {&dh, &xn2, g[9], g[10]}, {&dyw, &ao, g[4], g[5]}, {&dqkv, &xn1w, g[2], g[3]}},
                 ss.side, g_ws_side);
-    return dx0;
+    if (s2_next) return {dx0, dy2n};
+    return {dx0};
 }
 
 // ----------------------------------------------------------------------------------------------- housekeeping

@@ -117,6 +117,9 @@ def _use_fused_wmsa(dtype, C, nH, nwin):
     return _FUSED_WMSA == "1" or nwin >= 512 or (nwin >= 256 and C <= 256)
 
 
+_DP_FOLD = os.environ.get("MVLT_DP_FOLD", "1") != "0"     # the producer's LayerNorm backward writes the DropPath-scaled branch gradient
+
+
 class _SwinFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, token, img, mod, fuse_gelu, save):
@@ -340,9 +343,11 @@ class SwinTransformer(nn.Module):
                 dx = ops.layernorm_bwd(dxm, xin, mean, rstd, ds.norm.weight.data, g(ds.norm.weight), g(ds.norm.bias),
                                        merge=(H, W), defer=lnq)
                 ar.mark(ds.reduction.weight, ds.norm.weight, ds.norm.bias)
-            for _ in layer.blocks:
+            pre = None                               # dx * (DropPath scales of the consumer's MLP branch), when the producer wrote it
+            for k in range(len(layer.blocks)):
                 bi -= 1
-                dx = self._block_bwd(ar, saved["blocks"][bi], dx, B)
+                nxt = saved["blocks"][bi - 1] if (k + 1 < len(layer.blocks) and _DP_FOLD) else None
+                dx, pre = self._block_bwd(ar, saved["blocks"][bi], dx, B, pre, nxt[3] if (nxt is not None and len(nxt) == 6) else None)
         cols, x0, mean, rstd = saved["pe"]
         pe = self.patch_embed
         dx0 = ops.layernorm_bwd(dx, x0, mean, rstd, pe.norm.weight.data, g(pe.norm.weight), g(pe.norm.bias), defer=lnq)
@@ -378,22 +383,24 @@ class SwinTransformer(nn.Module):
             d = ar._views[key] = (w, f, gr)
         return d
 
-    def _block_bwd_native(self, ar, sv, dx2, B):
+    def _block_bwd_native(self, ar, sv, dx2, B, dy2_pre=None, s2_next=None):
         blk, saved, s1, s2, H, W = sv
         w2n, n2w = batched_window_maps(B, H, W, blk.window_size, blk.shift_size, dx2.device)
         w, f, gr = self._block_desc(ar, blk)
         at, mlp = blk.attn, blk.mlp
-        dx0 = ops.host().swin_block_bwd(dx2, saved, w, f, gr, [B, H, blk.dim, blk.num_heads, blk.shift_size, 0],
+        out = ops.host().swin_block_bwd(dx2, saved, w, f, gr, [B, H, blk.dim, blk.num_heads, blk.shift_size, 0],
                                         [w2n.data_ptr(), n2w.data_ptr()], at.scale, 0 if s1 is None else s1.data_ptr(),
-                                        0 if s2 is None else s2.data_ptr(), ops.stream_int(), ops.side_int(dx2.device))
+                                        0 if s2 is None else s2.data_ptr(), 0 if s2_next is None else s2_next.data_ptr(),
+                                        dy2_pre if s2 is not None else None, ops.stream_int(), ops.side_int(dx2.device))
+        dx0 = out[0]
         ar.mark(mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, blk.norm1.weight, blk.norm1.bias,
                 blk.norm2.weight, blk.norm2.bias, at.qkv.weight, at.qkv.bias, at.proj.weight, at.proj.bias,
                 at.relative_position_bias_table)
-        return dx0
+        return dx0, (out[1] if len(out) > 1 else None)
 
-    def _block_bwd(self, ar, sv, dx2, B):
+    def _block_bwd(self, ar, sv, dx2, B, dy2_pre=None, s2_next=None):
         if len(sv) == 6:
-            return self._block_bwd_native(ar, sv, dx2, B)
+            return self._block_bwd_native(ar, sv, dx2, B, dy2_pre, s2_next)
         (blk, x, mean1, rstd1, xn1w, qkv, ao, lse, x1, mean2, rstd2, xn2, h, a, s1, s2, H, W) = sv
         g = ar.grad_view
         C, nH, ws = blk.dim, blk.num_heads, blk.window_size
@@ -434,4 +441,4 @@ class SwinTransformer(nn.Module):
         ar.mark(mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, blk.norm1.weight, blk.norm1.bias,
                 blk.norm2.weight, blk.norm2.bias, at.qkv.weight, at.qkv.bias, at.proj.weight, at.proj.bias,
                 at.relative_position_bias_table)
-        return dx0
+        return dx0, None

@@ -1,6 +1,7 @@
-"""Where do the small copies / fills of a pre-training step come from?  torch.profiler with Python stacks over 2 steps;
-every aten::copy_ / clone / fill_ / zero_ / cat / _to_copy is attributed to the innermost frame inside this repository."""
-import os, sys, collections
+"""Which host calls are behind the small device copies / fills of a pre-training step?  torch.profiler (CPU + GPU
+activities) over 2 steps; every hipMemcpy* / hipMemset* runtime call is attributed to the innermost ATen / autograd op
+that encloses it in time on its thread, and the GPU-side memcpy / memset records are counted by kind and size."""
+import os, sys, json, collections, tempfile
 import torch
 from torch.profiler import profile, ProfilerActivity
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,22 +19,29 @@ for _ in range(5):
     step(batch)
 torch.cuda.synchronize()
 NSTEP = 2
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for _ in range(NSTEP):
         step(batch)
     torch.cuda.synchronize()
-WATCH = ("aten::copy_", "aten::clone", "aten::fill_", "aten::zero_", "aten::cat", "aten::_to_copy", "aten::contiguous",
-         "aten::zeros", "aten::zeros_like", "aten::empty", "aten::empty_like", "aten::index", "aten::nonzero",
-         "aten::rand", "aten::bernoulli_", "aten::add", "aten::mul", "aten::div", "aten::sum", "aten::floor_", "aten::floor")
+path = os.path.join(tempfile.gettempdir(), "mvlt_copy_trace.json")
+prof.export_chrome_trace(path)
+ev = json.load(open(path))["traceEvents"]
+ops = [e for e in ev if e.get("ph") == "X" and e.get("cat") in ("cpu_op", "user_annotation", "python_function")]
+rt = [e for e in ev if e.get("ph") == "X" and e.get("cat") in ("cuda_runtime", "cuda_driver") and
+      ("emcpy" in e["name"] or "emset" in e["name"])]
+gpu = [e for e in ev if e.get("ph") == "X" and e.get("cat") in ("gpu_memcpy", "gpu_memset")]
 by = collections.Counter()
-for ev in prof.events():
-    if ev.name not in WATCH:
-        continue
-    where = "?"
-    for fr in ev.stack:
-        if "/mvlt_amd/" in fr or "medical-vision" in fr or "/bench.py" in fr:
-            where = fr.split("/")[-1]
-            break
-    by[(ev.name, where)] += 1
-for (name, where), n in sorted(by.items(), key=lambda kv: -kv[1])[:70]:
-    print(f"{n / NSTEP:7.1f} /step  {name:22s} {where}")
+for r in rt:
+    best = None
+    for o in ops:
+        if o.get("tid") == r.get("tid") and o["ts"] <= r["ts"] and o["ts"] + o["dur"] >= r["ts"] + r.get("dur", 0):
+            if best is None or o["dur"] < best["dur"]:
+                best = o
+    by[(r["name"], best["name"] if best else "(no enclosing op: native host code / Python)")] += 1
+print("runtime copy / set calls per step, by enclosing op:")
+for (name, op), n in sorted(by.items(), key=lambda kv: -kv[1]):
+    print(f"  {n / NSTEP:6.1f}  {name:28s} <- {op}")
+kinds = collections.Counter((g["name"], g.get("args", {}).get("bytes", g.get("args", {}).get("Bytes", "?"))) for g in gpu)
+print("GPU-side records per step (name, bytes):")
+for (name, b), n in sorted(kinds.items(), key=lambda kv: -kv[1])[:30]:
+    print(f"  {n / NSTEP:6.1f}  {name}  {b}")
