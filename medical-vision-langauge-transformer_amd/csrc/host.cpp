@@ -86,6 +86,9 @@ void* workspace(Scratch& s, size_t need, const Tensor& like) {
 // evaluated in timer_collect -- counting the dense upper bound overstated the round-2 roofline by 13 %.
 struct KernelTimer {
     bool on = false; int every = 4, count = 0;
+    bool subtract_record_cost = true;     // checked against the kernel trace of the same run (scripts/roofline_vs_trace.py): the
+                                          // main-stream family reads +27 % without and +0.2 % with it; the grouped launches on
+                                          // the side stream, which start behind a cross-stream wait, +2 % without and -5 % with
     std::vector<hipEvent_t> ev;
     std::vector<double> mn2;          // per sample: 2 * sum_i (the two dimensions that are not ragged)
     std::vector<int> bound;           // per sample: host-known upper bound of the ragged dimension
@@ -96,24 +99,32 @@ struct KernelTimer {
         mn2.push_back(mn2_); bound.push_back(bound_);
         dev_rows[used] = -1;
         if (rows_dev) (void)hipMemcpyAsync(&dev_rows[used], rows_dev, sizeof(int), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
-        (void)hipEventRecord(ev[2 * used], static_cast<hipStream_t>(stream));
+        (void)hipEventRecord(ev[3 * used], static_cast<hipStream_t>(stream));
     }
-    void end(void* stream) { (void)hipEventRecord(ev[2 * used + 1], static_cast<hipStream_t>(stream)); ++used; }
+    // a third event straight behind the second: (e2 - e1) is what one event record costs on this stream at this point of
+    // the step, and collect() takes it off (e1 - e0) -- without that the bracket of a 25 us kernel reads 27 % high
+    // against the profiler's kernel duration (profiles/README.md, round 3)
+    void end(void* stream) {
+        (void)hipEventRecord(ev[3 * used + 1], static_cast<hipStream_t>(stream));
+        (void)hipEventRecord(ev[3 * used + 2], static_cast<hipStream_t>(stream));
+        ++used;
+    }
     void reset(int every_, size_t cap_) {
         for (auto e : ev) (void)hipEventDestroy(e);
         if (dev_rows) (void)hipHostFree(dev_rows);
         ev.clear(); mn2.clear(); bound.clear(); dev_rows = nullptr; used = 0; count = 0;
         on = cap_ > 0; every = std::max(1, every_); cap = cap_;
         if (!on) return;
-        ev.resize(2 * cap);
+        ev.resize(3 * cap);
         for (auto& e : ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate");
         TORCH_CHECK(hipHostMalloc(reinterpret_cast<void**>(&dev_rows), cap * sizeof(int), hipHostMallocDefault) == hipSuccess, "hipHostMalloc");
     }
     std::vector<std::pair<double, double>> collect() {          // [(executed flops, milliseconds)]; call after a device synchronize
         std::vector<std::pair<double, double>> out;
         for (size_t i = 0; i < used; ++i) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) continue;
+            float ms = 0.f, over = 0.f;
+            if (hipEventElapsedTime(&ms, ev[3 * i], ev[3 * i + 1]) != hipSuccess) continue;
+            if (subtract_record_cost && hipEventElapsedTime(&over, ev[3 * i + 1], ev[3 * i + 2]) == hipSuccess && over < ms) ms -= over;
             const int rows = dev_rows[i] >= 0 ? std::min(dev_rows[i], bound[i]) : bound[i];
             out.emplace_back(mn2[i] * rows, (double)ms);
         }
@@ -121,7 +132,7 @@ struct KernelTimer {
         return out;
     }
 };
-KernelTimer g_timer;        // grouped weight-gradient launches (gemm_group_kernel)
+KernelTimer g_timer = [] { KernelTimer t; t.subtract_record_cost = false; return t; }();        // grouped weight-gradient launches (gemm_group_kernel)
 KernelTimer g_timer_fam;    // forward / dgrad products of the layers (gemm_kernel, gemm_glds_kernel, gemm8_kernel)
 
 // ----------------------------------------------------------------------------------------------- GEMM
