@@ -192,9 +192,26 @@ __global__ __launch_bounds__(256, (SWIN ? 4 : 2)) void attn_fwd_kernel(const Att
     if (SWIN && (int)blockIdx.x < p.nseq) issue(blockIdx.x);
     SwinLane<SWIN ? KT : 1, true> sl;
     if (SWIN) {
-        stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, 0, h, false);     // bias-table column of this head: once
-        __syncthreads();
-        sl.init(s.tbl, 16 * wave + c15, g, p.shift);                   // NT == 4 == waves: wave w owns query tile w
+        if (p.shift == 0 || p.shift == 3) {
+            // NT == 4 == waves: wave w owns query tile w.  The relative-position indices and shift-mask bit sets of a
+            // thread's 16 score elements are constants (SWIN_PAIRS); the bias values are gathered from the table column
+            // of this head -- no LDS staging, no barrier, none of the ~400 instructions of SwinLane::init
+            const u32x4 idx4 = *reinterpret_cast<const u32x4*>(SWIN_PAIRS.ridx[threadIdx.x]);
+#pragma unroll
+            for (int t = 0; t < (SWIN ? KT : 1); ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = (idx4[t & 3] >> (8 * j)) & 255;
+                    const float b = p.bias_table[min(idx, 168) * p.nH + h];
+                    sl.bias[t][j] = idx < 169 ? b : NEG_BIG;
+                }
+            const uint32_t bb = p.shift ? SWIN_PAIRS.bits3[threadIdx.x] : 0u;
+            sl.rowbits = bb & 0xffffu; sl.colbits = bb >> 16;
+        } else {
+            stage_small<SWIN>(p, s.kmask, s.tbl, s.tblg, 0, h, false);     // bias-table column of this head: once
+            __syncthreads();
+            sl.init(s.tbl, 16 * wave + c15, g, p.shift);
+        }
     }
     for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
         const long rs = seq_row0(p, seq);
@@ -574,22 +591,6 @@ constexpr int SW2_IMG = 64 * SW2_LD * 2, SW2_PIMG = 64 * SW2_LDP * 2;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr size_t SW2_SMEM = 3 * SW2_IMG + 2 * SW2_PIMG + 4 * 256 * sizeof(f32x4) + 64 * 4;
 
-// relative-position index of accumulator element (t, j) of thread tid (keys-on-rows orientation: query 16 (tid / 64) +
-// (tid & 15), key 16 t + 4 ((tid & 63) / 16) + j); 255 = outside the 49 x 49 window.  The same for every launch.
-struct RelIdxTable { uint8_t v[256][16]; };
-constexpr RelIdxTable make_relidx() {
-    RelIdxTable r{};
-    for (int tid = 0; tid < 256; ++tid) {
-        const int q = 16 * (tid >> 6) + (tid & 15), g = (tid & 63) >> 4;
-        for (int e = 0; e < 16; ++e) {
-            const int k = 16 * (e >> 2) + 4 * g + (e & 3);
-            r.v[tid][e] = (q < 49 && k < 49) ? (uint8_t)((q / 7 - k / 7 + 6) * 13 + (q % 7 - k % 7 + 6)) : (uint8_t)255;
-        }
-    }
-    return r;
-}
-__device__ const RelIdxTable SW_RELIDX = make_relidx();
-
 #ifdef SW2_TRACE
 #define SW2_T(i) do { if (p.delta_ws && threadIdx.x == 0) reinterpret_cast<long long*>(p.delta_ws)[((long)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
 #else
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p)
     // table column of this head through the constant index table; the shift-mask bit sets (wave w owns query tile w)
     SW2_T(1);
     {
-        const u32x4 idx4 = *reinterpret_cast<const u32x4*>(SW_RELIDX.v[threadIdx.x]);
+        const u32x4 idx4 = *reinterpret_cast<const u32x4*>(SWIN_PAIRS.ridx[threadIdx.x]);
         float bv[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -676,18 +677,7 @@ __global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p)
     }
     SW2_T(2);
     uint32_t rowA = 0, colA = 0;
-    if (SHIFT) {
-        const int qc = min(16 * wave + c15, 48), oy = div7(qc), ox = qc - 7 * oy;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int tok = 16 * (e >> 2) + 4 * g + (e & 3);
-            const bool valid = tok < 49 && 16 * wave + c15 < 49;
-            const int tc = min(tok, 48), ty = div7(tc), tx = tc - 7 * ty;
-            // last window row: image rows >= res-7, split at res-shift  <=>  token row < 7-shift or not
-            if (valid && ((ty < 7 - p.shift) != (oy < 7 - p.shift))) rowA |= 1u << e;
-            if (valid && ((tx < 7 - p.shift) != (ox < 7 - p.shift))) colA |= 1u << e;
-        }
-    }
+    if (SHIFT) { const uint32_t b = SWIN_PAIRS.bits3[threadIdx.x]; rowA = b & 0xffffu; colA = b >> 16; }      // shift == 3 (host check)
     f32x4 dbacc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) dbacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1083,7 +1073,7 @@ int dispatch(AttnDev d, bool bwd, int dtype, hipStream_t s) {
     d.ld = d.hd + (sizeof(T) == 2 ? 8 : 4);
     if (d.mode == MVLT_ATTN_SWIN) {
         if (d.hd != 32 || d.L != 49) return MVLT_ERR_UNSUPPORTED;
-        if (bwd && sizeof(T) == 2 && d.drop_thresh == 0 && swin_bwd_form() &&
+        if (bwd && sizeof(T) == 2 && d.drop_thresh == 0 && swin_bwd_form() && (d.shift == 0 || d.shift == 3) &&
             (double)d.nseq * 49 * 3 * d.nH * 32 * 2 < 2147483648.0) return launch_swin_bwd2(d, s);     // buffer-store range check: < 2 GB
         return launch<T, 32, 4, true>(d, bwd, dtype, s);
     }

@@ -56,5 +56,34 @@ MVLT_DEV int rel_index(int q, int k) {
     return (qy - ky + 6) * 13 + ((q - 7 * qy) - (k - 7 * ky) + 6);
 }
 
+// Window-invariant facts about the 16 (key, query) pairs the score registers of thread tid hold in the keys-on-rows
+// orientation (query 16 (tid / 64) + (tid & 15); element e = 4 t + j is key 16 t + 4 ((tid & 63) / 16) + j): the
+// relative-position index (169 = outside the 49 x 49 window) and, for the shift of 3 every shifted Swin block uses, the
+// pairs that straddle the image border in the last window row / column (low / high half of bits3).  Constant for every
+// launch: computing them cost ~400 instructions per thread of every workgroup.
+struct SwinPairTable { uint32_t ridx[256][4]; uint32_t bits3[256]; };
+constexpr SwinPairTable make_swin_pairs() {
+    SwinPairTable r{};
+    for (int tid = 0; tid < 256; ++tid) {
+        const int q = 16 * (tid >> 6) + (tid & 15), g = (tid & 63) >> 4;
+        const int qc = q < 48 ? q : 48, qy = qc / 7, qx = qc % 7;
+        uint32_t rowbits = 0, colbits = 0;
+        for (int t = 0; t < 4; ++t) {
+            uint32_t packed = 0;
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * t + 4 * g + j;
+                const bool valid = q < 49 && k < 49;
+                const int kc = k < 48 ? k : 48, ky = kc / 7, kx = kc % 7;
+                packed |= (uint32_t)(valid ? (qy - ky + 6) * 13 + (qx - kx + 6) : 169) << (8 * j);
+                if (valid && ((ky < 4) != (qy < 4))) rowbits |= 1u << (4 * t + j);
+                if (valid && ((kx < 4) != (qx < 4))) colbits |= 1u << (4 * t + j);
+            }
+            r.ridx[tid][t] = packed;
+        }
+        r.bits3[tid] = rowbits | (colbits << 16);
+    }
+    return r;
+}
+static __device__ const SwinPairTable SWIN_PAIRS = make_swin_pairs();
 
 }  // namespace mvlt_attn

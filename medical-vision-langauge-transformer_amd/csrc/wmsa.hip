@@ -195,7 +195,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void wmsa_fwd_kernel(const WmsaDev p
     // ---- per-lane pair facts for this wave's query tile; shift-mask bits of this window
     const int qt = wave & 3;                      // this wave's query tile in every attention unit it runs
     LanePairs lp;
-    lp.init(16 * qt + c15, g, p.shift);
+    if (p.shift == 0 || p.shift == 3) {           // the constants of attn_frag.h instead of ~400 instructions per thread and window
+        const int e = qt * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lp.ridx[t] = SWIN_PAIRS.ridx[e][t];
+        const uint32_t bb = p.shift ? SWIN_PAIRS.bits3[e] : 0u;
+        lp.rowbits = bb & 0xffffu; lp.colbits = bb >> 16;
+    } else {
+        lp.init(16 * qt + c15, g, p.shift);
+    }
     uint32_t mbits = 0;
     if (p.shift != 0) {
         const int w = win % p.nW, nwx = p.res / 7;
