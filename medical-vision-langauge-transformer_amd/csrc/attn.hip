@@ -991,6 +991,214 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
     }
 }
 
+// ------------------------------------------------------------------ MVLBert backward, scores once (bf16, hd 64, L <= 160)
+// The two launches above each evaluate scores, probabilities, the dropout decisions and dS -- ~20 vector instructions per
+// element, twice.  Here one workgroup of 5 waves owns a (sequence, head); wave w keeps the key tiles w and w + 5 (their K
+// and V fragments and the dK / dV accumulators stay in registers) and the workgroup walks the queries in blocks of 32:
+//   * scores with the QUERIES on the accumulator rows, so P and dS are directly the second MFMA operand of
+//     dV^T += dO^T P and dK^T += Q^T dS (contraction over the block's 32 queries);
+//   * delta_q = rowsum(dO o O) from the forward output (equal to rowsum(P o dP), dropout included), computed while the
+//     operands are staged: every (query tile, key tile) pair is independent of the others;
+//   * dS also goes to LDS as a bf16 image [32 queries][keys]; after a barrier the waves split dQ^T = K^T dS^T by
+//     (feature tile, query tile): complete results, no reduction over the waves that own the keys.
+// LDS: K image (for the transposing read), double-buffered Q / dO / dS block images, lse, delta, key mask: 60 KB.
+constexpr int AB2_NW = 5, AB2_NT = 64 * AB2_NW;
+constexpr int AB2_LD = 72, AB2_LDS = 168;                     // row strides (elements): [.][64] images, [32][160] dS image
+constexpr int AB2_ROWS = 160;
+constexpr size_t AB2_SMEM = (size_t)AB2_ROWS * AB2_LD * 2 + 2 * 2 * 32 * AB2_LD * 2 + 2 * 32 * AB2_LDS * 2 + 3 * AB2_ROWS * 4;
+
+template <bool S2S, bool DROP>
+__global__ __launch_bounds__(AB2_NT) void bert_attn_bwd2_kernel(const AttnDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using T = bf16_t;
+    using M = Mma<T>;
+    T* kimg = reinterpret_cast<T*>(smem_raw);
+    T* qblk = kimg + AB2_ROWS * AB2_LD;                        // [2 buffers][32][72]
+    T* dblk = qblk + 2 * 32 * AB2_LD;
+    T* simg = dblk + 2 * 32 * AB2_LD;                          // [2 buffers][32][168]
+    float* lse_s = reinterpret_cast<float*>(simg + 2 * 32 * AB2_LDS);
+    float* delta_s = lse_s + AB2_ROWS;
+    float* kmask = delta_s + AB2_ROWS;
+    const int seq = blockIdx.x, h = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c15 = lane & 15;
+    const int C = p.nH * 64;
+    const long rs = seq_row0(p, seq);
+    const int Ls = seq_length(p, seq);
+    const int nt = (Ls + 15) >> 4, nqb = (nt + 1) >> 1;
+    const long rowbase = ((long)seq * p.nH + h) * p.L;
+    const T* qg = reinterpret_cast<const T*>(p.qkv) + rs * 3 * C + h * 64;
+    const T* dg = reinterpret_cast<const T*>(p.dout) + rs * C + h * 64;
+    const T* og = reinterpret_cast<const T*>(p.out) + rs * C + h * 64;
+    T* dqkv = reinterpret_cast<T*>(p.dqkv) + rs * 3 * C + h * 64;
+    constexpr float LOG2E_ = 1.4426950408889634f;
+
+    // ---- this wave's key tiles: K and V fragments (rows = keys, k-slots = features) straight from global memory
+    bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = min(16 * (wave + AB2_NW * i) + c15, Ls - 1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            kf[i][kb] = *reinterpret_cast<const bf16x8*>(qg + (long)row * 3 * C + C + kb * 32 + g * 8);
+            vf[i][kb] = *reinterpret_cast<const bf16x8*>(qg + (long)row * 3 * C + 2 * C + kb * 32 + g * 8);
+        }
+    }
+    // first query block: this thread's 16-byte chunk of Q and dO (threads 0..255; clamped row)
+    const int srow = (threadIdx.x >> 3) & 31, sch = (threadIdx.x & 7) * 8;
+    bf16x8 gq, gd;
+    auto issue_block = [&](int qb) {
+        const long r = min(32 * qb + srow, Ls - 1);
+        gq = *reinterpret_cast<const bf16x8*>(qg + r * 3 * C + sch);
+        gd = *reinterpret_cast<const bf16x8*>(dg + r * C + sch);
+    };
+    issue_block(0);
+
+    // ---- K image, delta = rowsum(dO o O), lse, key mask; the dS images start as zeros (tiles nobody owns stay zero)
+    for (int i = threadIdx.x; i < 2 * 32 * AB2_LDS / 8; i += AB2_NT) reinterpret_cast<bf16x8*>(simg)[i] = zero_vec<T>();
+    for (int u = threadIdx.x; u < AB2_ROWS * 8; u += AB2_NT) {
+        const int row = u >> 3, ch = (u & 7) * 8;
+        const bool ok = row < Ls;
+        const long r = min(row, Ls - 1);
+        const bf16x8 kv = *reinterpret_cast<const bf16x8*>(qg + r * 3 * C + C + ch);
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dg + r * C + ch);
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(og + r * C + ch);
+        *reinterpret_cast<bf16x8*>(kimg + row * AB2_LD + ch) = ok ? kv : zero_vec<T>();
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf((float)dv[e], (float)ov[e], d);
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        if ((u & 7) == 0) delta_s[row] = ok ? d : 0.f;
+    }
+    for (int q = threadIdx.x; q < AB2_ROWS; q += AB2_NT) {
+        lse_s[q] = q < Ls ? p.lse[rowbase + min(q, p.L - 1)] * LOG2E_ : 1.0e30f;      // a query outside the sequence: P = 0
+        bool ok = q < Ls;
+        if (!S2S && ok) {
+            const int n_img = p.obj_end - 1;
+            if (q >= 1 && q <= n_img) ok = p.image_mask ? p.image_mask[(long)seq * n_img + q - 1] != 0 : true;
+            else if (q > p.obj_end) ok = p.text_ids[(long)seq * p.T + (q - p.obj_end - 1)] > 0;
+        }
+        kmask[q] = q < Ls ? (ok ? 0.0f : -10000.0f * LOG2E_) : NEG_BIG;              // a key outside the sequence: P = 0
+    }
+
+    f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int td = 0; td < 4; ++td) { dk[i][td] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][td] = dk[i][td]; }
+    const float sc2 = p.scale * LOG2E_;
+    const bool own0 = wave < nt, own1 = wave + AB2_NW < nt;
+
+    for (int qb = 0; qb < nqb; ++qb) {
+        T* qb_img = qblk + (qb & 1) * 32 * AB2_LD;
+        T* db_img = dblk + (qb & 1) * 32 * AB2_LD;
+        T* s_img = simg + (qb & 1) * 32 * AB2_LDS;
+        if (threadIdx.x < 256) {
+            const bool ok = 32 * qb + srow < Ls;
+            *reinterpret_cast<bf16x8*>(qb_img + srow * AB2_LD + sch) = ok ? gq : zero_vec<T>();
+            *reinterpret_cast<bf16x8*>(db_img + srow * AB2_LD + sch) = ok ? gd : zero_vec<T>();
+        }
+        __syncthreads();                                   // block staged (first pass: K image, lse, delta, mask too)
+        issue_block(min(qb + 1, nqb - 1));                 // next block in flight (last pass: a harmless re-read)
+
+        // ---- scores of the block against this wave's key tiles: queries on accumulator rows
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 0 ? own0 : own1) {
+                const int kt = wave + AB2_NW * i;
+                const int k = 16 * kt + c15;
+                f32x4 sc[2], dp[2];
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) {
+                    sc[qi] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qi] = sc[qi];
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        M::mma(sc[qi], frag_rowmajor<T>(qb_img, AB2_LD, 16 * qi, kb * 32), kf[i][kb]);
+                        M::mma(dp[qi], frag_rowmajor<T>(db_img, AB2_LD, 16 * qi, kb * 32), vf[i][kb]);
+                    }
+                }
+                const float kb2 = kmask[k];
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) {
+                    const int q0 = 32 * qb + 16 * qi + 4 * g;
+                    const f32x4 lq = *reinterpret_cast<const f32x4*>(lse_s + q0);
+                    const f32x4 dl = *reinterpret_cast<const f32x4*>(delta_s + q0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = q0 + j;
+                        float bias = kb2;
+                        if (S2S) bias += (k <= q || k <= p.obj_end) ? 0.0f : -10000.0f * LOG2E_;
+                        const float pr = __builtin_amdgcn_exp2f(fmaf(sc[qi][j], sc2, bias) - lq[j]);
+                        float dpv = dp[qi][j], pd = pr;
+                        if (DROP) {
+                            const bool keep = rng_keep(p.seed, p.tag, (uint32_t)((rowbase + q) * p.L + k), p.drop_thresh);
+                            dpv = keep ? dpv * p.drop_scale : 0.0f;
+                            pd = keep ? pr * p.drop_scale : 0.0f;
+                        }
+                        sc[qi][j] = pr * (dpv - dl[j]);
+                        dp[qi][j] = pd;
+                    }
+                    // dS of this (query tile, key tile) -> the block's dS image [query][key]
+                    T* dst = s_img + (16 * qi + 4 * g) * AB2_LDS + k;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dst[j * AB2_LDS] = (T)sc[qi][j];
+                }
+                const bf16x8 fs = frag_acc<2>(sc, 0, T());
+                const bf16x8 fp = frag_acc<2>(dp, 0, T());
+#pragma unroll
+                for (int td = 0; td < 4; ++td) {
+                    M::mma(dk[i][td], frag_tok(qb_img, AB2_LD, 16 * td, 0), fs);
+                    M::mma(dv[i][td], frag_tok(db_img, AB2_LD, 16 * td, 0), fp);
+                }
+            }
+        }
+        __syncthreads();                                   // the block's dS image is complete
+
+        // ---- dQ^T[feature tile, query tile] = sum over key blocks of K^T dS^T: units dealt to the waves
+        for (int u = wave; u < 8; u += AB2_NW) {
+            const int dt = u & 3, qi = u >> 2;
+            f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
+            const T* srow_p = s_img + (16 * qi + c15) * AB2_LDS + 4 * g;
+            for (int kb = 0; kb < nqb; ++kb) {
+                // k-slot (g, e) of frag_tok <-> key 32 kb + 16 (e / 4) + 4 g + e % 4
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(srow_p + 32 * kb);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(srow_p + 32 * kb + 16);
+                bf16x8 fb;
+                fb[0] = lo[0]; fb[1] = lo[1]; fb[2] = lo[2]; fb[3] = lo[3]; fb[4] = hi[0]; fb[5] = hi[1]; fb[6] = hi[2]; fb[7] = hi[3];
+                M::mma(dq, frag_tok(kimg, AB2_LD, 16 * dt, kb), fb);
+            }
+            const int q = 32 * qb + 16 * qi + c15;
+            if (q < Ls) store4f(dqkv + (long)q * 3 * C + 16 * dt + 4 * g, dq * p.scale);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = 16 * (wave + AB2_NW * i) + c15;
+        if (k < Ls) {
+#pragma unroll
+            for (int td = 0; td < 4; ++td) {
+                T* ob = dqkv + (long)k * 3 * C + 16 * td + 4 * g;
+                store4f(ob + C, dk[i][td] * p.scale);
+                store4f(ob + 2 * C, dv[i][td]);
+            }
+        }
+    }
+}
+
+static int bert_bwd_form() {          // MVLT_BERT_BWD=split: the two-launch backward
+    static int v = [] { const char* e = getenv("MVLT_BERT_BWD"); return (e && e[0] == 's') ? 0 : 1; }();
+    return v;
+}
+static int launch_bert_bwd2(const AttnDev& d, hipStream_t s) {
+    dim3 grid(d.nseq, d.nH);
+    const bool s2s = d.mode == MVLT_ATTN_SEQ2SEQ, drop = d.drop_thresh != 0;
+#define AB2_LAUNCH(S, D) hipLaunchKernelGGL((bert_attn_bwd2_kernel<S, D>), grid, dim3(AB2_NT), AB2_SMEM, s, d)
+    if (s2s) { if (drop) AB2_LAUNCH(true, true); else AB2_LAUNCH(true, false); }
+    else { if (drop) AB2_LAUNCH(false, true); else AB2_LAUNCH(false, false); }
+#undef AB2_LAUNCH
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
 template <typename T, int HD, int KT>
 int launch_split(const AttnDev& d, int dtype, hipStream_t s) {
     const size_t sh = smem_bytes_split(dtype, d.rows_alloc, d.ld);
@@ -1078,6 +1286,7 @@ int dispatch(AttnDev d, bool bwd, int dtype, hipStream_t s) {
         return launch<T, 32, 4, true>(d, bwd, dtype, s);
     }
     if (d.hd != 64) return MVLT_ERR_UNSUPPORTED;
+    if (bwd && sizeof(T) == 2 && d.NT <= 10 && bert_bwd_form()) return launch_bert_bwd2(d, s);
     if (bwd && d.delta_ws) {           // two-launch backward (dQ+delta, then dK/dV): 2 workgroups per CU
         if (d.NT <= 5) return launch_split<T, 64, 5>(d, dtype, s);
         if (d.NT <= 9) return launch_split<T, 64, 9>(d, dtype, s);
