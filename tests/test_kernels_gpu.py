@@ -561,7 +561,8 @@ def bert_ref(qkv, B, Lq, nH, mask_add, scale, keep=None, p=0.0):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("T,seq2seq,p", [(80, False, 0.0), (80, True, 0.0), (23, False, 0.0), (24, True, 0.1),
-                                         (80, False, 0.1), (128, False, 0.1), (128, True, 0.0)])   # 128: config #5 (L=179)
+                                         (80, False, 0.1), (128, False, 0.1), (128, True, 0.0),   # 128: config #5 (L=179)
+                                         (109, True, 0.1), (109, False, 0.0), (110, False, 0.1)])   # L=160: the longest sequence of the one-launch bf16 backward (10 key tiles); 161: back to two launches
 def test_bert_attention(ops, dt, T, seq2seq, p):
     from mvlt_amd._lib import ATTN_BIDIR, ATTN_SEQ2SEQ
     from oracle import mvlt_oracle as O
@@ -591,15 +592,52 @@ def test_bert_attention(ops, dt, T, seq2seq, p):
     assert rel(dqkv, qr.grad) < tol(dt) * 3
 
 
+@pytest.mark.parametrize("seq2seq", [False, True])
+def test_bert_attention_backward_full_batch_per_sequence(ops, seq2seq):
+    """bf16 MVLBert attention backward at the step's size (B=32, 12 heads, L=131, dropout 0.1, every caption length
+    from empty to full): the one-launch scores-once kernel against the fp32 torch statement of modeling_bert.py:111-136,
+    globally and per sequence (a workgroup that mixed up two sequences or mis-sized its last key tile would hide in the
+    global norm)."""
+    from mvlt_amd._lib import ATTN_BIDIR, ATTN_SEQ2SEQ
+    from oracle import mvlt_oracle as O
+    dt = torch.bfloat16
+    B, nH, n_img, T, p = 32, 12, 49, 80, 0.1
+    Lq = n_img + 2 + T
+    qkv = rnd((B * Lq, 3 * nH * 64), dt, 52)
+    ids = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        ln = (b * 83) % (T + 1)                     # 0 .. 80, including 0, 77, 78, 79 (9 key tiles) and 80
+        ids[b, :ln] = 5 + torch.arange(ln)
+    if seq2seq:
+        mask = O.additive_mask(O.seq2seq_bool_mask(Lq, n_img + 1)[None].expand(B, Lq, Lq)).cuda()
+        mode = ATTN_SEQ2SEQ
+    else:
+        mask = O.additive_mask(O.bidir_bool_mask(ids, B, n_img)).cuda()
+        mode = ATTN_BIDIR
+    kw = dict(text_ids=ids.cuda(), obj_end=n_img + 1, dropout=(p, 77, 6))
+    out, lse = ops.attn_fwd(qkv, mode, B, Lq, nH, 64, 0.125, **kw)
+    keep = ops.dropout_mask(B * nH * Lq * Lq, p, 77, 6, qkv.device).view(B, nH, Lq, Lq).float()
+    qr = qkv.float().requires_grad_(True)
+    ref = bert_ref(qr, B, Lq, nH, mask, 0.125, keep, p)
+    dout = rnd(out.shape, dt, 53)
+    ref.backward(dout.float())
+    dqkv = ops.attn_bwd(dout, qkv, out, lse, mode, B, Lq, nH, 64, 0.125, **kw)
+    assert rel(dqkv, qr.grad) < tol(dt) * 3
+    e = (dqkv.float() - qr.grad).view(B, -1).norm(dim=1) / (qr.grad.view(B, -1).norm(dim=1) + 1e-30)
+    assert float(e.max()) < tol(dt) * 4, int(e.argmax())
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("seq2seq,p", [(False, 0.0), (True, 0.0), (False, 0.1)])
-def test_bert_attention_packed_rows_equal_dense(ops, dt, seq2seq, p):
+@pytest.mark.parametrize("T,lens_t", [(40, [40, 13, 1, 27]), (80, [80, 79, 78, 77, 0, 13, 45, 61])])
+def test_bert_attention_packed_rows_equal_dense(ops, dt, seq2seq, p, T, lens_t):
     """MvltAttn.row_start / seq_len: the kept rows of a packed launch == the same rows of the dense launch
-    (forward, backward, same dropout mask -- its index is (sequence, head, q, k) in both layouts)."""
+    (forward, backward, same dropout mask -- its index is (sequence, head, q, k) in both layouts).  T = 80: the
+    step's sequence length, with captions that end in the ninth key tile (78..80), just before it (77), and an
+    empty one."""
     from mvlt_amd._lib import ATTN_BIDIR, ATTN_SEQ2SEQ
-    B, nH, n_img, T = 4, 4, 49, 40
+    B, nH, n_img = len(lens_t), 4, 49
     Lq = n_img + 2 + T
-    lens_t = [40, 13, 1, 27]
     ids = torch.zeros(B, T, dtype=torch.long)
     for b, ln in enumerate(lens_t):
         ids[b, :ln] = 5 + torch.arange(ln)
