@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256, (SWIN ? 2 : 1)) void attn_bwd_kernel(const Att
 // images [query][key]; phase B (one key tile per wave) reads them back through the transposing LDS read as the
 // key-indexed operand of dK^T = Q^T dS and dV^T = dO^T P: 8 MFMAs and 24 LDS reads per wave, no vector arithmetic.
 //   * V is only ever a row-major operand: its four fragments go from global memory straight into registers, the LDS
-//     holds Q, K, dO, P, dS and the per-lane bias values of ONE orientation (52 KB: three workgroups per CU).
+//     holds Q, K, dO, P, dS and the per-lane bias values of ONE orientation (50 KB).
 //   * exp(x) = exp2(x log2 e): log2 e is folded into the scale, the bias values, the mask constant and the saved lse.
 //   * 1/sqrt(hd) is applied to the dQ / dK accumulators (8 values per lane) instead of the 16 dS values.
 constexpr int SW2_LD = 40;                                   // row stride of the [64][32] images (elements)
