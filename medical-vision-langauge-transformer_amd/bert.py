@@ -207,7 +207,8 @@ class MVLBert(nn.Module):
                                       torch.is_grad_enabled(), pack)
         return hidden, (pooled if self.pooler is not None else None), pack[3], pack[1]
 
-    def forward_autopack(self, text_idx, image_feature, labels=None, seq2seq_mask=False):
+    def forward_autopack(self, text_idx, image_feature, labels=None, seq2seq_mask=False, inputs_ready=None,
+                         want_label_plan=False):
         """forward_packed with the plan computed ON THE DEVICE from the ids themselves (mvlt_pack_plan): no extra
         argument, no host sync.  Sample b keeps [CLS] img [SEP] and its caption up to the last position that holds a
         non-zero id (or a label); the launch geometry is sized for the dense upper bound B * L and every kernel
@@ -217,10 +218,29 @@ class MVLBert(nn.Module):
         cd = compute_dtype_of(self)
         B, n_img, _ = image_feature.shape
         dev = image_feature.device
+        ids_in = text_idx
         text_idx = text_idx.contiguous()
         lab = None if labels is None else labels.reshape(text_idx.shape).to(torch.int64).contiguous()
-        with ops.pin_stream():
-            rs, sl, tot, rs64, trow = ops.pack_plan(text_idx, lab, n_img)
+        self.__dict__.pop("_mvlt_label_plan", None)
+        same_inputs = (inputs_ready is not None and text_idx.data_ptr() == ids_in.data_ptr()
+                       and (labels is None or lab.data_ptr() == labels.data_ptr()))
+        if same_inputs:
+            # ``inputs_ready``: an event recorded before the image tower was queued.  The ids / labels are the caller's own
+            # tensors (no conversion kernel of ours produced them), so the two single-workgroup plan kernels (19 + 13 us)
+            # run on the side stream behind that event, beside the tower, and the encoder waits for them
+            side = ops.side_stream(dev)
+            side.wait_event(inputs_ready)
+            # (allocated under the side stream too: a block of the main stream's pool may still have a queued reader)
+            with torch.cuda.stream(side), ops.on_stream(side, "side"):
+                rs, sl, tot, rs64, trow = ops.pack_plan(text_idx, lab, n_img)
+                if want_label_plan and lab is not None:
+                    self.__dict__["_mvlt_label_plan"] = ops.label_plan(lab.reshape(-1), trow)
+            done = torch.cuda.Event()
+            done.record(side)
+            torch.cuda.current_stream().wait_event(done)
+        else:
+            with ops.pin_stream():
+                rs, sl, tot, rs64, trow = ops.pack_plan(text_idx, lab, n_img)
         pack = (rs, sl, B * (n_img + 2 + text_idx.shape[1]), rs64, tot)
         tok = self.__dict__.get("_mvlt_token")
         if tok is None or tok.device != dev:

@@ -430,6 +430,9 @@ class MVLBertPretrainedModel(nn.Module):
 _AUTO_PACK = os.environ.get("MVLT_AUTO_PACK", "1") != "0"
 
 
+_PLAN_SIDE = os.environ.get("MVLT_PLAN_SIDE", "1") != "0"
+
+
 class MVLBertForPretraining(MVLBertPretrainedModel):
     """model.py:352-420.  The seq2seq/bidirectional coin flip (model.py:390-394)
     uses Python's ``random`` like the reference; under DDP every rank must draw
@@ -451,6 +454,12 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
         every caption is not materialised (MVLBert.forward_packed); loss and gradients are those of the dense
         computation.  A non-zero id or a label at or beyond the stated length turns the loss into NaN."""
         Arena.of(self, compute_dtype_of(self))       # one arena for the whole model
+        # the packing / label plans depend on the ids and labels only: MVLBert.forward_autopack runs their two
+        # single-workgroup kernels on the side stream behind this point, i.e. beside the image tower instead of after it
+        entry = None
+        if _PLAN_SIDE and caption_masked.is_cuda:
+            entry = torch.cuda.Event()
+            entry.record()
         image_feature = self.conv(image)
         text_idx = caption_masked
         text_mask = None          # == (text_idx > 0); rebuilt in-kernel from the ids
@@ -465,8 +474,12 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
         n_img = image_feature.shape[1]
         text_row = None
         if auto:
+            lab_first_early = (self.config.MLM_task and getattr(self.config, "mlm_labelled_rows_first", True)
+                               and not (getattr(self.config, "mlm_max_labels_per_sample", None) is not None
+                                        and self.config.mlm_max_labels_per_sample * B < B * T))
             hidden, pooled, text_row = self.MVLBert.forward_autopack(
-                text_idx, image_feature, labels=caption_label if self.config.MLM_task else None, seq2seq_mask=seq2seq_mask)
+                text_idx, image_feature, labels=caption_label if self.config.MLM_task else None, seq2seq_mask=seq2seq_mask,
+                inputs_ready=entry, want_label_plan=lab_first_early)
             H = hidden.shape[1]
         elif packed:
             hidden, pooled, row_start, seq_len = self.MVLBert.forward_packed(text_idx, image_feature, text_lengths,
@@ -492,8 +505,12 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
             rd = None
             lab_first = auto and not compact and getattr(self.config, "mlm_labelled_rows_first", True)
             if lab_first:
-                with ops.pin_stream():
-                    gather_row, sel_labels, rd = ops.label_plan(labels, text_row)
+                early = self.MVLBert.__dict__.pop("_mvlt_label_plan", None)
+                if early is not None:
+                    gather_row, sel_labels, rd = early
+                else:
+                    with ops.pin_stream():
+                        gather_row, sel_labels, rd = ops.label_plan(labels, text_row)
             if compact:
                 # Only labelled positions contribute to F.cross_entropy(ignore_index=-100) (model.py:410),
                 # so the MLM head (768x30522 decoder, 312 MB of f32 logits in the reference) is evaluated on
