@@ -158,14 +158,23 @@ def packed_gflop_per_pair(batch, all_mlm_rows=False):
     return fwd * 2 * 3 / 1e9
 
 
-def timed_run(step, batch, steps, use_dist, dist):
+def timed_run(step, batch, steps, use_dist, dist, blocks=5):
+    """EXACTLY `steps` steps between two barrier + synchronize brackets (max over ranks).  Beside the total, the stream
+    is stamped with an event every steps/blocks steps (recorded, never waited for inside the region), so the per-block
+    times of the same run can be quoted: median / min / max of `blocks` blocks."""
+    per = max(1, steps // blocks) if steps >= 2 * blocks else 0
+    stamps = []
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if per:
+        e = torch.cuda.Event(enable_timing=True); e.record(); stamps.append((0, e))
+    for i in range(steps):
         loss = step(batch)
+        if per and (i + 1) % per == 0 and (i + 1) // per <= blocks:
+            e = torch.cuda.Event(enable_timing=True); e.record(); stamps.append((i + 1, e))
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -175,7 +184,21 @@ def timed_run(step, batch, steps, use_dist, dist):
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    timed_run.block_ms = [a[1].elapsed_time(b[1]) / (b[0] - a[0]) for a, b in zip(stamps, stamps[1:])]
     return elapsed, loss
+
+
+def block_stats(per_gpu_batch, world):
+    """{"blocks": n, "ms_per_step_median/min/max", "value_median/min/max"} of the last timed_run (this rank's stream)."""
+    b = sorted(getattr(timed_run, "block_ms", []))
+    if not b:
+        return None
+    med = b[len(b) // 2] if len(b) % 2 else 0.5 * (b[len(b) // 2 - 1] + b[len(b) // 2])
+    pps = lambda ms: round(per_gpu_batch * world / (ms * 1e-3), 1)
+    return {"blocks": len(b), "ms_per_step_median": round(med, 3), "ms_per_step_min": round(b[0], 3), "ms_per_step_max": round(b[-1], 3),
+            "value_median": pps(med), "value_min": pps(b[-1]), "value_max": pps(b[0]),
+            "note": "device time between events recorded on the compute stream every steps/5 steps inside the timed region "
+                    "(rank 0; `value` itself is steps / wall time of the whole region, max over ranks)"}
 
 
 def other_configs(M):
@@ -257,8 +280,8 @@ def roofline_entry(samples, name, traffic_key, every):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)      # >= 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)     # ... after >= 20 warm-up steps
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the packed-rows / labelled-rows extra measurement")
@@ -272,6 +295,15 @@ def main():
     if args.gpus > 1 and world == 1:
         self_launch(args)                           # never returns; this process has not touched the GPU
     import torch.distributed as dist
+    # MVLT_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the ranks then share the
+    # devices round-robin and exchange through gloo; RCCL refuses two ranks on one device).  tests/test_bench_gpu.py runs
+    # the self-launch -> torchrun -> relay path this way; the driver's SCALE runs use the default (RCCL, one rank per GPU).
+    backend = os.environ.get("MVLT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this box has {ndev} "
+                         "(MVLT_BENCH_BACKEND=gloo shares the devices for a functional rehearsal)")
+    local = local % max(1, ndev) if backend != "nccl" else local
     torch.cuda.set_device(local)
     use_dist = world > 1 or os.environ.get("MVLT_FORCE_DDP") == "1"     # FORCE: exercise RCCL + reducer on 1 rank
     real_stdout = None
@@ -283,7 +315,10 @@ def main():
         os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import mvlt_amd as M
     from mvlt_amd import ops
@@ -323,6 +358,7 @@ def main():
     else:
         ops.GEMM_TIMER = timer
     elapsed, loss = timed_run(step, batch, args.steps, use_dist, dist)
+    blocks = block_stats(PER_GPU_BATCH, world)
     ops.GEMM_TIMER = None
     if ops.NATIVE:
         native_samples = ops.host().timer_collect(0)          # [(executed flops, ms)] -- the stream is idle: timed_run synchronised
@@ -390,15 +426,19 @@ def main():
                                        "loss and gradients equal the dense run (tests/test_model_gpu.py::"
                                        "test_device_planned_packing_*); value_dense_rows = all padded rows computed",
                           "grad_exchange": ("none (1 GPU)" if not use_dist else
-                                            f"RCCL all-reduce AVG, {'bf16' if comm == torch.bfloat16 else 'f32'}, 64 MiB "
-                                            "buckets overlapped with backward; per-rank MLM mean over labelled tokens"),
+                                            f"{'RCCL' if backend == 'nccl' else backend} all-reduce AVG, "
+                                            f"{'bf16' if comm == torch.bfloat16 else 'f32'}, {bucket_mb} MiB buckets of the flat "
+                                            "gradient arena launched during the backward pass; MLM loss = mean over the labelled "
+                                            "tokens of the GLOBAL batch (4-byte label-count all-reduce in the forward pass, "
+                                            "ddp.GradReducer.label_sync), so the rank average equals the one-process step on the "
+                                            "whole batch"),
                           "loss": round(loss_value, 4)},
                # FLOPs the default path EXECUTES (padded caption rows and unlabelled MLM rows skipped) over the step time; the
                # reference-equivalent 132.7 GFLOP/pair figure is quoted only for the run that executes it (value_dense_rows)
                "executed_gflop_per_pair": round(gpp_exec, 1),
                "step_tflops_per_gpu": round(value / world * gpp_exec / 1e3, 2),
                "step_mfma_frac": round(value / world * gpp_exec / 1e3 / PEAK_BF16_TFLOPS, 4),
-               "roofline": roofline, "roofline_wgrad_group": roofline_wgrad}
+               "roofline": roofline, "roofline_wgrad_group": roofline_wgrad, "blocks": blocks}
         if dense is not None:
             out.update(dense)
         if extra is not None:

@@ -238,6 +238,12 @@ class MVLBert(nn.Module):
             done = torch.cuda.Event()
             done.record(side)
             torch.cuda.current_stream().wait_event(done)
+            # the plan tensors live in the SIDE stream's allocator pool and are read by main-stream kernels: tell the
+            # caching allocator, so a later side-stream allocation cannot reuse a block a queued main-stream kernel reads
+            main = torch.cuda.current_stream()
+            for t in (rs, sl, tot, rs64, trow) + tuple(self.__dict__.get("_mvlt_label_plan") or ()):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
         else:
             with ops.pin_stream():
                 rs, sl, tot, rs64, trow = ops.pack_plan(text_idx, lab, n_img)

@@ -49,23 +49,37 @@ def seed_coin_flip(seed: int) -> None:
 GAP_ELEMS = 2 << 20      # ranges of one bucket separated by less than this (8 MB of f32) leave as ONE collective
 
 
-def plan_ranges(arena: Arena, lo: int, hi: int, done: set, gap_elems: int = GAP_ELEMS) -> List[Tuple[int, int]]:
+def plan_ranges(arena: Arena, lo: int, hi: int, done: set, gap_elems: int = GAP_ELEMS, idle_ok=None,
+                rode_along: list | None = None) -> List[Tuple[int, int]]:
     """Contiguous element ranges inside [lo, hi) covered by parameters that
     received a gradient this step and have not been reduced yet (``done`` is
     updated).  Ranges separated only by a SMALL run of parameters without a gradient (the never-used Swin classifier
     head, resnet_fc, embedding_LayerNorm: 9 MB in all) are merged, so a bucket is one collective; the gap's stale
-    gradient slots are reduced along (nobody reads them: p.grad is None there).  The idle MLM head (96 MB) stays a gap."""
+    gradient slots are reduced along (nobody reads them: p.grad is None there).  The idle MLM head (96 MB) stays a gap.
+    A gap is merged only when ``idle_ok(p)`` holds for every parameter in it (GradReducer: frozen, or without a gradient
+    in the previous completed step -- a parameter whose gradient may still arrive later in this backward pass must not
+    be swept into an in-place collective); the ids of the parameters that ride along are appended to ``rode_along``."""
     out: List[List[int]] = []
+    gap: List[int] = []                      # ids of the gradient-less parameters since the last range
+    gap_ok = True
     for p in arena.params_between(lo, hi):
         o = arena.offset[id(p)]
         e = o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         if not arena.has_grad[id(p)] or id(p) in done:
+            if not arena.has_grad[id(p)]:
+                gap.append(id(p))
+                gap_ok = gap_ok and (idle_ok is None or idle_ok(p))
+            else:
+                gap_ok = False               # reduced earlier in this pass: never ride along a second time
             continue
         done.add(id(p))
-        if out and 0 <= o - out[-1][1] <= gap_elems:
+        if out and gap_ok and 0 <= o - out[-1][1] <= gap_elems:
             out[-1][1] = e
+            if rode_along is not None:
+                rode_along.extend(gap)
         else:
             out.append([o, e])
+        gap, gap_ok = [], True
     return [(a, b) for a, b in out]
 
 
@@ -87,14 +101,15 @@ class GradReducer:
         on both streams when the bucket leaves (each gradient element is written once per backward pass, before that point
         -- tests/test_model_gpu.py::test_ddp_buckets_carry_final_gradients checks every element, both settings run in
         tests/test_ddp_gpu.py); _finish waits for every handle before the optimizer or the next backward pass touches
-        the arena.  NOT yet run over RCCL on more than one GPU by the builder (one-GPU boxes): MVLT_DDP_FORK=0 restores
-        the main-stream join."""
+        the arena.  NOT yet run over RCCL on more than one GPU by the builder (one-GPU boxes), so the DEFAULT is the
+        main-stream join (MVLT_DDP_FORK unset / 0): the collective is then ordered by the stream every gradient kernel was
+        queued on or joined into -- correct by construction; MVLT_DDP_FORK=1 / fork_stream=True opts into the helper stream."""
         if comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("comm_dtype must be float32 or bfloat16")
         import os
         self.comm_dtype = comm_dtype
         self.average = average
-        self.use_fork = (os.environ.get("MVLT_DDP_FORK", "1") == "1") if fork_stream is None else bool(fork_stream)
+        self.use_fork = (os.environ.get("MVLT_DDP_FORK", "0") == "1") if fork_stream is None else bool(fork_stream)
         self.global_label_mean = global_label_mean
         self.gap_elems = merge_gap_elems      # plan_ranges: small runs of gradient-less parameters do not split a bucket
         self.comm_buf = None
@@ -113,6 +128,8 @@ class GradReducer:
         self.launched: List[Tuple[int, int]] = []
         self.done: set = set()
         self.pending_hi = 0
+        self.prev_marked = None    # ids of the parameters that received a gradient in the previous completed backward pass
+        self.rode_along: list = []  # ids of gradient-less parameters swept into a merged collective in this pass
         self.on_bucket = None      # optional consumer (ranges, handles) of a launched bucket: optim.FusedAdamW overlap
         self.attach()
 
@@ -145,6 +162,13 @@ class GradReducer:
         self.pending_hi = arena.total
         self.handles, self.launched, self.done = [], [], set()
         self.pending_casts = []
+        self.rode_along = []
+
+    def _idle_ok(self, p) -> bool:
+        # may this gradient-less parameter's stale slot ride along in a merged collective?  Only when nothing suggests its
+        # gradient could still arrive in this pass: frozen, or it had none in the previous completed pass either (the first
+        # pass merges nothing)
+        return (not p.requires_grad) or (self.prev_marked is not None and id(p) not in self.prev_marked)
 
     def _on_watermark(self, arena: Arena, lo: int) -> None:
         if self.pending_hi - lo >= self.bucket_elems:
@@ -166,7 +190,7 @@ class GradReducer:
                     fork = self._fork_stream = torch.cuda.Stream(device=arena.flat.device)
                 fork.wait_stream(torch.cuda.current_stream())
                 fork.wait_stream(ops.side_stream(arena.flat.device))
-        ranges = plan_ranges(arena, lo, hi, self.done, self.gap_elems)
+        ranges = plan_ranges(arena, lo, hi, self.done, self.gap_elems, self._idle_ok, self.rode_along)
         op = dist.ReduceOp.AVG if (self.average and self._avg_op) else dist.ReduceOp.SUM
 
         def reduce_ranges(rs):
@@ -207,8 +231,15 @@ class GradReducer:
     def _finish(self, arena: Arena) -> None:
         # everything not yet communicated, including parameters whose gradient
         # arrived out of watermark order (independent head branches)
+        late = [pid for pid in self.rode_along if arena.has_grad[pid]]
+        if late:
+            # a parameter that rode along in a merged collective as "gradient-less" was written afterwards: its slot was
+            # reduced in place while (or before) its gradient arrived, and would be reduced again below
+            raise RuntimeError(f"mvlt_amd.ddp: {len(late)} parameter(s) received a gradient after their arena slot had left in "
+                               "a merged bucket; construct GradReducer(merge_gap_elems=0) for models with data-dependent branches")
         self._launch(arena, 0, arena.total)
         self.pending_hi = 0
+        self.prev_marked = {id(p) for p in arena._marked}
         for h in self.handles:
             h.wait()
         self.handles = []

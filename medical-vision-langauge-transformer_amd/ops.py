@@ -339,8 +339,11 @@ def layernorm_acc_fwd(acc, bias, residual, gamma, beta, eps, dtype, out=None):
 
 
 _GROUP_LONG_K = int(os.environ.get("MVLT_GROUP_LONG_K", "8192"))
-# MVLT_DETERMINISTIC=1: no float atomics on the training / decoding path (Swin stage-0/1 weight gradients take split-K
-# slabs + the deterministic reduce instead of atomic k-slices; greedy decoding does not split its reductions)
+# MVLT_DETERMINISTIC=1: no float-atomic k-slices in the GEMM path (the 4-wave fallback of the Swin stage-0/1 weight
+# gradients takes split-K slabs + the deterministic reduce; greedy decoding does not split its reductions).  Still
+# accumulated with float atomics under the flag: the relative-position-bias-table gradient (swin_attn_bwd2_kernel) and the
+# word-embedding gradient (embed_bwd); tests/test_model_gpu.py::test_config2_step_is_bit_reproducible_* lists them.  The
+# flag is read once at import (decode.py too): set it before importing the package.
 DETERMINISTIC = os.environ.get("MVLT_DETERMINISTIC", "0") == "1"
 
 
