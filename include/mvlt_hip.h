@@ -36,7 +36,7 @@ enum { MVLT_OK = 0, MVLT_ERR_ARG = -1, MVLT_ERR_LAUNCH = -2, MVLT_ERR_UNSUPPORTE
  * signature; a binding compiles / hard-codes the value it was written against and compares it with what the
  * loaded library returns.  mvlt_sizeof(MVLT_STRUCT_*) lets a binding that mirrors the structs by hand (ctypes,
  * cgo, JNI) prove that its mirror has the size the library was compiled with (0 for an unknown id). */
-#define MVLT_ABI_VERSION 3
+#define MVLT_ABI_VERSION 4
 int mvlt_version(void);            /* MVLT_ABI_VERSION of the loaded library */
 const char* mvlt_arch(void);       /* "gfx950" */
 enum { MVLT_STRUCT_GEMM = 0, MVLT_STRUCT_LAYERNORM = 1, MVLT_STRUCT_LAYERNORM_BWD = 2, MVLT_STRUCT_LN_REDUCE_ITEM = 3,
@@ -265,6 +265,19 @@ int mvlt_swin_wmsa_supported(int dtype, int C, int nH);   /* 1 when the fused ke
 int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream);
 int mvlt_swin_wmsa_bwd(const MvltSwinWmsa* p, void* stream);
 int mvlt_swin_wmsa_bwd_supported(int dtype, int C, int nH);
+
+/* Second design of the fused forward (csrc/wmsa2.hip, bf16): a workgroup owns TWO windows (98 rows share every weight
+ * fragment) and a GROUP of heads; the head groups of a window pair run in different workgroups and meet through
+ * attn_out (write-through stores, arrival counter, sc1 loads) before each computes its own output columns of the
+ * projection -- still ONE launch, and 256 workgroups at stage 2 of a B = 32 step where the first design has 128.
+ * Same MvltSwinWmsa fields as mvlt_swin_wmsa_fwd (head_split ignored) with two differences: attn_out is REQUIRED (it is
+ * the exchange buffer; eval callers pass scratch), and sync_ws is an int32 workspace of mvlt_swin_wmsa2_sync_words(B, res)
+ * words that the caller zeroes ONCE when it allocates it: the kernel leaves it zeroed; the last word is a sticky error
+ * flag (a bounded wait ran out: never expected).  One launch at a time per sync_ws (launches on one stream are fine).
+ * Replaces visual_feature_extractor.py:224-254, 356-384 exactly like mvlt_swin_wmsa_fwd. */
+int mvlt_swin_wmsa2_supported(int dtype, int B, int res, int C, int nH);
+int mvlt_swin_wmsa2_sync_words(int B, int res);
+int mvlt_swin_wmsa2_fwd(const MvltSwinWmsa* p, int32_t* sync_ws, void* stream);
 
 /* ------------------------------------------------------------------ data movement / embeddings
  * PatchEmbed im2col (visual_feature_extractor.py:562): img f32 NCHW [B,3,S,S]

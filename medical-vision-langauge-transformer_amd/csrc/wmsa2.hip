@@ -1,0 +1,701 @@
+// Fused Swin (S)W-MSA forward, second design (round 4): several windows per workgroup, heads split across workgroups.
+// Same contract as wmsa.hip (MvltSwinWmsa, include/mvlt_hip.h): the attention half of a SwinTransformerBlock
+// (visual_feature_extractor.py:224-254 and :356-384) in ONE launch, bf16 storage / f32 accumulation.
+//
+// Why a second design: with one window per workgroup (wmsa.hip) every workgroup streams all 8 C^2 bytes of projection
+// weights for 49 rows, and a stage-2 launch of a B = 32 step has 128 windows for 256 CUs (profiles/r2_wmsa_pmc.md:
+// 7.6 % MFMA busy).  Here a UNIT is (W consecutive windows) x (G heads):
+//   * M = 49 W token rows share every weight fragment (W = 2: 98 rows = seven 16-row MFMA tiles, 12.5 % padding instead
+//     of 23 %), so a weight element is fetched from L2 once per 98 rows;
+//   * the nH / G head groups of a window set go to DIFFERENT workgroups: stage 2 at B = 32 is 64 sets x 4 groups = 256
+//     workgroups, one per CU, each streaming its own 6 C x 32 G slice of Wqkv and 32 G x C slice of Wproj;
+//   * the output projection needs all heads of a row: the groups meet through the attention-output tensor itself
+//     (attn_out, which training saves anyway).  Each workgroup writes its [M, 32 G] slice WRITE-THROUGH (sc1), drains,
+//     and adds to an arrival counter; when the counter shows all groups, it reads the full [M, C] rows back with sc1 loads
+//     (cdna_hip_programming.md Guideline 16, counter form; no fence, L1 bypassed) and computes ITS 32 G output columns
+//     of proj + bias + DropPath + shortcut.  Nothing depends on dispatch order or XCD placement; what the wait needs is
+//     that the groups of a set are co-resident: the launch is persistent with at most one workgroup per CU
+//     (grid <= 256, a multiple of the group count; LDS use forces one per CU), units dealt round-robin, so the groups
+//     of a set are always in flight together.  Spins are bounded (error word in the sync workspace).
+//   * counters clean up after themselves (the last group to finish READING resets them), so no memset per launch.
+//
+// Phases of a unit (8 waves):
+//   0  gather M rows through the row map, LayerNorm (f32 statistics) -> LDS tile [16 MT][C], XOR-swizzled so that the
+//      A fragments are conflict-free ds_read_b128 (scripts/lds_bank_model.py); group 0 also saves xn / mean / rstd
+//   1  qkv projection of the group's heads: N tiles dealt to the waves, weight fragments straight from L2 into MFMA
+//      operands through a register ring PD k-steps deep; q, k, v (+ bias) -> LDS tiles [part][head][row][32] with 64-byte
+//      rows, chunk' = (chunk + 2 (row >> 2)) & 3 (conflict-free row AND transposed reads at any window offset)
+//   2  attention: (window, head, query tile) units; scores transposed (keys on accumulator rows) so softmax is in-register;
+//      the accumulators START at (bias + mask) / scale -- read from an LDS copy of the table through per-lane offsets with
+//      the head as an immediate -- and exp2 folds scale and max into one fma: ~6 vector instructions per score
+//   3  hand-off (above), then the projection slice with all its weight fragments prefetched before the wait
+#include "common.h"
+#include "attn_frag.h"
+#include <stdlib.h>
+
+namespace {
+using namespace mvlt_attn;
+typedef bf16_t T;
+using Frag = bf16x8;
+
+struct Wmsa2Dev {
+    int nwin, nW, res, shift, nH, nunits;
+    const T* x; T* y; const int* w2n;
+    const float* gamma; const float* beta; float eps;
+    const T* wqkv; const float* bqkv; const T* wproj; const float* bproj;
+    const float* bias_table; float scale;
+    const float* rowscale;
+    T* xn; T* ao; T* qkv; float* lse; float* mean; float* rstd;
+    int* sync;               // [nsets] arrivals, [nsets] readers done, [1] error word
+};
+
+template <int C, int W, int G, int GS> struct W2Geom {
+    static constexpr int M = 49 * W, MT = (M + 15) / 16, MR = MT * 16;
+    static constexpr int NH = C / 32, NHG = NH / G, NSUB = G / GS;
+    static constexpr int QR = (49 * (W - 1) + 64 + 3) / 4 * 4;            // rows of one (part, head) tile
+    static constexpr int OC = G * 32;                                      // columns of the attention-output tile
+    static constexpr int XB = MR * C * 2;
+    static constexpr int QB = 3 * GS * QR * 64;
+    static constexpr int TB = G * 176 * 4;
+    static constexpr bool ALIAS_O = NSUB == 1 && NHG > 1 && (XB + QB + MR * OC * 2 + TB > 160 * 1024);
+    static constexpr int OB = ALIAS_O ? 0 : MR * OC * 2;
+    static constexpr int bytes = XB + QB + OB + TB;
+    static_assert(bytes <= 160 * 1024, "LDS");
+    static_assert(NH % G == 0 && G % GS == 0, "head groups");
+    static_assert((W * GS * 4) % 8 == 0, "attention units per wave");
+};
+
+// [rows][CC] bf16 tile: byte offset of 16-byte chunk `chunk` of row `row`; chunks XOR-swizzled with the row inside groups
+// of 16 / 8 / 4 chunks (whatever divides the row) -- the A fragments of every k-step are then conflict-free for C = 384, 768
+template <int CC> MVLT_DEV int xoff(int row, int chunk) {
+    constexpr int CPR = CC / 8;
+    constexpr int GRP = CPR % 16 == 0 ? 16 : (CPR % 8 == 0 ? 8 : 4);
+    return row * (CC * 2) + (((chunk & ~(GRP - 1)) | ((chunk ^ row) & (GRP - 1))) << 4);
+}
+// [rows][32] bf16 tile with 64-byte rows
+MVLT_DEV int hoff(int row, int chunk) { return row * 64 + (((chunk + 2 * (row >> 2)) & 3) << 4); }
+
+MVLT_DEV void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// -DW2_TRACE (diagnostic build only): thread 0 of every workgroup stamps the 100 MHz real-time counter at the phase
+// boundaries of its FIRST unit into a buffer set by mvlt_swin_wmsa2_trace_buffer (scripts/wmsa2_trace.py reads it)
+#ifdef W2_TRACE
+__device__ long long* g_w2_trace = nullptr;
+#define W2_STAMP(k) do { if (threadIdx.x == 0 && g_w2_trace && unit < (int)gridDim.x) { g_w2_trace[blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memrealtime(); g_w2_trace[blockIdx.x * 64 + 32 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define W2_STAMP(k) do { } while (0)
+#endif
+
+typedef __attribute__((address_space(3))) char lds_char;
+MVLT_DEV uint32_t lds_addr(const void* q) { return (uint32_t)(uintptr_t)(lds_char*)q; }      // generic pointer into LDS -> LDS byte address
+MVLT_DEV float lds_f32(uint32_t a) { return *reinterpret_cast<__attribute__((address_space(3))) float*>(a); }
+MVLT_DEV Frag lds_frag(uint32_t a) { return *reinterpret_cast<__attribute__((address_space(3))) Frag*>(a); }
+MVLT_DEV bf16x4 lds_tr(uint32_t a) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(a)); }
+// sum over the 2 / 4 / 8 / 16 consecutive lanes of a row segment with DPP adds (no LDS round trips)
+template <int LPR> MVLT_DEV float row_sum(float v) {
+    static_assert(LPR <= 16, "row_sum: one DPP row");
+    if (LPR >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    if (LPR >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    if (LPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    if (LPR >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)); // row_mirror
+    return v;
+}
+
+template <int C, int W, int G, int GS>
+__global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using GM = W2Geom<C, W, G, GS>;
+    constexpr int M = GM::M, MT = GM::MT, MR = GM::MR, NHG = GM::NHG, NSUB = GM::NSUB, QR = GM::QR, OC = GM::OC;
+    constexpr int NT = 512, NWV = 8;
+    constexpr int KSTEPS = C / 32;
+    constexpr int NTQ = 6 * GS, NTQW = (NTQ + NWV - 1) / NWV;      // qkv N tiles of a head sub-group, per wave
+    constexpr int NTP = (NHG > 1 ? OC : C) / 16, NTPW = (NTP + NWV - 1) / NWV;   // output-projection N tiles of this group
+    constexpr int PD = KSTEPS < 4 ? KSTEPS : 4;
+    constexpr int UPW = W * GS * 4 / NWV;                           // (head, query tile) attention units per wave
+    constexpr bool PAIR = C % 64 == 0;
+    constexpr int TILE = QR * 64;                                   // bytes of one (part, head) q/k/v tile
+    static_assert(C % 32 == 0, "width");
+    static_assert(W == 1 || W == 2, "windows per unit");
+
+    char* xln = smem;                                   // [MR][C] LayerNorm tile; later the full attention output [MR][C]
+    char* qkvt = smem + GM::XB;                         // [3][GS][QR][32]
+    char* ot = GM::ALIAS_O ? smem : smem + GM::XB + GM::QB;        // [MR][OC] attention output of this group's heads
+    float* tbl = reinterpret_cast<float*>(smem + GM::XB + GM::QB + GM::OB);     // [G][176] (bias / scale; 169.. = -1e30)
+
+    const int nsets = p.nwin / W;
+    const float cexp = p.scale * 1.4426950408889634f;   // exp(scale s) = exp2(cexp s)
+    const float inv_scale = 1.0f / p.scale;
+    const int nwx = p.res / 7;
+    constexpr int HS = 2 / W;
+
+    const __amdgpu_buffer_rsrc_t ao_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ao, 0, (int)((long)p.nwin * 49 * C * 2), 0x00020000);
+    // lse stores of invalid lanes (padded queries) and of eval launches (no lse) are dropped by the range check
+    const __amdgpu_buffer_rsrc_t lse_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.lse, 0, p.lse ? (int)((long)p.nwin * p.nH * 49 * 4) : 0, 0x00020000);
+
+    // unit order: blocks b and b + 8 share an XCD (observed round-robin placement; speed only), so the blocks of one XCD take a
+    // CONTIGUOUS run of units: the head groups of a window set then share an L2 (its rows are fetched once instead of NHG
+    // times).  (grid / 8) * 8 blocks are remapped, the rest keep their index; grid is a multiple of NHG either way.
+    const int gpx = gridDim.x / 8;
+    const int bid = ((int)blockIdx.x < gpx * 8 && gpx % NHG == 0) ? ((int)blockIdx.x & 7) * gpx + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+#pragma unroll 1
+    for (int unit = bid; unit < p.nunits; unit += gridDim.x) {
+        // every per-lane quantity is derived INSIDE the loop from an opaque copy of the thread id: with one unit per
+        // workgroup (the B = 32 case) loop-invariant hoisting only buys ~600 instructions and ~90 spilled registers up front
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c15 = lane & 15;
+        // element offset of a lane's 16 bytes at k-step kk inside a weight row / chunk index inside an activation row:
+        // lane group g takes bytes [32 g, 32 g + 32) of every 128-byte line, first half at the even step (whole lines per pair)
+        auto koff = [&](int kk) -> int { return PAIR ? (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 : kk * 32 + g * 8; };
+        auto kchunk = [&](int kk) -> int { return PAIR ? (kk >> 1) * 8 + 2 * g + (kk & 1) : kk * 4 + g; };
+        // attention units of this wave: window wloc, heads hl0 + HS u (u < UPW), query tile qt: the window is fixed per wave
+        // and the head advances by a compile-time step, so every LDS address is a per-lane constant plus an immediate
+        const int qt = wave & 3;
+        const int qrow = 16 * qt + c15;
+        const int wloc = W == 2 ? (wave >> 2) : 0, hl0 = W == 2 ? 0 : (wave >> 2);
+        const int rbase = 49 * wloc;
+
+        const int set = unit / NHG, hg = unit - set * NHG;
+        const int win0 = set * W;
+        const int head0 = hg * G;
+        const long grow0 = (long)win0 * 49;                 // first window-order row of the set
+        W2_STAMP(0);
+
+        // token row of window-order row m of this unit: roll(-shift) + window_partition (visual_feature_extractor.py:144-156,
+        // 360-367) evaluated directly -- the INT map of SURVEY 8a2 / 8a3 (mvlt_amd.indexing.window_token_map), no table read
+        int wbase[W], wy7[W], wx7[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int win = win0 + w, b = win / p.nW, wi = win - b * p.nW, wy = wi / nwx;
+            wbase[w] = b * p.res * p.res; wy7[w] = 7 * wy; wx7[w] = 7 * (wi - wy * nwx);
+        }
+        auto tok_of = [&](int m) -> int {
+            const int w = (W == 2 && m >= 49) ? 1 : 0, slot = m - 49 * w, sy = div7(slot), sx = slot - 7 * sy;
+            int h = wy7[w] + sy + p.shift, x = wx7[w] + sx + p.shift;
+            h = h >= p.res ? h - p.res : h; x = x >= p.res ? x - p.res : x;
+            return wbase[w] + h * p.res + x;
+        };
+
+        auto wq_ptr = [&](int hs, int t) -> const T* {      // weight row of qkv tile t (sub-group hs) for this lane
+            const int tt = min(t, NTQ - 1);
+            const int part = tt / (2 * GS), within = tt - part * 2 * GS;
+            return p.wqkv + (long)(part * C + (head0 + hs * GS) * 32 + within * 16 + c15) * C;
+        };
+        Frag fb[PD][NTQW];
+        uint32_t ridx[4], rowbits = 0, colbits = 0;
+        // ---- gather the rows (token order -> window order), LayerNorm, normalised tile -> LDS
+        {
+            constexpr int CPR = C / 8;                                       // 16-byte chunks per row
+            constexpr int LPR = CPR % 3 == 0 ? CPR / 3 : CPR / 2;             // lanes per row
+            constexpr int CPL = CPR / LPR;
+            constexpr int RPP = NT / LPR, NPASS = (MR + RPP - 1) / RPP;
+            static_assert(LPR <= 16 && (LPR & (LPR - 1)) == 0 && NT % LPR == 0, "LayerNorm lanes per row");
+            const int sub = tid % LPR, r0 = tid / LPR;
+            bf16x8 xv[NPASS][CPL];
+            int tok[NPASS];
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int row = ps * RPP + r0;
+                tok[ps] = row < M ? tok_of(row) : -1;
+                const T* src = p.x + (long)max(tok[ps], 0) * C;
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) xv[ps][i] = *reinterpret_cast<const bf16x8*>(src + (sub + LPR * i) * 8);
+            }
+            // gamma / beta of this lane's chunks: the same for every pass
+            f32x4 ga[CPL][2], be[CPL][2];
+#pragma unroll
+            for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    ga[i][hf] = load4f(p.gamma + (sub + LPR * i) * 8 + 4 * hf);
+                    be[i][hf] = load4f(p.beta + (sub + LPR * i) * 8 + 4 * hf);
+                }
+            // ---- the first weight fragments (requested right behind the rows: vmcnt retires in order and the LayerNorm math waits for the rows)
+#pragma unroll
+            for (int jj = 0; jj < NTQW; ++jj) {
+                const T* w = wq_ptr(0, wave + NWV * jj);
+#pragma unroll
+                for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
+            }
+            // packed pair facts of this wave's query tile (relative-position indices, border bits): 5 registers carried to the
+            // attention phase, expanded there
+            if (p.shift == 0 || p.shift == 3) {
+                const int e = qt * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ridx[t] = SWIN_PAIRS.ridx[e][t];
+                const uint32_t bb = p.shift ? SWIN_PAIRS.bits3[e] : 0u;
+                rowbits = bb & 0xffffu; colbits = bb >> 16;
+            } else {
+                const int query = 16 * qt + c15, oc = min(query, 48), oy = div7(oc), ox = oc - 7 * oy;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    ridx[t] = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = 16 * t + 4 * g + j;
+                        const bool valid = key < 49 && query < 49;
+                        const int kc = min(key, 48), ky = div7(kc), kx = kc - 7 * ky;
+                        ridx[t] |= (uint32_t)(valid ? rel_index(oc, kc) : 169) << (8 * j);
+                        if (valid && ((ky < 7 - p.shift) != (oy < 7 - p.shift))) rowbits |= 1u << (4 * t + j);
+                        if (valid && ((kx < 7 - p.shift) != (ox < 7 - p.shift))) colbits |= 1u << (4 * t + j);
+                    }
+                }
+            }
+
+            // bias table of this group's heads -> LDS, divided by scale (the score accumulators start there)
+            for (int i = tid; i < G * 176; i += NT) {
+                const int h = i / 176, e = i - h * 176;
+                tbl[i] = e < 169 ? p.bias_table[e * p.nH + head0 + h] * inv_scale : NEG_BIG;
+            }
+            // rows of the q/k/v tiles beyond the projected rows (read as padded keys of the last window): finite
+            for (int i = tid; i < 3 * GS * (QR - MR) * 4; i += NT) {
+                const int ch = i & 3, r = (i >> 2) % (QR - MR), tl = (i >> 2) / (QR - MR);
+                *reinterpret_cast<bf16x8*>(qkvt + tl * TILE + hoff(MR + r, ch)) = zero_vec<T>();
+            }
+            bf16x2 ones; ones[0] = (T)1.0f; ones[1] = (T)1.0f;
+#ifdef W2_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            W2_STAMP(16);                                  // rows, gamma / beta, first weight fragments arrived
+#endif
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int row = ps * RPP + r0;
+                if (row < MR) {
+                    const bool rv = tok[ps] >= 0;
+                    // sum and sum of squares with the packed dot product (no conversions), reduced over the row's lanes by DPP
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            bf16x2 a; a[0] = xv[ps][i][e]; a[1] = xv[ps][i][e + 1];
+                            s1 = __builtin_amdgcn_fdot2_f32_bf16(a, ones, s1, false);
+                            s2 = __builtin_amdgcn_fdot2_f32_bf16(a, a, s2, false);
+                        }
+                    s1 = row_sum<LPR>(s1); s2 = row_sum<LPR>(s2);
+                    const float mean = s1 * (1.0f / C);
+                    const float var = fmaxf(s2 * (1.0f / C) - mean * mean, 0.0f);
+                    const float rstd = __builtin_amdgcn_rsqf(var + p.eps);
+                    const bool save = rv && hg == 0;
+                    if (save && sub == 0 && p.mean) { p.mean[tok[ps]] = mean; p.rstd[tok[ps]] = rstd; }
+                    T* xs = (p.xn && save) ? p.xn + (grow0 + row) * C : nullptr;
+                    const float nm = -mean * rstd;
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) {
+                        const int ch = sub + LPR * i;
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float gm = ga[i][e >> 2][e & 3], bt = be[i][e >> 2][e & 3];
+                            // (x - mean) rstd gamma + beta = x (rstd gamma) + (beta - mean rstd gamma)
+                            // (padded rows normalise token 0's data: finite values nobody reads -- no per-element select)
+                            o[e] = (T)fmaf((float)xv[ps][i][e], rstd * gm, fmaf(nm, gm, bt));
+                        }
+                        *reinterpret_cast<bf16x8*>(xln + xoff<C>(row, ch)) = o;
+                        if (xs) *reinterpret_cast<bf16x8*>(xs + ch * 8) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        W2_STAMP(1);                                       // LayerNorm tile ready
+
+#pragma unroll
+        for (int hs = 0; hs < NSUB; ++hs) {
+            // ================= qkv projection of head sub-group hs: [MR, C] x [C, 96 GS]
+            {
+                f32x4 acc[MT][NTQW];
+                f32x4 b4[NTQW];
+#pragma unroll
+                for (int jj = 0; jj < NTQW; ++jj) {
+                    const int t = min(wave + NWV * jj, NTQ - 1);
+                    const int part = t / (2 * GS), within = t - part * 2 * GS;
+                    b4[jj] = load4f(p.bqkv + part * C + (head0 + hs * GS) * 32 + within * 16 + 4 * g);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const T* wrow[NTQW];
+#pragma unroll
+                for (int jj = 0; jj < NTQW; ++jj) wrow[jj] = wq_ptr(hs, wave + NWV * jj);
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    Frag fa[MT];
+#ifdef W2_NO_AREAD
+                    const int ch = kchunk(0);              // (ablation build: A fragments read once)
+#else
+                    const int ch = kchunk(kk);
+#endif
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const Frag*>(xln + xoff<C>(16 * i + c15, ch));
+#pragma unroll
+                    for (int jj = 0; jj < NTQW; ++jj) {
+                        if (wave + NWV * jj < NTQ) {
+#pragma unroll
+                            for (int i = 0; i < MT; ++i)
+                                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk % PD][jj], fa[i], acc[i][jj], 0, 0, 0);
+                        }
+#ifndef W2_NO_WLOAD
+                        if constexpr (PAIR && PD % 2 == 0) {
+                            // the two k-steps of a pair read the two halves of the same 128-byte lines: request them back to back
+                            // (the second request merges with the first's miss; issued one k-step apart the line has left the 32-KB
+                            // L1 again -- 72 KB of fragments are in flight per CU -- and every line crosses L2 -> L1 twice)
+                            if (kk & 1) {
+                                if (kk - 1 + PD < KSTEPS) fb[(kk - 1) % PD][jj] = *reinterpret_cast<const Frag*>(wrow[jj] + koff(kk - 1 + PD));
+                                if (kk + PD < KSTEPS) fb[kk % PD][jj] = *reinterpret_cast<const Frag*>(wrow[jj] + koff(kk + PD));
+                            }
+                        } else {
+                            if (kk + PD < KSTEPS) fb[kk % PD][jj] = *reinterpret_cast<const Frag*>(wrow[jj] + koff(kk + PD));
+                        }
+#endif
+                    }
+                }
+                W2_STAMP(12 + hs);                         // (wave 0) projection MFMAs issued
+                // + bias, to the q/k/v LDS tiles [part][head][row][32]
+#pragma unroll
+                for (int jj = 0; jj < NTQW; ++jj) {
+                    const int t = wave + NWV * jj;
+                    if (t < NTQ) {
+                        const int part = t / (2 * GS), within = t - part * 2 * GS;
+                        char* tile = qkvt + (part * GS + (within >> 1)) * TILE;
+                        const int ch = (within & 1) * 2 + (g >> 1), sub8 = (g & 1) * 8;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            store4f(reinterpret_cast<T*>(tile + hoff(16 * i + c15, ch) + sub8), acc[i][jj] + b4[jj]);
+                    }
+                }
+            }
+            // weight fragments of what comes next: the next sub-group's first k-steps
+            if (hs + 1 < NSUB) {
+#pragma unroll
+                for (int jj = 0; jj < NTQW; ++jj) {
+                    const T* w = wq_ptr(hs + 1, wave + NWV * jj);
+#pragma unroll
+                    for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
+                }
+            }
+            __syncthreads();
+            W2_STAMP(2 + 2 * hs);                          // q, k, v tiles ready
+
+            // ================= (training) q, k, v of the sub-group -> HBM in the [row, 3C] layout of the unfused kernels
+            if (p.qkv) {
+                T* qg = p.qkv + grow0 * 3 * C + (head0 + hs * GS) * 32;
+                for (int idx = tid; idx < M * 3 * GS * 4; idx += NT) {
+                    const int ch = idx & 3, ph = (idx >> 2) % (3 * GS), r = (idx >> 2) / (3 * GS);
+                    const int part = ph / GS, hl = ph - part * GS;
+                    *reinterpret_cast<bf16x8*>(qg + (long)r * 3 * C + part * C + hl * 32 + ch * 8) =
+                        *reinterpret_cast<const bf16x8*>(qkvt + (part * GS + hl) * TILE + hoff(r, ch));
+                }
+            }
+
+            // ================= window attention: heads hl0 + HS u of window wloc, this wave's query tile.  The UPW units are
+            // written stage by stage over u (straight-line code, no branches): three independent chains for the scheduler
+            {
+                const uint32_t qk0 = lds_addr(qkvt) + hl0 * TILE, tb0 = lds_addr(tbl) + (hs * GS + hl0) * 176 * 4;
+                uint32_t mbits = 0;
+                if (p.shift != 0) {
+                    const int wi = (win0 + wloc) % p.nW, wy = wi / nwx, wx = wi - wy * nwx;
+                    mbits = (wy == nwx - 1 ? rowbits : 0u) | (wx == nwx - 1 ? colbits : 0u);
+                }
+                const float maskv = -100.0f * inv_scale;
+                f32x4 sc[UPW][4];
+                // scores start at (bias + mask) / scale
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t a = tb0 + ((ridx[t] >> (8 * j)) & 255u) * 4;
+                        const float mk = (mbits & (1u << (4 * t + j))) ? maskv : 0.0f;
+#pragma unroll
+                        for (int u = 0; u < UPW; ++u) sc[u][t][j] = lds_f32(a + HS * u * 176 * 4) + mk;
+                    }
+                const uint32_t q_a = qk0 + hoff(rbase + 16 * qt + c15, g);
+                Frag fq[UPW];
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) fq[u] = lds_frag(q_a + (0 * GS + HS * u) * TILE);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t k_a = qk0 + hoff(rbase + 16 * t + c15, g);
+#pragma unroll
+                    for (int u = 0; u < UPW; ++u)
+                        sc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(k_a + (1 * GS + HS * u) * TILE), fq[u], sc[u][t], 0, 0, 0);
+                }
+                W2_STAMP(17);                              // score MFMAs issued
+                float mx[UPW], sum[UPW];
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) {
+                    float m = NEG_BIG;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) m = fmaxf(m, sc[u][t][j]);
+                    mx[u] = m;
+                }
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) mx[u] = fmaxf(mx[u], __shfl_xor(mx[u], 16, 64));
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) mx[u] = fmaxf(mx[u], __shfl_xor(mx[u], 32, 64));
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) {
+                    const float mxc = -mx[u] * cexp;
+                    float sm = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(fmaf(sc[u][t][j], cexp, mxc)); sc[u][t][j] = e; sm += e; }
+                    sum[u] = sm;
+                }
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) sum[u] += __shfl_xor(sum[u], 16, 64);
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) sum[u] += __shfl_xor(sum[u], 32, 64);
+                // lse (training); padded queries and eval launches fall outside the descriptor's range and are dropped
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) {
+                    const int h = head0 + hs * GS + hl0 + HS * u;
+                    const long off = (((long)(win0 + wloc) * p.nH + h) * 49 + qrow) * 4;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, fmaf(__builtin_amdgcn_logf(sum[u]), 0.6931471805599453f, mx[u] * p.scale)),
+                                                          lse_rsrc, (g == 0 && qrow < 49) ? (int)off : 0x7fffffff, 0, 0);
+                }
+                W2_STAMP(18);                              // softmax done
+                f32x4 o[UPW][2];
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) { o[u][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[u][1] = o[u][0]; }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int td = 0; td < 2; ++td) {
+                        // V^T fragment: features 16 td .. +15 on the rows, k-slots = keys 32 kb + 4 g + {0..3} and + 16
+                        const int q4 = c15 >> 2, pp = c15 & 3;
+                        const int row = rbase + 32 * kb + 4 * g + q4, el = 16 * td + 4 * pp;
+                        const uint32_t v0 = qk0 + hoff(row, el >> 3) + (el & 7) * 2, v1 = qk0 + hoff(row + 16, el >> 3) + (el & 7) * 2;
+#pragma unroll
+                        for (int u = 0; u < UPW; ++u) {
+                            const bf16x4 lo = lds_tr(v0 + (2 * GS + HS * u) * TILE), hi4 = lds_tr(v1 + (2 * GS + HS * u) * TILE);
+                            Frag fv;
+                            fv[0] = lo[0]; fv[1] = lo[1]; fv[2] = lo[2]; fv[3] = lo[3];
+                            fv[4] = hi4[0]; fv[5] = hi4[1]; fv[6] = hi4[2]; fv[7] = hi4[3];
+                            o[u][td] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, frag_acc<4>(sc[u], kb, T()), o[u][td], 0, 0, 0);
+                        }
+                    }
+                }
+                // normalised output -> attention-output tile; padded queries write the tile's last (unused) row
+                const int orow = qrow < 49 ? rbase + qrow : MR - 1;
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) {
+                    const float inv = __builtin_amdgcn_rcpf(sum[u]);
+#pragma unroll
+                    for (int td = 0; td < 2; ++td) {
+                        const int el = (hs * GS + hl0 + HS * u) * 32 + 16 * td + 4 * g;
+                        store4f(reinterpret_cast<T*>(ot + xoff<OC>(orow, el >> 3) + (el & 7) * 2), o[u][td] * inv);
+                    }
+                }
+            }
+            if (hs + 1 < NSUB) __syncthreads();          // the q/k/v tiles are rewritten by the next sub-group
+        }
+
+        // ================= output-projection operands that do not depend on the other groups: ALL weight fragments of this
+        // group's columns, bias, shortcut rows, DropPath scales -- requested before the hand-off so the wait hides them
+        Frag fpj[KSTEPS][NTPW];
+        f32x4 pb4[NTPW], resid[MT][NTPW];
+        int tokm[MT];
+        float rsm[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = 16 * i + c15;
+            tokm[i] = m < M ? tok_of(m) : -1;
+            rsm[i] = (p.rowscale && m < M) ? p.rowscale[(win0 + m / 49) / p.nW] : 1.0f;
+        }
+#pragma unroll
+        for (int jj = 0; jj < NTPW; ++jj) {
+            const int t = min(wave + NWV * jj, NTP - 1);
+            const int n0 = (NHG > 1 ? hg * OC : 0) + 16 * t;
+            const T* w = p.wproj + (long)(n0 + c15) * C;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) fpj[ks][jj] = *reinterpret_cast<const Frag*>(w + koff(ks));
+            pb4[jj] = load4f(p.bproj + n0 + 4 * g);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) resid[i][jj] = load4f(p.x + (long)max(tokm[i], 0) * C + n0 + 4 * g);
+        }
+        W2_STAMP(19);                                      // (wave 0) attention units and prefetch requests issued
+        __syncthreads();                                   // attention-output tile of the group complete
+        W2_STAMP(6);
+
+        const char* atile;                                 // A operand of the projection: [MR][C]
+        if constexpr (NHG > 1) {
+            // ---- this group's [M, OC] slice -> attn_out, write-through
+            {
+                constexpr int CH = OC / 8;
+                for (int idx = tid; idx < M * CH; idx += NT) {
+                    const int r = idx / CH, ch = idx - r * CH;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(ot + xoff<OC>(r, ch));
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ao_rsrc, (int)(((grow0 + r) * C + hg * OC + ch * 8) * 2), 0, 16);
+                }
+            }
+            vm_drain();
+            __syncthreads();
+            W2_STAMP(7);                                   // slice published
+            if (tid == 0) {
+                __hip_atomic_fetch_add(p.sync + set, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // wait for the other groups of the set (bounded: ~2 s, then the error word is set and the result is garbage)
+                const long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+                while (__hip_atomic_load(p.sync + set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NHG) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000LL) {
+                        __hip_atomic_store(p.sync + 2 * nsets, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            W2_STAMP(8);                                   // all groups arrived
+            // ---- all heads of the set's rows: sc1 loads (L1 bypassed: another CU wrote them) -> LDS, A-operand layout
+            {
+                constexpr int CH = C / 8, TOT = M * CH, PER = (TOT + NT - 1) / NT;
+                u32x4 v[PER];
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int idx = min(tid + NT * i, TOT - 1);
+                    v[i] = __builtin_amdgcn_raw_buffer_load_b128(ao_rsrc, (int)((grow0 * C + (long)idx * 8) * 2), 0, 16);
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int idx = tid + NT * i;
+                    if (idx < TOT) { const int r = idx / CH, ch = idx - r * CH; *reinterpret_cast<u32x4*>(xln + xoff<C>(r, ch)) = v[i]; }
+                }
+                // padded rows M..MR-1 of the tile keep the LayerNorm tile's zeros (the attention-output tile ends below them)
+            }
+            __syncthreads();
+            W2_STAMP(9);                                   // full rows in LDS
+            if (tid == NT - 64) {
+                // (last wave: it has no projection tile) every reader counts itself out; the last one re-arms the set's counters
+                const int d = __hip_atomic_fetch_add(p.sync + nsets + set, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d == NHG - 1) {
+                    __hip_atomic_store(p.sync + set, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.sync + nsets + set, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            atile = xln;
+        } else {
+            // all heads are here: (training) the attention output -> HBM for the proj weight gradient
+            if (p.ao) {
+                constexpr int CH = C / 8;
+                for (int idx = tid; idx < M * CH; idx += NT) {
+                    const int r = idx / CH, ch = idx - r * CH;
+                    *reinterpret_cast<u32x4*>(p.ao + (grow0 + r) * C + ch * 8) = *reinterpret_cast<const u32x4*>(ot + xoff<OC>(r, ch));
+                }
+            }
+            atile = ot;
+        }
+
+        // ================= output projection slice: y[M, cols of this group] = A[M, C] Wproj[cols, :]^T
+        {
+            f32x4 pacc[MT][NTPW];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NTPW; ++jj) pacc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int ch = kchunk(ks);
+                Frag fa[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const Frag*>(atile + xoff<C>(16 * i + c15, ch));
+#pragma unroll
+                for (int jj = 0; jj < NTPW; ++jj) {
+                    if (wave + NWV * jj < NTP) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            pacc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fpj[ks][jj], fa[i], pacc[i][jj], 0, 0, 0);
+                    }
+                }
+            }
+            W2_STAMP(10);                                  // projection MFMAs issued
+            // ---- epilogue: + bias, DropPath scale, + shortcut, back to token order
+#pragma unroll
+            for (int jj = 0; jj < NTPW; ++jj) {
+                const int t = wave + NWV * jj;
+                if (t < NTP) {
+                    const int n = (NHG > 1 ? hg * OC : 0) + 16 * t + 4 * g;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        if (tokm[i] >= 0) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (pacc[i][jj][e] + pb4[jj][e]) * rsm[i] + resid[i][jj][e];
+                            store4f(p.y + (long)tokm[i] * C + n, v);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // the LDS tiles are rewritten by the next unit
+        W2_STAMP(11);
+    }
+}
+
+template <int C, int W, int G, int GS>
+int launch2(Wmsa2Dev d, hipStream_t s) {
+    using GM = W2Geom<C, W, G, GS>;
+    if (d.nwin % W) return MVLT_ERR_UNSUPPORTED;
+    const int nsets = d.nwin / W;
+    d.nunits = nsets * GM::NHG;
+    auto k = wmsa2_fwd_kernel<C, W, G, GS>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, GM::bytes);
+    (void)attr;
+    static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    // persistent, at most one workgroup per CU, a multiple of the group count: the groups of a set are in flight together
+    int grid = d.nunits < ncu ? d.nunits : ncu / GM::NHG * GM::NHG;
+    if (grid < GM::NHG) return MVLT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), GM::bytes, s, d);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
+}  // namespace
+
+#ifdef W2_TRACE
+extern "C" int mvlt_swin_wmsa2_trace_buffer(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_w2_trace), &buf, sizeof(buf)) == hipSuccess ? MVLT_OK : MVLT_ERR_LAUNCH;
+}
+#endif
+
+// which (W, G) the second design uses for a width / launch size; 0 = not covered (wmsa.hip or the unfused kernels run)
+extern "C" int mvlt_swin_wmsa2_supported(int dtype, int B, int res, int C, int nH) {
+    if (dtype != MVLT_BF16 || nH * 32 != C || res % 7) return 0;
+    const int nwin = B * (res / 7) * (res / 7);
+    if (nwin % 2) return 0;
+    return C == 384 || C == 192 || C == 96;
+}
+
+// sync_ws: int32 [2 * (B nW / 2) + 1], zeroed ONCE by the caller when it is allocated (the kernel leaves it zeroed);
+// the last word is a sticky error flag (a bounded wait ran out: never expected)
+extern "C" int mvlt_swin_wmsa2_sync_words(int B, int res) { return 2 * (B * (res / 7) * (res / 7) / 2) + 1; }
+
+extern "C" int mvlt_swin_wmsa2_fwd(const MvltSwinWmsa* p, int32_t* sync_ws, void* stream) {
+    MVLT_CHECK(p && p->x && p->y && p->w2n && p->ln_gamma && p->ln_beta, MVLT_ERR_ARG);
+    MVLT_CHECK(p->wqkv && p->bqkv && p->wproj && p->bproj && p->bias_table && p->attn_out && sync_ws, MVLT_ERR_ARG);
+    MVLT_CHECK(p->B > 0 && p->res > 0 && p->res % 7 == 0 && p->shift >= 0 && p->shift < 7, MVLT_ERR_ARG);
+    MVLT_CHECK(aligned16(p->x) && aligned16(p->y) && aligned16(p->wqkv) && aligned16(p->wproj) && aligned16(p->attn_out), MVLT_ERR_ARG);
+    MVLT_CHECK(aligned16(p->ln_gamma) && aligned16(p->ln_beta) && aligned16(p->bqkv) && aligned16(p->bproj), MVLT_ERR_ARG);
+    MVLT_CHECK((p->mean == nullptr) == (p->rstd == nullptr), MVLT_ERR_ARG);
+    if (p->xn_win) MVLT_CHECK(aligned16(p->xn_win), MVLT_ERR_ARG);
+    if (p->qkv_win) MVLT_CHECK(aligned16(p->qkv_win), MVLT_ERR_ARG);
+    if (!mvlt_swin_wmsa2_supported(p->dtype, p->B, p->res, p->C, p->nH)) return MVLT_ERR_UNSUPPORTED;
+    Wmsa2Dev d{};
+    d.nW = (p->res / 7) * (p->res / 7);
+    d.nwin = p->B * d.nW; d.res = p->res; d.shift = p->shift; d.nH = p->nH;
+    d.x = reinterpret_cast<const T*>(p->x); d.y = reinterpret_cast<T*>(p->y); d.w2n = p->w2n;
+    d.gamma = p->ln_gamma; d.beta = p->ln_beta; d.eps = p->ln_eps;
+    d.wqkv = reinterpret_cast<const T*>(p->wqkv); d.bqkv = p->bqkv; d.wproj = reinterpret_cast<const T*>(p->wproj); d.bproj = p->bproj;
+    d.bias_table = p->bias_table; d.scale = p->scale; d.rowscale = p->rowscale;
+    d.xn = reinterpret_cast<T*>(p->xn_win); d.ao = reinterpret_cast<T*>(p->attn_out); d.qkv = reinterpret_cast<T*>(p->qkv_win);
+    d.lse = p->lse; d.mean = p->mean; d.rstd = p->rstd;
+    d.sync = sync_ws;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (p->C) {
+        case 384: return launch2<384, 2, 3, 3>(d, s);       // stage 2: 12 heads in 4 groups
+        case 192: return launch2<192, 2, 6, 3>(d, s);       // stage 1: all 6 heads in one workgroup, two passes of 3
+        case 96:  return launch2<96, 2, 3, 3>(d, s);        // stage 0
+        default: return MVLT_ERR_UNSUPPORTED;
+    }
+}

@@ -670,6 +670,51 @@ def swin_wmsa_fwd(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj
     return y, saved
 
 
+def swin_wmsa2_supported(dtype, B, res, C_, nH):
+    return bool(L.lib().mvlt_swin_wmsa2_supported(_DT[dtype], B, res, C_, nH))
+
+
+_WMSA2_SYNC = {}
+
+
+def wmsa2_sync_ws(device, words):
+    """The int32 hand-off workspace of mvlt_swin_wmsa2_fwd: zeroed once here, left zeroed by every launch (the kernel's
+    counters re-arm themselves).  One per device; launches are serialised by the compute stream."""
+    ws = _WMSA2_SYNC.get(device)
+    if ws is None or ws.numel() < words:
+        ws = torch.zeros(max(words, 4096), dtype=torch.int32, device=device)
+        _WMSA2_SYNC[device] = ws
+    return ws
+
+
+def wmsa2_sync_errors():
+    """Sticky error words of the hand-off workspaces (0 = no bounded wait ever ran out).  Forces a device sync."""
+    return sum(int(ws.ne(0).sum().item()) for ws in _WMSA2_SYNC.values())
+
+
+def swin_wmsa2_fwd(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj, bproj, table, scale,
+                   rowscale=None, save=False):
+    """Second design of the fused forward (csrc/wmsa2.hip): same result as swin_wmsa_fwd, two windows per workgroup,
+    head groups across workgroups.  save=True also returns (xn_win, qkv_win, attn_out, lse, mean, rstd)."""
+    _need_cuda(x)
+    p = _wmsa_struct(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj, bproj, table, scale, rowscale)
+    y = torch.empty_like(x)
+    ao = torch.empty_like(x)
+    p.y, p.attn_out = y.data_ptr(), ao.data_ptr()
+    saved = None
+    if save:
+        rows, Cn = x.shape
+        xn = torch.empty_like(x)
+        qkv = torch.empty((rows, 3 * Cn), dtype=x.dtype, device=x.device)
+        lse = torch.empty((rows // 49, nH, 49), dtype=torch.float32, device=x.device)
+        mean, rstd = torch.empty((2, rows), dtype=torch.float32, device=x.device).unbind(0)
+        p.xn_win, p.lse, p.mean, p.rstd, p.qkv_win = xn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), qkv.data_ptr()
+        saved = (xn, qkv, ao, lse, mean, rstd)
+    ws = wmsa2_sync_ws(x.device, L.lib().mvlt_swin_wmsa2_sync_words(B, res))
+    L.check(L.lib().mvlt_swin_wmsa2_fwd(C.byref(p), ws.data_ptr(), _stream()), "mvlt_swin_wmsa2_fwd")
+    return y, saved
+
+
 def swin_wmsa_bwd_supported(dtype, C_, nH):
     return bool(L.lib().mvlt_swin_wmsa_bwd_supported(_DT[dtype], C_, nH))
 

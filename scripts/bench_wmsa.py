@@ -68,6 +68,14 @@ for st, (res, C, nH) in enumerate([(56, 96, 3), (28, 192, 6), (14, 384, 12)]):
         tf_eval = timeit(lambda: lib.mvlt_swin_wmsa_fwd(ctypes.byref(pe), st_), n=200)
         tf_save = timeit(lambda: lib.mvlt_swin_wmsa_fwd(ctypes.byref(ps), st_), n=200)
         line = f"s{st} res={res} C={C} shift={shift}: fused fwd {tf_eval:6.1f} us ({flop/tf_eval/1e6:6.1f} TFLOP/s), +saves {tf_save:6.1f} us"
+        if ops.swin_wmsa2_supported(dt, B, res, C, nH):
+            ws = ops.wmsa2_sync_ws(x.device, lib.mvlt_swin_wmsa2_sync_words(B, res))
+            wsp = ctypes.c_void_p(ws.data_ptr())
+            pe.attn_out = ao.data_ptr()
+            t2_eval = timeit(lambda: lib.mvlt_swin_wmsa2_fwd(ctypes.byref(pe), wsp, st_), n=200)
+            t2_save = timeit(lambda: lib.mvlt_swin_wmsa2_fwd(ctypes.byref(ps), wsp, st_), n=200)
+            pe.attn_out = None
+            line += f" | v2 fwd {t2_eval:6.1f} us ({flop/t2_eval/1e6:6.1f} TFLOP/s), +saves {t2_save:6.1f} us (sync errors {ops.wmsa2_sync_errors()})"
         # backward: proj dgrad + attention backward + qkv dgrad, fused (one launch) vs the three launches
         if ops.swin_wmsa_bwd_supported(dt, C, nH):
             lib.mvlt_swin_wmsa_fwd(ctypes.byref(ps), st_)

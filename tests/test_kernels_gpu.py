@@ -549,6 +549,59 @@ def test_swin_wmsa_fused_forward(ops, dt, res, C_, shift, B, dp):
     assert rel(y_s, y) < t
 
 
+@pytest.mark.parametrize("res,C_,shift,B,dp", [(14, 384, 3, 3, True), (14, 384, 0, 2, False), (14, 384, 3, 32, True),
+                                              (28, 192, 3, 2, True), (28, 192, 0, 5, False), (56, 96, 3, 1, False),
+                                              (56, 96, 0, 2, True), (14, 384, 5, 1, False)])
+def test_swin_wmsa2_forward(ops, res, C_, shift, B, dp):
+    """mvlt_swin_wmsa2_fwd (two windows per workgroup, head groups across workgroups meeting through attn_out inside the one
+    launch) against the fp32 torch statement and the unfused kernel sequence; B = 32 is the stage-2 launch of config #2 (256
+    workgroups, every CU waits on three others), B = 3 / 5 leave a partly filled grid; the launch is repeated to show the
+    hand-off counters re-arm themselves."""
+    from mvlt_amd._lib import ATTN_SWIN
+    from mvlt_amd.indexing import batched_window_maps
+    dt = torch.bfloat16
+    nH = C_ // 32
+    assert ops.swin_wmsa2_supported(dt, B, res, C_, nH)
+    nW = (res // 7) ** 2
+    x = rnd((B * res * res, C_), dt, 60)
+    g1 = (1.0 + 0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(61))).cuda()
+    b1 = (0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(62))).cuda()
+    wqkv = rnd((3 * C_, C_), dt, 63, C_ ** -0.5)
+    bqkv = (0.1 * torch.randn(3 * C_, generator=torch.Generator().manual_seed(64))).cuda()
+    wproj = rnd((C_, C_), dt, 65, C_ ** -0.5)
+    bproj = (0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(66))).cuda()
+    table = (0.5 * torch.randn(169, nH, generator=torch.Generator().manual_seed(67))).cuda()
+    rs = (0.25 + torch.arange(B, dtype=torch.float32) % 3).cuda() if dp else None
+    scale = 32 ** -0.5
+    w2n, n2w = batched_window_maps(B, res, res, 7, shift, x.device)
+    args = (x, w2n, B, res, nH, shift, g1, b1, 1e-5, wqkv, bqkv, wproj, bproj, table, scale)
+    y, (xn, qkv, ao, lse, mean, rstd) = ops.swin_wmsa2_fwd(*args, rowscale=rs, save=True)
+    ref, xw_ref, ao_ref = wmsa_ref(x.float(), w2n, nW, res, shift, nH, g1, b1, wqkv.float(), bqkv, wproj.float(), bproj,
+                                   table, scale, rs)
+    t = tol(dt)
+    assert rel(xn, xw_ref) < t
+    assert rel(ao, ao_ref) < t * 2
+    assert rel(y, ref) < t * 2
+    # the unfused kernel sequence
+    xn_u, mean_u, rstd_u, _ = ops.layernorm_fwd(x, g1, b1, 1e-5, out_rowmap=n2w)
+    qkv_u = ops.gemm(xn_u, wqkv, bias=bqkv)
+    ao_u, lse_u = ops.attn_fwd(qkv_u, ATTN_SWIN, B * nW, 49, nH, 32, scale, bias_table=table, nW=nW, win_res=res, shift=shift)
+    y_u = ops.gemm(ao_u, wproj, bias=bproj, residual=x, rowmap=w2n, rowscale=(rs, res * res) if rs is not None else None)
+    assert rel(xn, xn_u) < 1e-4 and rel(mean, mean_u) < 1e-5 and rel(rstd, rstd_u) < 1e-5
+    assert rel(qkv, qkv_u) < t
+    assert rel(lse, lse_u) < 2e-3
+    assert rel(ao, ao_u) < t and rel(y, y_u) < t
+    # every row, not just the norm: a wrong window / head slice would hide in a relative norm at B = 32
+    assert float((y.float() - y_u.float()).abs().max()) < 0.25
+    # repeated launches (eval mode: nothing saved) reproduce y bit for bit and leave the sync workspace clean
+    for _ in range(3):
+        y2, none = ops.swin_wmsa2_fwd(*args, rowscale=rs)
+        assert none is None and torch.equal(y2, y)
+    assert ops.wmsa2_sync_errors() == 0
+    ws = ops.wmsa2_sync_ws(x.device, 1)
+    assert int(ws.abs().sum().item()) == 0
+
+
 def bert_ref(qkv, B, Lq, nH, mask_add, scale, keep=None, p=0.0):
     hd = qkv.shape[1] // (3 * nH)
     q, k, v = qkv.view(B, Lq, 3, nH, hd).permute(2, 0, 3, 1, 4)
