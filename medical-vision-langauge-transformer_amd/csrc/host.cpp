@@ -383,13 +383,14 @@ Tensor bert_layer_bwd(const Tensor& dx, const std::vector<Tensor>& sv, const Ptr
 // ----------------------------------------------------------------------------------------------- Swin block
 // w: compute-dtype weights [wqkv, wproj, wfc1, wfc2]; f: f32 [n1g, n1b, bqkv, bproj, table, n2g, n2b, bfc1, bfc2];
 // g: f32 gradients [dn1g, dn1b, dwqkv, dbqkv, dwproj, dbproj, dtable, dn2g, dn2b, dwfc1, dbfc1, dwfc2, dbfc2]
-// geo: [B, H(res), C, nH, shift, fused]; maps: [w2n, n2w] int32 device pointers; s1/s2: DropPath scales f32 [B] or 0
+// geo: [B, H(res), C, nH, shift, fused (0 | 1 wmsa.hip | 2 wmsa2.hip), sync workspace of wmsa2]; maps: [w2n, n2w] int32 device pointers; s1/s2: DropPath scales f32 [B] or 0
 std::vector<Tensor> swin_block_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f, const Ptrs& geo, const Ptrs& maps, double scale,
                                    double eps, int64_t s1, int64_t s2, bool save, int64_t stream_) {
     check_device(x);
     void* st = P(stream_);
     const int B = (int)geo[0], res = (int)geo[1], C = (int)geo[2], nH = (int)geo[3], shift = (int)geo[4];
     const bool fused = geo[5] != 0;
+    const bool fused2 = geo[5] == 2;                     // second design (csrc/wmsa2.hip): geo[6] = its int32 sync workspace
     const int64_t rows = x.size(0);
     const int Lt = res * res, nW = (res / 7) * (res / 7);
     const int dtype = dtype_of(x);
@@ -409,7 +410,12 @@ std::vector<Tensor> swin_block_fwd(const Tensor& x, const Ptrs& w, const Ptrs& f
             xn1w = empty2(rows, C, x); qkv = empty2(rows, 3 * C, x); ao = empty2(rows, C, x); lse = emptyf({rows / 49, nH, 49}, x);
             p.xn_win = dp(xn1w); p.qkv_win = dp(qkv); p.attn_out = dp(ao); p.lse = fp(lse); p.mean = m1; p.rstd = r1;
         }
-        ck(mvlt_swin_wmsa_fwd(&p, st), "mvlt_swin_wmsa_fwd");
+        if (fused2) {
+            if (!save) { ao = empty2(rows, C, x); p.attn_out = dp(ao); }       // the head groups meet through attn_out
+            ck(mvlt_swin_wmsa2_fwd(&p, P<int32_t>(geo[6]), st), "mvlt_swin_wmsa2_fwd");
+        } else {
+            ck(mvlt_swin_wmsa_fwd(&p, st), "mvlt_swin_wmsa_fwd");
+        }
     } else {
         xn1w = empty2(rows, C, x);
         ln_fwd(x, (int)rows, C, f[0], f[1], (float)eps, xn1w, m1, r1, P<const int32_t>(maps[1]), st);

@@ -62,7 +62,6 @@ template <int C, int W, int G, int GS> struct W2Geom {
     static constexpr int bytes = XB + QB + OB + TB;
     static_assert(bytes <= 160 * 1024, "LDS");
     static_assert(NH % G == 0 && G % GS == 0, "head groups");
-    static_assert((W * GS * 4) % 8 == 0, "attention units per wave");
 };
 
 // [rows][CC] bf16 tile: byte offset of 16-byte chunk `chunk` of row `row`; chunks XOR-swizzled with the row inside groups
@@ -101,17 +100,25 @@ template <int LPR> MVLT_DEV float row_sum(float v) {
     return v;
 }
 
-template <int C, int W, int G, int GS>
-__global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
+template <int C, int W, int G, int GS, int NWV>
+__global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GM = W2Geom<C, W, G, GS>;
     constexpr int M = GM::M, MT = GM::MT, MR = GM::MR, NHG = GM::NHG, NSUB = GM::NSUB, QR = GM::QR, OC = GM::OC;
-    constexpr int NT = 512, NWV = 8;
+    constexpr int NT = 64 * NWV;
     constexpr int KSTEPS = C / 32;
     constexpr int NTQ = 6 * GS, NTQW = (NTQ + NWV - 1) / NWV;      // qkv N tiles of a head sub-group, per wave
     constexpr int NTP = (NHG > 1 ? OC : C) / 16, NTPW = (NTP + NWV - 1) / NWV;   // output-projection N tiles of this group
     constexpr int PD = KSTEPS < 4 ? KSTEPS : 4;
-    constexpr int UPW = W * GS * 4 / NWV;                           // (head, query tile) attention units per wave
+    // attention: W GS (window, head) pairs x 4 query tiles; wave = (pair group NG', query tile), UPW pairs per wave.  With as many
+    // pair groups as heads (12 waves, 3 heads) a wave keeps ONE head (bias values in registers) and walks the windows; with as
+    // many as windows (8 waves, 2 windows) it keeps one window and walks the heads
+    constexpr int NG = NWV / 4;
+    constexpr int UPW = W * GS / NG;
+    constexpr bool HEAD_FIXED = NG == GS;
+    static_assert(NWV % 4 == 0 && (W * GS) % NG == 0 && (HEAD_FIXED || NG == W), "attention units per wave");
+    // output projection: NTP column tiles; when there are more waves than tiles the row tiles are split into MG groups
+    constexpr int MG = NTP < NWV ? NWV / NTP : 1, MTW = (MT + MG - 1) / MG;
     constexpr bool PAIR = C % 64 == 0;
     constexpr int TILE = QR * 64;                                   // bytes of one (part, head) q/k/v tile
     static_assert(C % 32 == 0, "width");
@@ -126,7 +133,6 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
     const float cexp = p.scale * 1.4426950408889634f;   // exp(scale s) = exp2(cexp s)
     const float inv_scale = 1.0f / p.scale;
     const int nwx = p.res / 7;
-    constexpr int HS = 2 / W;
 
     const __amdgpu_buffer_rsrc_t ao_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ao, 0, (int)((long)p.nwin * 49 * C * 2), 0x00020000);
     // lse stores of invalid lanes (padded queries) and of eval launches (no lse) are dropped by the range check
@@ -148,12 +154,8 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
         // lane group g takes bytes [32 g, 32 g + 32) of every 128-byte line, first half at the even step (whole lines per pair)
         auto koff = [&](int kk) -> int { return PAIR ? (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 : kk * 32 + g * 8; };
         auto kchunk = [&](int kk) -> int { return PAIR ? (kk >> 1) * 8 + 2 * g + (kk & 1) : kk * 4 + g; };
-        // attention units of this wave: window wloc, heads hl0 + HS u (u < UPW), query tile qt: the window is fixed per wave
-        // and the head advances by a compile-time step, so every LDS address is a per-lane constant plus an immediate
-        const int qt = wave & 3;
+        const int qt = wave & 3, wg = wave >> 2;
         const int qrow = 16 * qt + c15;
-        const int wloc = W == 2 ? (wave >> 2) : 0, hl0 = W == 2 ? 0 : (wave >> 2);
-        const int rbase = 49 * wloc;
 
         const int set = unit / NHG, hg = unit - set * NHG;
         const int win0 = set * W;
@@ -210,48 +212,6 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                     ga[i][hf] = load4f(p.gamma + (sub + LPR * i) * 8 + 4 * hf);
                     be[i][hf] = load4f(p.beta + (sub + LPR * i) * 8 + 4 * hf);
                 }
-            // ---- the first weight fragments (requested right behind the rows: vmcnt retires in order and the LayerNorm math waits for the rows)
-#pragma unroll
-            for (int jj = 0; jj < NTQW; ++jj) {
-                const T* w = wq_ptr(0, wave + NWV * jj);
-#pragma unroll
-                for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
-            }
-            // packed pair facts of this wave's query tile (relative-position indices, border bits): 5 registers carried to the
-            // attention phase, expanded there
-            if (p.shift == 0 || p.shift == 3) {
-                const int e = qt * 64 + lane;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) ridx[t] = SWIN_PAIRS.ridx[e][t];
-                const uint32_t bb = p.shift ? SWIN_PAIRS.bits3[e] : 0u;
-                rowbits = bb & 0xffffu; colbits = bb >> 16;
-            } else {
-                const int query = 16 * qt + c15, oc = min(query, 48), oy = div7(oc), ox = oc - 7 * oy;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    ridx[t] = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int key = 16 * t + 4 * g + j;
-                        const bool valid = key < 49 && query < 49;
-                        const int kc = min(key, 48), ky = div7(kc), kx = kc - 7 * ky;
-                        ridx[t] |= (uint32_t)(valid ? rel_index(oc, kc) : 169) << (8 * j);
-                        if (valid && ((ky < 7 - p.shift) != (oy < 7 - p.shift))) rowbits |= 1u << (4 * t + j);
-                        if (valid && ((kx < 7 - p.shift) != (ox < 7 - p.shift))) colbits |= 1u << (4 * t + j);
-                    }
-                }
-            }
-
-            // bias table of this group's heads -> LDS, divided by scale (the score accumulators start there)
-            for (int i = tid; i < G * 176; i += NT) {
-                const int h = i / 176, e = i - h * 176;
-                tbl[i] = e < 169 ? p.bias_table[e * p.nH + head0 + h] * inv_scale : NEG_BIG;
-            }
-            // rows of the q/k/v tiles beyond the projected rows (read as padded keys of the last window): finite
-            for (int i = tid; i < 3 * GS * (QR - MR) * 4; i += NT) {
-                const int ch = i & 3, r = (i >> 2) % (QR - MR), tl = (i >> 2) / (QR - MR);
-                *reinterpret_cast<bf16x8*>(qkvt + tl * TILE + hoff(MR + r, ch)) = zero_vec<T>();
-            }
             bf16x2 ones; ones[0] = (T)1.0f; ones[1] = (T)1.0f;
 #ifdef W2_TRACE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -260,6 +220,54 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int row = ps * RPP + r0;
+                if (ps == 1 || NPASS == 1) {
+                    asm volatile("" ::: "memory");         // (keeps the requests below behind the first pass's loads)
+            // ---- behind the first rows' statistics: the first weight fragments, the pair facts and the tables.  Requested any
+                    // earlier they queue IN FRONT of nothing but share the start-up burst (every CU fetching ~75 KB of rows at once runs at
+                    // ~11 B/cycle/CU) and the rows, which everything waits for, arrive later
+#pragma unroll
+                    for (int jj = 0; jj < NTQW; ++jj) {
+                        const T* w = wq_ptr(0, wave + NWV * jj);
+#pragma unroll
+                        for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
+                    }
+                    // packed pair facts of this wave's query tile (relative-position indices, border bits): 5 registers carried to the
+                    // attention phase, expanded there
+                    if (p.shift == 0 || p.shift == 3) {
+                        const int e = qt * 64 + lane;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) ridx[t] = SWIN_PAIRS.ridx[e][t];
+                        const uint32_t bb = p.shift ? SWIN_PAIRS.bits3[e] : 0u;
+                        rowbits = bb & 0xffffu; colbits = bb >> 16;
+                    } else {
+                        const int query = 16 * qt + c15, oc = min(query, 48), oy = div7(oc), ox = oc - 7 * oy;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            ridx[t] = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int key = 16 * t + 4 * g + j;
+                                const bool valid = key < 49 && query < 49;
+                                const int kc = min(key, 48), ky = div7(kc), kx = kc - 7 * ky;
+                                ridx[t] |= (uint32_t)(valid ? rel_index(oc, kc) : 169) << (8 * j);
+                                if (valid && ((ky < 7 - p.shift) != (oy < 7 - p.shift))) rowbits |= 1u << (4 * t + j);
+                                if (valid && ((kx < 7 - p.shift) != (ox < 7 - p.shift))) colbits |= 1u << (4 * t + j);
+                            }
+                        }
+                    }
+
+                    // bias table of this group's heads -> LDS, divided by scale (the score accumulators start there)
+                    for (int i = tid; i < G * 176; i += NT) {
+                        const int h = i / 176, e = i - h * 176;
+                        tbl[i] = e < 169 ? p.bias_table[e * p.nH + head0 + h] * inv_scale : NEG_BIG;
+                    }
+                    // rows of the q/k/v tiles beyond the projected rows (read as padded keys of the last window): finite
+                    for (int i = tid; i < 3 * GS * (QR - MR) * 4; i += NT) {
+                        const int ch = i & 3, r = (i >> 2) % (QR - MR), tl = (i >> 2) / (QR - MR);
+                        *reinterpret_cast<bf16x8*>(qkvt + tl * TILE + hoff(MR + r, ch)) = zero_vec<T>();
+                    }
+                    asm volatile("" ::: "memory");
+                }
                 if (row < MR) {
                     const bool rv = tok[ps] >= 0;
                     // sum and sum of squares with the packed dot product (no conversions), reduced over the row's lanes by DPP
@@ -387,38 +395,49 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                 }
             }
 
-            // ================= window attention: heads hl0 + HS u of window wloc, this wave's query tile.  The UPW units are
-            // written stage by stage over u (straight-line code, no branches): three independent chains for the scheduler
+            // ================= window attention: this wave's query tile of UPW (window, head) pairs.  The pairs are written stage
+            // by stage over u (straight-line code, no branches): independent chains for the scheduler
             {
-                const uint32_t qk0 = lds_addr(qkvt) + hl0 * TILE, tb0 = lds_addr(tbl) + (hs * GS + hl0) * 176 * 4;
-                uint32_t mbits = 0;
-                if (p.shift != 0) {
-                    const int wi = (win0 + wloc) % p.nW, wy = wi / nwx, wx = wi - wy * nwx;
-                    mbits = (wy == nwx - 1 ? rowbits : 0u) | (wx == nwx - 1 ? colbits : 0u);
-                }
+                // pair u of this wave: (window, head inside the sub-group)
+                auto pw = [&](int u) -> int { return HEAD_FIXED ? u : wg; };
+                auto ph = [&](int u) -> int { return HEAD_FIXED ? wg : u; };
+                const uint32_t qk0 = lds_addr(qkvt), tb0 = lds_addr(tbl) + hs * GS * 176 * 4;
                 const float maskv = -100.0f * inv_scale;
                 f32x4 sc[UPW][4];
                 // scores start at (bias + mask) / scale
+                uint32_t mbits[UPW];
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) {
+                    mbits[u] = 0;
+                    if (p.shift != 0) {
+                        const int wi = (win0 + pw(u)) % p.nW, wy = wi / nwx, wx = wi - wy * nwx;
+                        mbits[u] = (wy == nwx - 1 ? rowbits : 0u) | (wx == nwx - 1 ? colbits : 0u);
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const uint32_t a = tb0 + ((ridx[t] >> (8 * j)) & 255u) * 4;
-                        const float mk = (mbits & (1u << (4 * t + j))) ? maskv : 0.0f;
+                        if constexpr (HEAD_FIXED) {
+                            const float bv = lds_f32(a + wg * 176 * 4);
 #pragma unroll
-                        for (int u = 0; u < UPW; ++u) sc[u][t][j] = lds_f32(a + HS * u * 176 * 4) + mk;
+                            for (int u = 0; u < UPW; ++u) sc[u][t][j] = (mbits[u] & (1u << (4 * t + j))) ? bv + maskv : bv;
+                        } else {
+                            const float mk = (mbits[0] & (1u << (4 * t + j))) ? maskv : 0.0f;
+#pragma unroll
+                            for (int u = 0; u < UPW; ++u) sc[u][t][j] = lds_f32(a + u * 176 * 4) + mk;
+                        }
                     }
-                const uint32_t q_a = qk0 + hoff(rbase + 16 * qt + c15, g);
                 Frag fq[UPW];
 #pragma unroll
-                for (int u = 0; u < UPW; ++u) fq[u] = lds_frag(q_a + (0 * GS + HS * u) * TILE);
+                for (int u = 0; u < UPW; ++u) fq[u] = lds_frag(qk0 + (0 * GS + ph(u)) * TILE + hoff(49 * pw(u) + 16 * qt + c15, g));
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint32_t k_a = qk0 + hoff(rbase + 16 * t + c15, g);
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int u = 0; u < UPW; ++u)
-                        sc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(k_a + (1 * GS + HS * u) * TILE), fq[u], sc[u][t], 0, 0, 0);
-                }
+                        sc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(qk0 + (1 * GS + ph(u)) * TILE + hoff(49 * pw(u) + 16 * t + c15, g)),
+                                                                            fq[u], sc[u][t], 0, 0, 0);
                 W2_STAMP(17);                              // score MFMAs issued
                 float mx[UPW], sum[UPW];
 #pragma unroll
@@ -451,8 +470,8 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                 // lse (training); padded queries and eval launches fall outside the descriptor's range and are dropped
 #pragma unroll
                 for (int u = 0; u < UPW; ++u) {
-                    const int h = head0 + hs * GS + hl0 + HS * u;
-                    const long off = (((long)(win0 + wloc) * p.nH + h) * 49 + qrow) * 4;
+                    const int h = head0 + hs * GS + ph(u);
+                    const long off = (((long)(win0 + pw(u)) * p.nH + h) * 49 + qrow) * 4;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, fmaf(__builtin_amdgcn_logf(sum[u]), 0.6931471805599453f, mx[u] * p.scale)),
                                                           lse_rsrc, (g == 0 && qrow < 49) ? (int)off : 0x7fffffff, 0, 0);
                 }
@@ -464,13 +483,13 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                 for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                     for (int td = 0; td < 2; ++td) {
-                        // V^T fragment: features 16 td .. +15 on the rows, k-slots = keys 32 kb + 4 g + {0..3} and + 16
-                        const int q4 = c15 >> 2, pp = c15 & 3;
-                        const int row = rbase + 32 * kb + 4 * g + q4, el = 16 * td + 4 * pp;
-                        const uint32_t v0 = qk0 + hoff(row, el >> 3) + (el & 7) * 2, v1 = qk0 + hoff(row + 16, el >> 3) + (el & 7) * 2;
 #pragma unroll
                         for (int u = 0; u < UPW; ++u) {
-                            const bf16x4 lo = lds_tr(v0 + (2 * GS + HS * u) * TILE), hi4 = lds_tr(v1 + (2 * GS + HS * u) * TILE);
+                            // V^T fragment: features 16 td .. +15 on the rows, k-slots = keys 32 kb + 4 g + {0..3} and + 16
+                            const int q4 = c15 >> 2, pp = c15 & 3;
+                            const int row = 49 * pw(u) + 32 * kb + 4 * g + q4, el = 16 * td + 4 * pp;
+                            const uint32_t vb = qk0 + (2 * GS + ph(u)) * TILE + (el & 7) * 2;
+                            const bf16x4 lo = lds_tr(vb + hoff(row, el >> 3)), hi4 = lds_tr(vb + hoff(row + 16, el >> 3));
                             Frag fv;
                             fv[0] = lo[0]; fv[1] = lo[1]; fv[2] = lo[2]; fv[3] = lo[3];
                             fv[4] = hi4[0]; fv[5] = hi4[1]; fv[6] = hi4[2]; fv[7] = hi4[3];
@@ -479,13 +498,13 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                     }
                 }
                 // normalised output -> attention-output tile; padded queries write the tile's last (unused) row
-                const int orow = qrow < 49 ? rbase + qrow : MR - 1;
 #pragma unroll
                 for (int u = 0; u < UPW; ++u) {
+                    const int orow = qrow < 49 ? 49 * pw(u) + qrow : MR - 1;
                     const float inv = __builtin_amdgcn_rcpf(sum[u]);
 #pragma unroll
                     for (int td = 0; td < 2; ++td) {
-                        const int el = (hs * GS + hl0 + HS * u) * 32 + 16 * td + 4 * g;
+                        const int el = (hs * GS + ph(u)) * 32 + 16 * td + 4 * g;
                         store4f(reinterpret_cast<T*>(ot + xoff<OC>(orow, el >> 3) + (el & 7) * 2), o[u][td] * inv);
                     }
                 }
@@ -494,33 +513,39 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
         }
 
         // ================= output-projection operands that do not depend on the other groups: ALL weight fragments of this
-        // group's columns, bias, shortcut rows, DropPath scales -- requested before the hand-off so the wait hides them
+        // wave's columns, bias, shortcut rows, DropPath scales -- requested before the hand-off so the wait hides them.
+        // Wave -> (column tiles pt(jj), row tiles pm0 .. pm0 + MTW): more waves than column tiles split the row tiles
+        const int pm0 = MG > 1 ? (wave / NTP) * MTW : 0;
+        auto pt = [&](int jj) -> int { return MG > 1 ? wave % NTP : wave + NWV * jj; };
+        const bool pact = MG > 1 ? wave < MG * NTP : true;
         Frag fpj[KSTEPS][NTPW];
-        f32x4 pb4[NTPW], resid[MT][NTPW];
-        int tokm[MT];
-        float rsm[MT];
+        f32x4 pb4[NTPW];
+        bf16x4 resid[MTW][NTPW];             // shortcut values, converted where they are used (a conversion here would wait for the load)
+        int tokm[MTW];
+        float rsm[MTW];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = 16 * i + c15;
+        for (int i = 0; i < MTW; ++i) {
+            const int m = 16 * (pm0 + i) + c15;
             tokm[i] = m < M ? tok_of(m) : -1;
             rsm[i] = (p.rowscale && m < M) ? p.rowscale[(win0 + m / 49) / p.nW] : 1.0f;
         }
 #pragma unroll
         for (int jj = 0; jj < NTPW; ++jj) {
-            const int t = min(wave + NWV * jj, NTP - 1);
+            const int t = min(pt(jj), NTP - 1);
             const int n0 = (NHG > 1 ? hg * OC : 0) + 16 * t;
             const T* w = p.wproj + (long)(n0 + c15) * C;
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) fpj[ks][jj] = *reinterpret_cast<const Frag*>(w + koff(ks));
             pb4[jj] = load4f(p.bproj + n0 + 4 * g);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) resid[i][jj] = load4f(p.x + (long)max(tokm[i], 0) * C + n0 + 4 * g);
+            for (int i = 0; i < MTW; ++i) resid[i][jj] = *reinterpret_cast<const bf16x4*>(p.x + (long)max(tokm[i], 0) * C + n0 + 4 * g);
         }
         W2_STAMP(19);                                      // (wave 0) attention units and prefetch requests issued
         __syncthreads();                                   // attention-output tile of the group complete
         W2_STAMP(6);
 
         const char* atile;                                 // A operand of the projection: [MR][C]
+        int done_ticket = -1;
         if constexpr (NHG > 1) {
             // ---- this group's [M, OC] slice -> attn_out, write-through
             {
@@ -566,14 +591,8 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
             }
             __syncthreads();
             W2_STAMP(9);                                   // full rows in LDS
-            if (tid == NT - 64) {
-                // (last wave: it has no projection tile) every reader counts itself out; the last one re-arms the set's counters
-                const int d = __hip_atomic_fetch_add(p.sync + nsets + set, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (d == NHG - 1) {
-                    __hip_atomic_store(p.sync + set, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(p.sync + nsets + set, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            // every reader counts itself out (the add is issued here, its result is looked at after the projection)
+            if (tid == NT - 64) done_ticket = __hip_atomic_fetch_add(p.sync + nsets + set, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atile = xln;
         } else {
             // all heads are here: (training) the attention output -> HBM for the proj weight gradient
@@ -589,23 +608,25 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
 
         // ================= output projection slice: y[M, cols of this group] = A[M, C] Wproj[cols, :]^T
         {
-            f32x4 pacc[MT][NTPW];
+            f32x4 pacc[MTW][NTPW];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MTW; ++i)
 #pragma unroll
                 for (int jj = 0; jj < NTPW; ++jj) pacc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (pact) {
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const int ch = kchunk(ks);
-                Frag fa[MT];
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const int ch = kchunk(ks);
+                    Frag fa[MTW];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const Frag*>(atile + xoff<C>(16 * i + c15, ch));
+                    for (int i = 0; i < MTW; ++i) fa[i] = *reinterpret_cast<const Frag*>(atile + xoff<C>(min(16 * (pm0 + i), MR - 16) + c15, ch));
 #pragma unroll
-                for (int jj = 0; jj < NTPW; ++jj) {
-                    if (wave + NWV * jj < NTP) {
+                    for (int jj = 0; jj < NTPW; ++jj) {
+                        if (pt(jj) < NTP) {
 #pragma unroll
-                        for (int i = 0; i < MT; ++i)
-                            pacc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fpj[ks][jj], fa[i], pacc[i][jj], 0, 0, 0);
+                            for (int i = 0; i < MTW; ++i)
+                                pacc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fpj[ks][jj], fa[i], pacc[i][jj], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -613,19 +634,26 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
             // ---- epilogue: + bias, DropPath scale, + shortcut, back to token order
 #pragma unroll
             for (int jj = 0; jj < NTPW; ++jj) {
-                const int t = wave + NWV * jj;
-                if (t < NTP) {
+                const int t = pt(jj);
+                if (pact && t < NTP) {
                     const int n = (NHG > 1 ? hg * OC : 0) + 16 * t + 4 * g;
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) {
+                    for (int i = 0; i < MTW; ++i) {
                         if (tokm[i] >= 0) {
                             f32x4 v;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = (pacc[i][jj][e] + pb4[jj][e]) * rsm[i] + resid[i][jj][e];
+                            for (int e = 0; e < 4; ++e) v[e] = (pacc[i][jj][e] + pb4[jj][e]) * rsm[i] + (float)resid[i][jj][e];
                             store4f(p.y + (long)tokm[i] * C + n, v);
                         }
                     }
                 }
+            }
+        }
+        if constexpr (NHG > 1) {
+            // the last reader of the set re-arms its counters for the next launch
+            if (tid == NT - 64 && done_ticket == NHG - 1) {
+                __hip_atomic_store(p.sync + set, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.sync + nsets + set, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();                                   // the LDS tiles are rewritten by the next unit
@@ -633,20 +661,20 @@ __global__ __launch_bounds__(512) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
     }
 }
 
-template <int C, int W, int G, int GS>
+template <int C, int W, int G, int GS, int NWV>
 int launch2(Wmsa2Dev d, hipStream_t s) {
     using GM = W2Geom<C, W, G, GS>;
     if (d.nwin % W) return MVLT_ERR_UNSUPPORTED;
     const int nsets = d.nwin / W;
     d.nunits = nsets * GM::NHG;
-    auto k = wmsa2_fwd_kernel<C, W, G, GS>;
+    auto k = wmsa2_fwd_kernel<C, W, G, GS, NWV>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, GM::bytes);
     (void)attr;
     static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
     // persistent, at most one workgroup per CU, a multiple of the group count: the groups of a set are in flight together
     int grid = d.nunits < ncu ? d.nunits : ncu / GM::NHG * GM::NHG;
     if (grid < GM::NHG) return MVLT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), GM::bytes, s, d);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NWV), GM::bytes, s, d);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }
@@ -693,9 +721,10 @@ extern "C" int mvlt_swin_wmsa2_fwd(const MvltSwinWmsa* p, int32_t* sync_ws, void
     d.sync = sync_ws;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (p->C) {
-        case 384: return launch2<384, 2, 3, 3>(d, s);       // stage 2: 12 heads in 4 groups
-        case 192: return launch2<192, 2, 6, 3>(d, s);       // stage 1: all 6 heads in one workgroup, two passes of 3
-        case 96:  return launch2<96, 2, 3, 3>(d, s);        // stage 0
+        // 8 waves: 12 (three per SIMD, 168 registers) measured the same 30 us at stage 2 and spills
+        case 384: return launch2<384, 2, 3, 3, 8>(d, s);    // stage 2: 12 heads in 4 groups
+        case 192: return launch2<192, 2, 6, 3, 8>(d, s);    // stage 1: 6 heads in one workgroup, two passes of 3
+        case 96:  return launch2<96, 2, 3, 3, 8>(d, s);     // stage 0
         default: return MVLT_ERR_UNSUPPORTED;
     }
 }

@@ -106,15 +106,23 @@ class PatchEmbed(nn.Module):
 
 _FUSED_WMSA_BWD = os.environ.get("MVLT_FUSED_WMSA_BWD", "0") == "1"
 _FUSED_WMSA = os.environ.get("MVLT_FUSED_WMSA", "auto")     # "0" never, "1" wherever supported, "auto" where it wins
+_WMSA2 = os.environ.get("MVLT_WMSA2", "1") != "0"           # second design at stage 2 (A/B measurements and parity tests turn it off)
 
 
-def _use_fused_wmsa(dtype, C, nH, nwin):
-    """One-launch W-MSA (mvlt_swin_wmsa_fwd) or the four-launch sequence.  A workgroup owns one window, so the
-    fused kernel needs enough windows to fill the 256 CUs; measured on MI355X (scripts/bench_wmsa.py, B=32):
-    2048 / 512 windows (stages 0 / 1) fused is 2x faster, 128 windows of C=384 (stage 2) it is not."""
-    if _FUSED_WMSA == "0" or not ops.swin_wmsa_supported(dtype, C, nH):
-        return False
-    return _FUSED_WMSA == "1" or nwin >= 512 or (nwin >= 256 and C <= 256)
+def _wmsa_mode(dtype, B, res, C, nH):
+    """How the attention half of a block runs: 0 = four launches, 1 = mvlt_swin_wmsa_fwd (one window per workgroup), 2 =
+    mvlt_swin_wmsa2_fwd (two windows x a head group per workgroup, the groups meet inside the launch).  Measured on MI355X
+    at B = 32 (scripts/bench_wmsa.py, profiles/r4_wmsa*): stage 2 (128 windows of C = 384) 30 us with the second design
+    against 52 us for the first or for four launches; stages 0 / 1 (2048 / 512 windows) both designs are 2x faster than four
+    launches.  MVLT_FUSED_WMSA=0 forces the four launches (the parity tests use it to compare the paths)."""
+    if _FUSED_WMSA == "0":
+        return 0
+    nwin = B * (res // 7) ** 2
+    if _WMSA2 and C >= 384 and nwin >= 64 and ops.swin_wmsa2_supported(dtype, B, res, C, nH):
+        return 2
+    if not ops.swin_wmsa_supported(dtype, C, nH):
+        return 0
+    return 1 if (_FUSED_WMSA == "1" or nwin >= 512 or (nwin >= 256 and C <= 256)) else 0
 
 
 _DP_FOLD = os.environ.get("MVLT_DP_FOLD", "1") != "0"     # the producer's LayerNorm backward writes the DropPath-scaled branch gradient
@@ -287,14 +295,17 @@ class SwinTransformer(nn.Module):
         if ops.NATIVE:
             # one native call per block (csrc/host.cpp swin_block_fwd)
             w, f, _ = self._block_desc(ar, blk)
-            geo = [B, H, C, nH, blk.shift_size, int(_use_fused_wmsa(x.dtype, C, nH, B * nW))]
+            mode = _wmsa_mode(x.dtype, B, H, C, nH)
+            geo = [B, H, C, nH, blk.shift_size, mode,
+                   ops.wmsa2_sync_ws(x.device, L.lib().mvlt_swin_wmsa2_sync_words(B, H)).data_ptr() if mode == 2 else 0]
             out = ops.host().swin_block_fwd(x, w, f, geo, [w2n.data_ptr(), n2w.data_ptr()], at.scale, blk.norm1.eps,
                                             0 if s1 is None else s1.data_ptr(), 0 if s2 is None else s2.data_ptr(),
                                             save, ops.stream_int())
             return out[0], ((blk, out[1:], s1, s2, H, W) if save else None)
-        if _use_fused_wmsa(x.dtype, C, nH, B * nW):
+        mode = _wmsa_mode(x.dtype, B, H, C, nH)
+        if mode:
             # norm1 + shift/partition + qkv + window attention + proj + reverse + DropPath + residual: one launch
-            x1, fs = ops.swin_wmsa_fwd(x, w2n, B, H, nH, blk.shift_size, blk.norm1.weight.data, blk.norm1.bias.data,
+            x1, fs = (ops.swin_wmsa2_fwd if mode == 2 else ops.swin_wmsa_fwd)(x, w2n, B, H, nH, blk.shift_size, blk.norm1.weight.data, blk.norm1.bias.data,
                                        blk.norm1.eps, ar.compute(at.qkv.weight), at.qkv.bias.data,
                                        ar.compute(at.proj.weight), at.proj.bias.data,
                                        at.relative_position_bias_table.data, at.scale, rowscale=s1, save=save)
