@@ -1184,10 +1184,7 @@ __global__ __launch_bounds__(AB2_NT) void bert_attn_bwd2_kernel(const AttnDev p)
     }
 }
 
-static int bert_bwd_form() {          // MVLT_BERT_BWD=split: the two-launch backward
-    static int v = [] { const char* e = getenv("MVLT_BERT_BWD"); return (e && e[0] == 's') ? 0 : 1; }();
-    return v;
-}
+static int bert_bwd_form() { return 1; }          // 1 = one-launch backward where it applies (bf16, <= 160 rows); else two launches
 static int launch_bert_bwd2(const AttnDev& d, hipStream_t s) {
     dim3 grid(d.nseq, d.nH);
     const bool s2s = d.mode == MVLT_ATTN_SEQ2SEQ, drop = d.drop_thresh != 0;
@@ -1224,8 +1221,7 @@ int launch(const AttnDev& d, bool bwd, int dtype, hipStream_t s) {
     if (SWIN) {   // several windows per workgroup: the LDS bias-gradient table is flushed once
         // backward: ~512 workgroups in total, each walking several windows of one head, so the LDS
         // bias-gradient table is flushed with 169 global atomics per workgroup instead of per window
-        static int fwd_target = [] { const char* e = getenv("MVLT_SWF_TARGET"); return e ? atoi(e) : 2048; }();
-        const int target = (bwd ? 512 : fwd_target) / (d.nH > 0 ? d.nH : 1);
+        const int target = (bwd ? 512 : 2048) / (d.nH > 0 ? d.nH : 1);          // (forward: 512 .. 2048 workgroups measured equal)
         if (gx > target) gx = target < 1 ? 1 : target;
     }
     dim3 grid(gx, d.nH);
@@ -1242,11 +1238,8 @@ int launch(const AttnDev& d, bool bwd, int dtype, hipStream_t s) {
     return MVLT_OK;
 }
 
-// Swin backward, bf16, no attention dropout: the scores-once kernel; MVLT_SWIN_BWD=wg keeps attn_bwd_kernel
-static int swin_bwd_form() {
-    static int v = [] { const char* e = getenv("MVLT_SWIN_BWD"); return (e && e[0] == 'w' && e[1] == 'g') ? 0 : 1; }();
-    return v;
-}
+// Swin backward, bf16, no attention dropout: the scores-once kernel (f32 and dropout keep attn_bwd_kernel)
+static int swin_bwd_form() { return 1; }
 static int cu_count() {
     static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev);
                         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
@@ -1260,8 +1253,7 @@ static int launch_swin_bwd2(const AttnDev& d, hipStream_t s) {
     // measured (B = 32, us at 1 / 2 / 3 workgroups per CU): stage 0 45.8 / 43.1 / 45.3, stage 1 28.9 / 32.8 / 35.2,
     // stage 2 20.9 / 25.2 / 29.8, stage 3 13.8 / 16.2 / 21.4 -- the set-up of a workgroup costs more than a second
     // resident workgroup hides, except where every workgroup walks dozens of windows
-    static int forced = [] { const char* e = getenv("MVLT_SW2_WGS"); return e ? atoi(e) : 0; }();
-    const int per_cu = forced > 0 ? forced : ((long)d.nseq * d.nH > 16L * cu_count() ? 2 : 1);
+    const int per_cu = (long)d.nseq * d.nH > 16L * cu_count() ? 2 : 1;
     const int cap = per_cu * cu_count() / d.nH;
     if (gx > cap) gx = cap < 1 ? 1 : cap;
     dim3 grid(gx, d.nH);

@@ -466,93 +466,6 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     asm volatile("" :: "v"(pfv));
 }
 
-// EXPERIMENT (MVLT_BIG=1, off by default): 256 x 256 macro-tile, 8 waves (2 x 4, 128 x 64 outputs per wave), one
-// workgroup per CU, same LDS-DMA double buffer (2 x 64 KB): 8.4 MFLOP per 64 KB loaded (1.8x the 128 x 128 tiles at 2.25
-// workgroups per CU), 0.375 ds_read_b128 per MFMA instead of 0.5.  Measured (profiles/r2_gemm_pmc.md, "macro-tile"):
-// BERT FFN-in forward 40.3 -> 34-35 us, every other eligible shape slower, 16.0 vs 15.5 ms in the step.
-template <int R, int NW>
-MVLT_DEV void glds_fill_n(const bf16_t* const (&src)[R / (8 * NW)], bf16_t* lds_tile, int wave, long koff) {
-#pragma unroll
-    for (int j = 0; j < R / (8 * NW); ++j) {
-        bf16_t* dst = lds_tile + (wave * (R / (8 * NW)) + j) * 8 * 64;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(src[j] + koff), (lds_void_t*)dst, 16, 0, 0);
-    }
-}
-
-template <int BM, int BN>
-__global__ __launch_bounds__(512, 1) void gemm_glds8_kernel(const GemmDev p_in) {
-    using T = bf16_t;
-    constexpr int BKE = 64, NW = 8, WN = 4, WM = NW / WN, FM = BM / (16 * WM), FN = BN / (16 * WN);
-    constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW);
-    extern __shared__ __attribute__((aligned(16))) char smem8_raw[];
-    T* smem = reinterpret_cast<T*>(smem8_raw);
-    const GemmDev p = effective<false>(p_in);
-    const int gx = gridDim.x;
-    const int gy = min((int)gridDim.y, (p.M + BM - 1) / BM);
-    const int orig = blockIdx.y * gx + blockIdx.x;
-    if (orig >= gx * gy) return;
-    const int t = xcd_remap(orig, gx * gy);
-    const int by = t / gx, bx = t - by * gx;
-    const int m0 = by * BM, n0 = bx * BN;
-    const int nkt = p.K / BKE;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wm = wave / WN, wn = wave % WN;
-    const T* A = reinterpret_cast<const T*>(p.A);
-    const T* B = reinterpret_cast<const T*>(p.B);
-    constexpr int STAGE = (BM + BN) * BKE;
-    const int rin = lane >> 3, chs = (lane & 7) ^ rin;
-    const T* srcA[PA];
-    const T* srcB[PB];
-#pragma unroll
-    for (int j = 0; j < PA; ++j) {
-        const int row = min(m0 + (wave * PA + j) * 8 + rin, p.M - 1);
-        srcA[j] = A + (long)row * p.lda + chs * 8;
-    }
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-        const int row = min(n0 + (wave * PB + j) * 8 + rin, p.N - 1);
-        srcB[j] = B + (long)row * p.ldb + chs * 8;
-    }
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nkt > 0) { glds_fill_n<BM, NW>(srcA, smem, wave, 0); glds_fill_n<BN, NW>(srcB, smem + BM * BKE, wave, 0); }
-    for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nkt) {
-            T* nxt = smem + ((kt + 1) & 1) * STAGE;
-            glds_fill_n<BM, NW>(srcA, nxt, wave, (long)(kt + 1) * BKE);
-            glds_fill_n<BN, NW>(srcB, nxt + BM * BKE, wave, (long)(kt + 1) * BKE);
-        }
-        const T* a = smem + (kt & 1) * STAGE;
-        const T* b = a + BM * BKE;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            typename Mma<T>::Frag fa[FM], fb[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) fa[i] = tile_frag<T, BM, false>(a, wm * (BM / WM) + i * 16, kb);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) fb[j] = tile_frag<T, BN, false>(b, wn * (BN / WN) + j * 16, kb);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + 4 * (lane >> 4);
-            epilogue4<T>(p, m, n, acc[i][j]);
-        }
-    }
-}
-
 template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2>
 __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     __shared__ __attribute__((aligned(16))) T sA[TileGeom<T, BM, AK>::ELEMS];
@@ -972,27 +885,11 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
                 return MVLT_OK;
             }
         }
-        // MVLT_GLDS: 0 = never, 1 = every tile, 2 (default) = 64-row tiles only.  Standalone the LDS-DMA loop is 5-12 %
+        // LDS-DMA loop: 64-row tiles only.  Standalone the LDS-DMA loop is 5-12 %
         // faster on 128x128 tiles and 18-24 % on 64x64; inside the training step the 128x128 form (64 KB of LDS, two
         // workgroups per CU) is SLOWER than the register-staged one (three per CU, shares the CU better with the
         // weight-gradient stream): 16.5 vs 16.1 ms per step.
-        static const int big_mode = [] { const char* e = getenv("MVLT_BIG"); return e ? atoi(e) : 0; }();
-        if (big_mode && !ak && !bk && d.split_k <= 1 && p->K % 64 == 0 && p->N % 256 == 0 && d.a_vec && d.b_vec) {
-            const long t256 = (long)ceil_div(p->M, 256) * (p->N / 256);
-            if (t256 >= 64 && (t256 <= 256 || big_mode == 2)) {          // MVLT_BIG=2: any number of macro-tiles (size sweeps)
-                constexpr int sh = 2 * (256 + 256) * 64 * 2;
-                static const bool attr = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds8_kernel<256, 256>),
-                                                                         hipFuncAttributeMaxDynamicSharedMemorySize, sh) == hipSuccess; }();
-                (void)attr;
-                hipLaunchKernelGGL((gemm_glds8_kernel<256, 256>), dim3(p->N / 256, ceil_div(p->M, 256)), dim3(512), sh, s, d);
-                MVLT_LAUNCH_CHECK();
-                if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
-                return MVLT_OK;
-            }
-        }
-        static const int glds_mode = [] { const char* e = getenv("MVLT_GLDS"); return e ? atoi(e) : 2; }();
-        // 3: as 2, plus the 128 x 128 tiles of k-major-B products (wide dgrads)
-        const bool glds_on = glds_mode == 1 || (glds_mode >= 2 && pl.bm == 64) || (glds_mode == 3 && bk);
+        const bool glds_on = pl.bm == 64;          // LDS-DMA loop for the 64-row tiles (comment above)
         const int kspan = d.split_k > 1 ? d.k_per_split : p->K;
         const bool bkm_ok = !bk || ((pl.bn == 64 || pl.bn == 128) && p->N % 8 == 0 && p->N >= 8);
         if (glds_on && !ak && bkm_ok && p->K % 64 == 0 && kspan % 64 == 0 && d.a_vec && d.b_vec) {
@@ -1078,41 +975,34 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
         long t128 = 0;
         for (int i = 0; i < n; ++i) t128 += (long)ceil_div(items[i].M, 128) * ceil_div(items[i].N, 128);
         if (t128 >= 256) bm = 128;
-        if (const char* ov = getenv("MVLT_GROUP_BM")) bm = atoi(ov) == 128 ? 128 : 64;
     }
     long tiles = 0;
     int kmin = items[0].K;
     for (int i = 0; i < n; ++i) { tiles += (long)ceil_div(items[i].M, bm) * ceil_div(items[i].N, bn); kmin = items[i].K < kmin ? items[i].K : kmin; }
     // In-launch split-K: groups with fewer than 200 tiles (Swin stages 0/1: 21 / 72 tiles, 100k / 25k reduction rows) are
-    // cut into k-slices AUTOMATICALLY (MVLT_GROUP_SPLIT=n forces n slices for any group); the slices meet in the zeroed f32
-    // output through atomicAdd.  Groups with >= 200 tiles are never split: measured on the B=32 step it does not shorten
+    // cut into k-slices: on the 8-wave engine below (f32 slabs, deterministic) when it takes the group, otherwise here, where the
+    // slices meet in the zeroed f32 output through atomicAdd.  Groups with >= 200 tiles are never split: measured on the B=32 step it does not shorten
     // the stage-2 groups in situ and the zeroing launch + atomics cost 1 ms per step (17.1 vs 15.9 ms).
     const int bke = 128 / (int)sizeof(T);
     int split = 1;
-    const char* ov_split = getenv("MVLT_GROUP_SPLIT");
     // the k-slices meet through f32 atomicAdd: the order of the 7-24 additions per element is not fixed, so the result is
     // not bit-reproducible run to run.  Never in the exact-f32 mode (the parity path), never under MVLT_DETERMINISTIC=1.
     static const bool deterministic = [] { const char* e = getenv("MVLT_DETERMINISTIC"); return e && e[0] == '1'; }();
-    if ((ov_split || tiles < 200) && sizeof(T) == 2 && !deterministic) {
-        const int v = ov_split ? atoi(ov_split) : 0;
-        if (v >= 1) split = v;
-        else if (tiles < (ov_split ? 384 : 200)) {
-            split = (int)((512 + tiles - 1) / tiles);
-            const int nkt = ceil_div(kmin, bke);
-            if (split > nkt / 8) split = nkt / 8;
-            if (split > 64) split = 64;
-            if (split < 1) split = 1;
-        }
+    if (tiles < 200 && sizeof(T) == 2 && !deterministic) {
+        split = (int)((512 + tiles - 1) / tiles);
+        const int nkt = ceil_div(kmin, bke);
+        if (split > nkt / 8) split = nkt / 8;
+        if (split > 64) split = 64;
+        if (split < 1) split = 1;
     }
     // 8-wave ping-pong engine (gemm8.hip) for the groups this kernel would cut into ATOMIC k-slices (few tiles, tens of
     // thousands of reduction rows: Swin stages 0 / 1): one persistent launch of 128 x 128 tiles, k-slices that meet through
     // f32 slabs (the last arriver of a tile sums them in slice order: deterministic, no float atomics), bias gradients as
     // dY^T . 1 on the matrix pipe -- 100 vs 137 us (stage 0) and 78 vs 91 us (stage 1) per group.  MVLT_G8=1 sends every
-    // group there (experiments: the BertLayer / stage-2 groups tie with this kernel), MVLT_G8_GROUP=0 none.
+    // group there (tests / experiments: the BertLayer / stage-2 groups tie with this kernel), MVLT_G8=0 none.
     if constexpr (sizeof(T) == 2) {
-        static const bool g8_groups = [] { const char* e = getenv("MVLT_G8_GROUP"); return !(e && e[0] == '0'); }();
-        const int g8m = g8_groups ? g8_mode() : 0;
-        if (g8m && (g8m == 1 || split > 1 || (tiles < 200 && !ov_split))) {
+        const int g8m = g8_mode();
+        if (g8m && (g8m == 1 || split > 1 || tiles < 200)) {
             GemmDev tmp[GROUP_MAX];
             float* outs[GROUP_MAX];
             bool ok = true;
@@ -1150,18 +1040,14 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
         if (rc != MVLT_OK) return rc;
     }
     // at most 2 workgroups per CU (of the 3 that fit): the group runs on the side stream beside the dgrad
-    // chain, which should keep a share of every CU (16.8 vs 17.1 ms/step uncapped; MVLT_GROUP_WGS=n overrides, 0 = no cap)
-    int total = g.start[n], per_cu = 2;
-    if (const char* ov = getenv("MVLT_GROUP_WGS")) per_cu = atoi(ov);
-    if (per_cu > 0 && total > per_cu * 256) total = per_cu * 256;
-    static const int deep = [] { const char* e = getenv("MVLT_GROUP_DEEP"); return e ? atoi(e) : 2; }();
+    // chain, which should keep a share of every CU (16.8 vs 17.1 ms/step uncapped; 1 / 3 per CU measured equal or worse)
+    int total = g.start[n];
+    constexpr int per_cu = 2;
+    if (total > per_cu * 256) total = per_cu * 256;
+    // bf16: two LDS stages + two register sets, one barrier per k-tile (the single-stage form measured 1.3 % slower in the step)
 #define GROUP_LAUNCH(BM_, BN_, D_) hipLaunchKernelGGL((gemm_group_kernel<T, BM_, BN_, true, true, D_>), dim3(total), dim3(256), 0, s, g)
     if constexpr (sizeof(T) == 2) {
-        if (deep == 2) {
-            if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 2); else if (bn == 128) GROUP_LAUNCH(64, 128, 2); else GROUP_LAUNCH(64, 96, 2);
-        } else {
-            if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 0); else if (bn == 128) GROUP_LAUNCH(64, 128, 0); else GROUP_LAUNCH(64, 96, 0);
-        }
+        if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 2); else if (bn == 128) GROUP_LAUNCH(64, 128, 2); else GROUP_LAUNCH(64, 96, 2);
     } else {
         if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 0); else if (bn == 128) GROUP_LAUNCH(64, 128, 0); else GROUP_LAUNCH(64, 96, 0);
     }

@@ -24,9 +24,15 @@ struct LnDev {
 };
 MVLT_DEV int ln_rows(const LnDev& p) { return p.rows_dev ? min(p.rows, max(*p.rows_dev, 0)) : p.rows; }
 
+// sum over the LPR consecutive lanes of a row: the steps inside a 16-lane DPP row are DPP adds (no LDS round trip: the
+// reduction sits on every row's critical path), the 16 / 32 steps go through the permute network
 template <int LPR> MVLT_DEV float group_sum(float v) {
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (LPR >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    if (LPR >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    if (LPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    if (LPR >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)); // row_mirror
+    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPR >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
@@ -325,15 +331,25 @@ __global__ __launch_bounds__(256) void ln_acc_fwd_kernel(float* acc, const float
 
 constexpr int LN_BWD_PARTS = 256;
 constexpr int LN_BWD_WAVES = 16;
-static int ln_env(const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; }
 static int ln_bwd_waves(int C) {
-    static int forced = ln_env("MVLT_LN_WAVES", 0);
-    if (forced) return forced;
     int nw = 16;                                   // per-wave partial rows: nw * 2 * C floats of LDS, keep <= 64 KB
     while (nw > 1 && (size_t)nw * 2 * C * sizeof(float) > 64 * 1024) nw >>= 1;
     return nw;
 }
-static int ln_bwd_parts() { static int w = ln_env("MVLT_LN_PARTS", LN_BWD_PARTS); return w < LN_BWD_PARTS ? w : LN_BWD_PARTS; }     // 1024-thread blocks: 16 waves per CU hide the load latency, still 256 partial rows
+static int ln_bwd_parts() { return LN_BWD_PARTS; }     // 1024-thread blocks: 16 waves per CU hide the load latency, still 256 partial rows
+
+// lanes per row of the instantiation dispatch() picks for a width (the ONE place that decides it: the number of partial
+// parameter-gradient rows a backward launch writes follows from it)
+static int ln_lpr(int C) {
+    if (C == 96) return 8;
+    if (C == 192) return 16;
+    if (C == 384) return 32;
+    return C <= 64 ? 16 : (C <= 128 ? 32 : 64);
+}
+static int ln_bwd_blocks(int rows, int C) {
+    const int blocks = ceil_div(rows, ln_bwd_waves(C) * (64 / ln_lpr(C)));
+    return blocks > ln_bwd_parts() ? ln_bwd_parts() : blocks;
+}
 
 template <typename T, int LPR, int NV>
 void launch_fwd(const LnDev& d, bool merge, hipStream_t s) {
@@ -345,9 +361,7 @@ void launch_fwd(const LnDev& d, bool merge, hipStream_t s) {
 template <typename T, int LPR, int NV>
 void launch_bwd(LnDev d, bool merge, hipStream_t s) {
     const int nw = ln_bwd_waves(d.C);
-    const int rpb = nw * (64 / LPR);
-    int blocks = ceil_div(d.rows, rpb);
-    if (blocks > ln_bwd_parts()) blocks = ln_bwd_parts();
+    const int blocks = ln_bwd_blocks(d.rows, d.C);       // (LPR == ln_lpr(C): dispatch() below)
     d.nparts = blocks;
     const size_t sh = 2 * (size_t)nw * d.C * sizeof(float);
     if (merge) hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, true>), dim3(blocks), dim3(64 * nw), sh, s, d);
@@ -358,7 +372,13 @@ template <typename T, bool BWD>
 int dispatch(const LnDev& d, bool merge, hipStream_t s) {
     const int C = d.C;
 #define LN_CASE(LPR, NV) do { if (BWD) launch_bwd<T, LPR, NV>(d, merge, s); else launch_fwd<T, LPR, NV>(d, merge, s); } while (0)
-    if (C <= 64) LN_CASE(16, 1);
+    // widths that are 12 x a power of two (the Swin-S stages) fit three 4-element chunks per lane exactly: more rows per wave
+    // (the per-row reduction chain, not the bytes, is what these kernels wait for) and no idle lanes
+    // (keep in step with ln_lpr above)
+    if (C == 96) LN_CASE(8, 3);
+    else if (C == 192) LN_CASE(16, 3);
+    else if (C == 384) LN_CASE(32, 3);
+    else if (C <= 64) LN_CASE(16, 1);
     else if (C <= 128) LN_CASE(32, 1);
     else if (C <= 256) LN_CASE(64, 1);
     else if (C <= 512) LN_CASE(64, 2);
@@ -427,9 +447,7 @@ extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
     else return MVLT_ERR_UNSUPPORTED;
     if (rc != MVLT_OK) return rc;
     // the number of partial rows written == number of blocks launched above
-    int lpr = p->C <= 64 ? 16 : (p->C <= 128 ? 32 : 64);
-    int blocks = ceil_div(p->rows, ln_bwd_waves(p->C) * (64 / lpr));
-    if (blocks > ln_bwd_parts()) blocks = ln_bwd_parts();
+    const int blocks = ln_bwd_blocks(p->rows, p->C);
     if (p->defer_param_reduce) return MVLT_OK;       // caller batches it with mvlt_layernorm_param_reduce_batch
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(p->C, 64)), dim3(1024), 0, s, d.part_g, d.part_b,
                        blocks, p->C, p->dgamma, p->dbeta, p->accumulate);
@@ -438,9 +456,7 @@ extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
 }
 
 extern "C" int mvlt_layernorm_bwd_nparts(int rows, int C) {
-    int lpr = C <= 64 ? 16 : (C <= 128 ? 32 : 64);
-    int blocks = ceil_div(rows, ln_bwd_waves(C) * (64 / lpr));
-    return blocks > ln_bwd_parts() ? ln_bwd_parts() : blocks;
+    return ln_bwd_blocks(rows, C);
 }
 
 extern "C" int mvlt_layernorm_param_reduce_batch(const MvltLnReduceItem* items, int n, void* stream) {

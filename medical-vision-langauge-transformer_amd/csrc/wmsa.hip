@@ -746,8 +746,7 @@ int launch_bwd(const WmsaBwdDev& d, hipStream_t s) {
     static const hipError_t attr = sh > 64 * 1024
         ? hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) : hipSuccess;
     (void)attr;
-    static const int cap = [] { const char* e = getenv("MVLT_WMSA_BWD_GRID"); return e ? atoi(e) : 512; }();
-    const int grid = d.nwin < cap ? d.nwin : cap;
+    const int grid = d.nwin < 512 ? d.nwin : 512;          // persistent workgroups (512 / 1024 / 2048 measured the same or worse)
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), sh, s, d);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
@@ -767,30 +766,12 @@ int launch_fwd(const WmsaDev& d, hipStream_t s) {
     return MVLT_OK;
 }
 
-// experiments: MVLT_WMSA_CFG=<G><NW> (e.g. "24" = heads in pairs, 4 waves) picks another instantiation where one exists
-int cfg_override() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MVLT_WMSA_CFG"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 int dispatch_fwd_bf16(const WmsaDev& d, int C, hipStream_t s) {
     using T = bf16_t;
-    const int o = cfg_override();
-    switch (C) {
-        case 96:                                                      // 3 heads
-            if (o == 14) return launch_fwd<T, 96, 1, 4>(d, s);
-            return launch_fwd<T, 96, 3, 4>(d, s);
-        case 192:                                                     // 6 heads
-            if (o == 24) return launch_fwd<T, 192, 2, 4>(d, s);
-            if (o == 34) return launch_fwd<T, 192, 3, 4>(d, s);
-            if (o == 28) return launch_fwd<T, 192, 2, 8>(d, s);
-            return launch_fwd<T, 192, 6, 8>(d, s);
-        case 384:                                                     // 12 heads
-            if (o == 24) return launch_fwd<T, 384, 2, 4>(d, s);
-            if (o == 44) return launch_fwd<T, 384, 4, 4>(d, s);
-            if (o == 28) return launch_fwd<T, 384, 2, 8>(d, s);
-            return launch_fwd<T, 384, 4, 8>(d, s);
+    switch (C) {                                                      // <C, heads per group, waves>: the fastest of the round-2 sweep
+        case 96:  return launch_fwd<T, 96, 3, 4>(d, s);               // 3 heads
+        case 192: return launch_fwd<T, 192, 6, 8>(d, s);              // 6 heads
+        case 384: return launch_fwd<T, 384, 4, 8>(d, s);              // 12 heads
         case 128: return launch_fwd<T, 128, 2, 4>(d, s);              // Swin-B
         case 256: return launch_fwd<T, 256, 2, 4>(d, s);
         case 512: return launch_fwd<T, 512, 4, 8>(d, s);

@@ -28,8 +28,8 @@ from .runtime import compute_dtype_of
 
 # the split reductions meet in an f32 accumulator through atomicAdd (order not fixed: bf16 greedy decoding can flip a
 # near-tie between two runs); MVLT_DECODE_SPLITK=0 or MVLT_DETERMINISTIC=1 keep every reduction in one workgroup
-_SKINNY_SPLIT = os.environ.get("MVLT_DECODE_SPLITK", "1") != "0" and os.environ.get("MVLT_DETERMINISTIC", "0") != "1"
-_SPLITS = tuple(int(v) for v in os.environ.get("MVLT_DECODE_SPLITS", "2,4").split(","))      # (attention output, FFN-out)
+_SKINNY_SPLIT = os.environ.get("MVLT_DETERMINISTIC", "0") != "1"
+_SPLITS = (2, 4)      # reduction splits of (attention output, FFN-out) projections: the fastest of the round-2 sweep
 
 
 def _layers_cached(mv, ar, x, kc, vc, past, n_new):

@@ -430,7 +430,6 @@ class MVLBertPretrainedModel(nn.Module):
 _AUTO_PACK = os.environ.get("MVLT_AUTO_PACK", "1") != "0"
 
 
-_PLAN_SIDE = os.environ.get("MVLT_PLAN_SIDE", "1") != "0"
 
 
 class MVLBertForPretraining(MVLBertPretrainedModel):
@@ -457,7 +456,7 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
         # the packing / label plans depend on the ids and labels only: MVLBert.forward_autopack runs their two
         # single-workgroup kernels on the side stream behind this point, i.e. beside the image tower instead of after it
         entry = None
-        if _PLAN_SIDE and caption_masked.is_cuda:
+        if caption_masked.is_cuda:
             entry = torch.cuda.Event()
             entry.record()
         image_feature = self.conv(image)

@@ -35,36 +35,20 @@ class PretrainStep:
     """loss = model(batch); loss.backward(); optimizer.step()  -- one call per step.
     ``reducer`` (mvlt_amd.ddp.GradReducer) makes it data parallel."""
 
-    def __init__(self, model, lr=None, reducer=None, world_size=1, overlap_optimizer=None):
-        import os
+    def __init__(self, model, lr=None, reducer=None, world_size=1, overlap_optimizer=False):
         self.model = model
         # the reducer hands out rank-averaged gradients by default (like torch DDP); a SUM reducer is rescaled here
         gs = 1.0 if (reducer is None or getattr(reducer, "average", False)) else 1.0 / world_size
         self.opt = FusedAdamW(model, lr=lr if lr is not None else model.config.lr, betas=(0.9, 0.999), eps=1e-6,
                               weight_decay=1e-4, grad_scale=gs)
         self.reducer = reducer
-        if overlap_optimizer is None:
-            overlap_optimizer = os.environ.get("MVLT_OPT_OVERLAP", "0") == "1"
         if overlap_optimizer:
             # opt-in: AdamW of finished arena slices is queued beside the rest of the backward pass.  On one
             # GPU the step is throughput-bound and this measured neutral (18.8 vs 19.0 ms); it exists for DDP,
             # where it takes all but the last bucket's update off the serial tail behind the all-reduce.
             self.opt.overlap_with_backward(reducer)
-        self.hp_stream = torch.cuda.Stream(priority=-1) if os.environ.get("MVLT_HP_STREAM", "0") == "1" else None
 
     def __call__(self, batch):
-        if self.hp_stream is None:
-            return self._step(batch)
-        # critical path (forward, dgrad chain, optimizer) on a high-priority HIP stream; the weight
-        # gradients run on the default-priority side stream and fill the gaps
-        cur = torch.cuda.current_stream()
-        self.hp_stream.wait_stream(cur)
-        with torch.cuda.stream(self.hp_stream):
-            loss = self._step(batch)
-        cur.wait_stream(self.hp_stream)
-        return loss
-
-    def _step(self, batch):
         # batch = (image, caption_masked, caption_label, image_text_label[, text_lengths (host ints)])
         loss = self.model(*batch[:4], text_lengths=batch[4]) if len(batch) > 4 else self.model(*batch)
         loss.backward()
