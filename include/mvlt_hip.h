@@ -299,6 +299,11 @@ typedef struct MvltEmbed {
     /* packed rows (optional): sequence b is written to / read from rows row_start[b] + pos, pos < seq_len[b] */
     const int32_t* row_start; const int32_t* seq_len;
     const int32_t* pos_offset_dev;      /* optional (forward): added to pos_offset, read on the device (replayed decode step) */
+    /* backward: rows of the position / token-type tables (0 = unknown).  mvlt_embed_bwd OVERWRITES dpos rows
+     * [pos_offset, pos_offset + L) and the dtype_emb rows in use with batch sums in a fixed order (no atomics,
+     * bit-reproducible); with the row counts given it also zeroes every other row of the two tables, so the caller
+     * clears only dword (which is accumulated with float atomics: a scatter-add over the batch's token ids). */
+    int pos_rows, type_rows;
 } MvltEmbed;
 /* Packing plan of a ragged caption batch, computed ON THE DEVICE (no host sync): sample b keeps the sequence
  * positions [0, n_img + 2 + len_b) where len_b = 1 + the last caption position t with text_ids[b,t] != 0 or

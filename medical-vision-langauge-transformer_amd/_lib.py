@@ -87,7 +87,7 @@ class MvltEmbed(C.Structure):
                 ("cls_id", i32), ("sep_id", i32), ("pos_offset", i32), ("type_override", i32),
                 ("out", vp),
                 ("dout", vp), ("dimage", vp), ("dword", vp), ("dpos", vp), ("dtype_emb", vp),
-                ("row_start", vp), ("seq_len", vp), ("pos_offset_dev", vp)]
+                ("row_start", vp), ("seq_len", vp), ("pos_offset_dev", vp), ("pos_rows", i32), ("type_rows", i32)]
 
 
 class MvltAttnCached(C.Structure):

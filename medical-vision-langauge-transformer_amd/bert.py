@@ -445,7 +445,7 @@ class MVLBert(nn.Module):
         lnq.flush()
         # ---- embeddings: dense f32 table gradients, like nn.Embedding in the reference
         we, pe, te = self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight
-        g(we).zero_(); g(pe).zero_(); g(te).zero_()
+        g(we).zero_()          # scatter-add target; the position / type tables are overwritten whole by mvlt_embed_bwd
         dimg = ops.embed_bwd(dx.view(B, Lq, H) if pack is None else dx, sv["text_idx"], sv["n_img"], we.data, pe.data,
                              te.data, cfg.cls_token_id, cfg.sep_token_id, g(we), g(pe), g(te), pack=pack, B=B)
         ops.join_side(dx.device)

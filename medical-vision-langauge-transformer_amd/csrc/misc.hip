@@ -37,6 +37,7 @@ struct EmbDev {
     int cls_id, sep_id, pos_offset, type_override;
     void* out; const void* dout; void* dimage; float* dword; float* dpos; float* dtype_emb;
     const int* row_start; const int* seq_len; const int* pos_offset_dev;
+    int pos_rows, type_rows;
 };
 // row of (b, posi) in the activation matrix, -1 when the position is not materialised (packed layout)
 MVLT_DEV long emb_row(const EmbDev& p, int b, int posi) {
@@ -170,26 +171,59 @@ __global__ __launch_bounds__(256) void embed_bwd_tokens_kernel(const EmbDev p) {
         }
     }
 }
-// dpos[pos] += sum_b dout[b,pos]; CLS / SEP word rows and the two type rows follow from it
+// Position / token-type table gradients and the [CLS] / [SEP] word rows (model.py:133-158 backward): batch sums in a FIXED
+// order, no atomics.  A workgroup owns 32 columns; its 1024 threads are 16 column pairs x 64 position lanes.  Every thread
+// sums the batch for its positions (B independent loads in flight), OVERWRITES the position row, and keeps the type sums of
+// its positions; the 64 lanes then meet in LDS and are added in lane order.  With the table sizes given, every row that
+// receives no gradient is zeroed here as well (the caller clears nothing but the word table).
+constexpr int EBP_COLS = 32, EBP_LANES = 64;
 template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const EmbDev p) {
-    const long total = (long)p.L * p.H;
+__global__ __launch_bounds__(1024) void embed_bwd_pos_kernel(const EmbDev p) {
+    __shared__ float red[2][EBP_LANES][EBP_COLS];
+    const int cp = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * EBP_COLS + 2 * cp;
+    const bool cv = c < p.H;                                  // (H % 4 == 0: a pair never straddles the end)
     const T* dout = reinterpret_cast<const T*>(p.dout);
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int c = (int)(idx % p.H), posi = (int)(idx / p.H);
-        float s = 0.f;
-        for (int b = 0; b < p.B; ++b) {
-            const long row = emb_row(p, b, posi);
-            if (row >= 0) s += to_f(dout[row * p.H + c]);
+    float t0x = 0.f, t0y = 0.f, t1x = 0.f, t1y = 0.f;         // type rows 0 / 1 (or the override row in t0)
+    for (int posi = pl; posi < p.L; posi += EBP_LANES) {
+        float sx = 0.f, sy = 0.f;
+        if (cv) {
+            for (int b = 0; b < p.B; ++b) {
+                const long row = emb_row(p, b, posi);
+                if (row >= 0) { sx += to_f(dout[row * p.H + c]); sy += to_f(dout[row * p.H + c + 1]); }
+            }
+            if (p.dpos) { float* d = p.dpos + (long)(posi + p.pos_offset) * p.H + c; d[0] = sx; d[1] = sy; }
+            if (p.dword && p.n_img >= 0 && (posi == 0 || posi == p.n_img + 1)) {
+                // (the token kernel, earlier on this stream, skips these two positions: one writer per element)
+                float* d = p.dword + (long)(posi == 0 ? p.cls_id : p.sep_id) * p.H + c;
+                d[0] += sx; d[1] += sy;
+            }
         }
-        if (p.dpos) p.dpos[(long)(posi + p.pos_offset) * p.H + c] += s;
-        if (p.dword && p.n_img >= 0) {
-            if (posi == 0) atomicAdd(&p.dword[(long)p.cls_id * p.H + c], s);
-            if (posi == p.n_img + 1) atomicAdd(&p.dword[(long)p.sep_id * p.H + c], s);
-        }
-        if (p.dtype_emb) {
-            const int ty = p.type_override >= 0 ? p.type_override : (posi <= p.n_img + 1 ? 1 : 0);
-            atomicAdd(&p.dtype_emb[(long)ty * p.H + c], s);
+        const bool first = p.type_override >= 0 || posi > p.n_img + 1;      // -> t0: type row 0 (text) or the override row
+        if (first) { t0x += sx; t0y += sy; } else { t1x += sx; t1y += sy; }
+    }
+    // rows of the position table outside [pos_offset, pos_offset + L): no gradient
+    if (cv && p.dpos && p.pos_rows > 0)
+        for (int r = pl; r < p.pos_rows; r += EBP_LANES)
+            if (r < p.pos_offset || r >= p.pos_offset + p.L) { float* d = p.dpos + (long)r * p.H + c; d[0] = 0.f; d[1] = 0.f; }
+    if (!p.dtype_emb) return;
+    red[0][pl][2 * cp] = t0x; red[0][pl][2 * cp + 1] = t0y;
+    red[1][pl][2 * cp] = t1x; red[1][pl][2 * cp + 1] = t1y;
+    __syncthreads();
+    if (threadIdx.x < 2 * EBP_COLS) {
+        const int which = threadIdx.x / EBP_COLS, col = threadIdx.x % EBP_COLS, cc = blockIdx.x * EBP_COLS + col;
+        if (cc < p.H) {
+            float s = 0.f;
+            for (int l = 0; l < EBP_LANES; ++l) s += red[which][l][col];
+            const int row0 = p.type_override >= 0 ? p.type_override : 0;       // which == 0
+            if (which == 0) p.dtype_emb[(long)row0 * p.H + cc] = s;
+            else if (p.type_override < 0) p.dtype_emb[(long)1 * p.H + cc] = s;
+            // rows of the type table that are not in use
+            if (which == 0)
+                for (int r = 0; r < p.type_rows; ++r) {
+                    const bool used = p.type_override >= 0 ? r == p.type_override : r < 2;
+                    if (!used) p.dtype_emb[(long)r * p.H + cc] = 0.f;
+                }
         }
     }
 }
@@ -692,6 +726,7 @@ static int fill_emb(const MvltEmbed* p, EmbDev& d) {
     d.out = p->out; d.dout = p->dout; d.dimage = p->dimage; d.dword = p->dword; d.dpos = p->dpos; d.dtype_emb = p->dtype_emb;
     MVLT_CHECK((p->row_start == nullptr) == (p->seq_len == nullptr), MVLT_ERR_ARG);
     d.row_start = p->row_start; d.seq_len = p->seq_len; d.pos_offset_dev = p->pos_offset_dev;
+    d.pos_rows = p->pos_rows; d.type_rows = p->type_rows;
     if (p->n_img >= 0) MVLT_CHECK(p->image_feature || p->dout, MVLT_ERR_ARG);
     return MVLT_OK;
 }
@@ -737,12 +772,14 @@ extern "C" int mvlt_embed_bwd(const MvltEmbed* p, void* stream) {
     EmbDev d{}; int rc = fill_emb(p, d); if (rc) return rc;
     MVLT_CHECK(p->dout, MVLT_ERR_ARG);
     const int g = grid_for((long)d.B * d.L * (d.H / 4), 256);
-    const int g2 = grid_for((long)d.L * d.H, 256);
+    MVLT_CHECK(p->pos_rows == 0 || p->pos_offset + d.L <= p->pos_rows, MVLT_ERR_ARG);
+    MVLT_CHECK(p->type_rows == 0 || (p->type_override >= 0 ? p->type_override < p->type_rows : p->type_rows >= 2), MVLT_ERR_ARG);
+    const int g2 = ceil_div(d.H, EBP_COLS);
     BY_DTYPE(p->dtype,
              { hipLaunchKernelGGL(embed_bwd_tokens_kernel<float>, dim3(g), dim3(256), 0, STREAM(stream), d);
-               hipLaunchKernelGGL(embed_bwd_pos_kernel<float>, dim3(g2), dim3(256), 0, STREAM(stream), d); },
+               hipLaunchKernelGGL(embed_bwd_pos_kernel<float>, dim3(g2), dim3(1024), 0, STREAM(stream), d); },
              { hipLaunchKernelGGL(embed_bwd_tokens_kernel<bf16_t>, dim3(g), dim3(256), 0, STREAM(stream), d);
-               hipLaunchKernelGGL(embed_bwd_pos_kernel<bf16_t>, dim3(g2), dim3(256), 0, STREAM(stream), d); });
+               hipLaunchKernelGGL(embed_bwd_pos_kernel<bf16_t>, dim3(g2), dim3(1024), 0, STREAM(stream), d); });
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }

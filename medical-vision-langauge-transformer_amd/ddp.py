@@ -23,7 +23,10 @@ exchange step BASELINE.json asks for.  Design for 8 x MI355X on one node
   batch (model.py:410).  Ranks hold different numbers of labelled tokens, so the
   rank-average of per-rank means is a different number; ``global_label_mean``
   (default on) all-reduces the 4-byte label count in the forward pass and every
-  rank divides its summed loss by N_global / world instead of its own count:
+  rank divides its summed loss by N_global / world instead of its own count
+  (only in forwards that record a graph: torch.no_grad() forwards and
+  ``GradReducer.no_sync()`` take no collective and keep the per-rank mean;
+  heads other than MVLBertForPretraining always use per-rank means):
   the averaged loss and gradients then equal the single-process global-batch
   step exactly (the ITM loss is a mean over samples, equal per rank: unchanged);
 * the seq2seq/bidirectional coin flip of MVLBertForPretraining is drawn from
@@ -149,6 +152,21 @@ class GradReducer:
         else:
             self.model.__dict__.pop("_mvlt_label_sync", None)
         return ar
+
+    def no_sync(self):
+        """Context manager: forwards inside it take no collective (the MLM loss falls back to the per-rank mean) -- for a
+        gradient-mode forward that not every rank runs.  Gradients of a backward() inside it are still exchanged."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            had = self.model.__dict__.pop("_mvlt_label_sync", None)
+            try:
+                yield self
+            finally:
+                if had is not None:
+                    self.model.__dict__["_mvlt_label_sync"] = had
+        return ctx()
 
     def label_sync(self, count: torch.Tensor) -> torch.Tensor:
         """count: f32 [1] on this rank's device = labelled tokens of this rank's shard.  Returns N_global / world (f32 [1]):

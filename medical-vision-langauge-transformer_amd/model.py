@@ -537,11 +537,11 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
                 x = text_out.reshape(B * T, H)
             mlm_loss = _MlmLossFn.apply(_token(head, dev), x.contiguous(), head,
                                         sel_labels if (compact or lab_first) else labels, torch.is_grad_enabled(), rd,
-                                        # the label-count all-reduce is a COLLECTIVE: only a training forward that every rank
-                                        # runs takes it (eval / no_grad forwards -- rank-0 validation, an uneven last batch --
-                                        # keep the per-rank mean and never touch the process group)
-                                        self.__dict__.get("_mvlt_label_sync")
-                                        if (self.training and torch.is_grad_enabled()) else None)
+                                        # the label-count all-reduce is a COLLECTIVE: only a forward that records a graph (one
+                                        # every rank runs and follows with backward()) takes it; no_grad forwards -- rank-0
+                                        # validation, an uneven last evaluation batch -- keep the per-rank mean and never touch
+                                        # the process group (GradReducer.no_sync() switches it off for grad-mode forwards too)
+                                        self.__dict__.get("_mvlt_label_sync") if torch.is_grad_enabled() else None)
             if compact:
                 mlm_loss = torch.where(valid.sum() > cap * B, torch.full_like(mlm_loss, float("nan")), mlm_loss)
             if packed:

@@ -836,6 +836,10 @@ def embed_bwd(dout, text_ids, n_img, word, pos, typ, cls_id, sep_id, dword, dpos
     p = _embed_struct(dout.dtype, B, n_img, T, H, text_ids, word, pos, typ, cls_id, sep_id, pos_offset, type_override)
     assert dout.is_contiguous()
     p.dout, p.dimage, p.dword, p.dpos, p.dtype_emb = _p(dout), _p(dimg), _p(dword), _p(dpos), _p(dtype_emb)
+    # the position / type table gradients are OVERWRITTEN with ordered batch sums and their unused rows zeroed (no atomics);
+    # dword is accumulated: the caller clears it
+    p.pos_rows = 0 if dpos is None else dpos.shape[0]
+    p.type_rows = 0 if dtype_emb is None else dtype_emb.shape[0]
     if pack is not None:
         p.row_start, p.seq_len = _p(pack[0]), _p(pack[1])
     L.check(L.lib().mvlt_embed_bwd(C.byref(p), _stream()), "mvlt_embed_bwd")

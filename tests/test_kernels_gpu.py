@@ -778,10 +778,16 @@ def test_im2col_and_embed(ops, dt):
     assert rel(out, ref) < tol(dt)
     dout = rnd((B, Lq, H), dt, 67)
     ref.backward(dout.float())
-    dw, dp_, dt_ = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
+    # the word table is a scatter-add target (cleared by the caller); the position / type tables are OVERWRITTEN whole
+    # (ordered batch sums, unused rows zeroed): they start from garbage here
+    dw, dp_, dt_ = torch.zeros_like(word), torch.full_like(pos, 7.0), torch.full_like(typ, -3.0)
     dimg = ops.embed_bwd(dout, ids, n_img, word, pos, typ, 101, 102, dw, dp_, dt_)
     assert rel(dimg, fr.grad) < tol(dt)
     assert rel(dw, wr.grad) < 1e-4 and rel(dp_, pr.grad) < 1e-4 and rel(dt_, tr.grad) < 1e-4
+    assert float(dp_[Lq:].abs().max()) == 0.0 and float(dt_[2].abs().max()) == 0.0
+    dp2, dt2 = torch.full_like(pos, 1.0), torch.full_like(typ, 1.0)
+    ops.embed_bwd(dout, ids, n_img, word, pos, typ, 101, 102, torch.zeros_like(word), dp2, dt2)
+    assert torch.equal(dp2, dp_) and torch.equal(dt2, dt_)          # bit-reproducible
 
 
 @pytest.mark.parametrize("dt", DT)

@@ -28,6 +28,11 @@ GRAD = {F32: 5e-3, BF16: 0.15}
 HASH_LOSS = {F32: 1e-4, BF16: 1e-3}
 HASH_ACT = {F32: 2e-4, BF16: 2e-2}
 HASH_GRAD = {F32: 5e-3, BF16: 8e-2}
+# bf16, first 256 elements of a gradient tensor: a 256-element slice of a 590k-element gradient moves between 0.03 and 0.10
+# with any change of a summation order upstream (measured across kernel variants of rounds 3-4: LayerNorm reduction order,
+# fused / unfused W-MSA) while the whole-tensor norm stays within 2e-3 -- the slice bound says "the right values", the
+# norm bound (HASH_GRAD, unchanged) says how exactly
+HASH_GRAD_SLICE = {F32: 5e-3, BF16: 0.12}
 
 
 def load_formula(model, spec):
@@ -302,7 +307,7 @@ def test_full_pretrain_vs_reference_on_well_conditioned_weights(M, golden, specs
             gr = params[pn].grad
             e_norm = abs(gr.double().norm().item() - g[k].item()) / g[k].item()
             e_head = rel_err(gr.reshape(-1)[:256].cpu(), g[f"grad_{name}_{pn}"])
-            if e_norm > HASH_GRAD[cd] or e_head > HASH_GRAD[cd]:
+            if e_norm > HASH_GRAD[cd] or e_head > HASH_GRAD_SLICE[cd]:
                 bad.append((pn, e_norm, e_head))
             if os.environ.get("MVLT_TEST_VERBOSE"):
                 print(f"{name} {pn}: norm err {e_norm:.2e}, first-256 err {e_head:.2e}")
@@ -808,7 +813,7 @@ def test_config2_step_is_bit_reproducible_except_the_atomic_accumulations(M, mon
     """the B=32 bf16 training step (train mode: dropout + DropPath, same seeds) run twice from the same
     parameters gives bit-identical gradients everywhere EXCEPT the tensors that are accumulated with float atomics:
     the 24 relative-position-bias-table gradients (every attention-backward workgroup adds its LDS table) and the
-    embedding-table gradients (mvlt_embed_bwd scatter-adds token rows); those agree to 1e-6 of their norm.  The Swin
+    word-embedding gradient (mvlt_embed_bwd scatter-adds token rows); those agree to 1e-6 of their norm.  The Swin
     stage-0/1 weight gradients, k-sliced through atomicAdd in round 2, now meet through f32 slabs summed in slice order by
     the last arriver (csrc/gemm8.hip) and are bit-reproducible too."""
     from mvlt_amd.train import synthetic_batch
@@ -834,8 +839,11 @@ def test_config2_step_is_bit_reproducible_except_the_atomic_accumulations(M, mon
     # row): last-bit differences; no gradient depends on it (dlogits = (softmax - onehot) / count)
     assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
     differ = [k for k in g0 if not torch.equal(g0[k], g1[k])]
-    emb = ("MVLBert.word_embeddings.weight", "MVLBert.token_type_embeddings.weight", "MVLBert.position_embeddings.weight")
+    # (round 4: the position / token-type table gradients are ordered batch sums -- they left this list)
+    emb = ("MVLBert.word_embeddings.weight",)
     atomic = lambda k: k in emb or k.endswith(".attn.relative_position_bias_table")
+    assert torch.equal(g0["MVLBert.position_embeddings.weight"], g1["MVLBert.position_embeddings.weight"])
+    assert torch.equal(g0["MVLBert.token_type_embeddings.weight"], g1["MVLBert.token_type_embeddings.weight"])
     assert all(atomic(k) for k in differ), [k for k in differ if not atomic(k)][:10]
     for k in differ:
         e = float((g1[k].double() - g0[k].double()).norm() / (g0[k].double().norm() + 1e-30))
