@@ -55,7 +55,12 @@ template <int C, int W, int G, int GS> struct W2Geom {
     static constexpr int QR = (49 * (W - 1) + 64 + 3) / 4 * 4;            // rows of one (part, head) tile
     static constexpr int OC = G * 32;                                      // columns of the attention-output tile
     static constexpr int XB = MR * C * 2;
-    static constexpr int QB = 3 * GS * QR * 64;
+    // q/k/v tiles; for widths whose weights stream through LDS (C % 64 == 0) the same region first holds the two stages of the
+    // weight ring ([96 GS rows][64 k] each) and, after the attention phase, the output-projection weights
+    static constexpr int WROWS = 96 * GS, WSTAGE = WROWS * 64, WNBUF = 4;          // stage = one k-step (32 k = 64 bytes per row)
+    static constexpr bool WLDS = C % 64 == 0 && NSUB == 1;          // (two sub-groups, C = 192: the LDS budget has no room for the ring)
+    static constexpr int QB0 = 3 * GS * QR * 64;
+    static constexpr int QB = (WLDS && WNBUF * WSTAGE > QB0) ? WNBUF * WSTAGE : QB0;
     static constexpr int TB = G * 176 * 4;
     static constexpr bool ALIAS_O = NSUB == 1 && NHG > 1 && (XB + QB + MR * OC * 2 + TB > 160 * 1024);
     static constexpr int OB = ALIAS_O ? 0 : MR * OC * 2;
@@ -75,6 +80,14 @@ template <int CC> MVLT_DEV int xoff(int row, int chunk) {
 MVLT_DEV int hoff(int row, int chunk) { return row * 64 + (((chunk + 2 * (row >> 2)) & 3) << 4); }
 
 MVLT_DEV void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// LDS-DMA, 16 bytes per lane to wave-uniform lds_dst + 16 lane (inline asm: M0 saved and restored inside the statement; hipcc
+// does not see the request, the callers wait for it with vm_drain before the barrier that publishes the bytes)
+MVLT_DEV void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 
 // -DW2_TRACE (diagnostic build only): thread 0 of every workgroup stamps the 100 MHz real-time counter at the phase
 // boundaries of its FIRST unit into a buffer set by mvlt_swin_wmsa2_trace_buffer (scripts/wmsa2_trace.py reads it)
@@ -185,6 +198,37 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
         };
         Frag fb[PD][NTQW];
         uint32_t ridx[4], rowbits = 0, colbits = 0;
+        // weight ring (WLDS): buffer kk % WNBUF <- k-step kk (columns 32 kk .. +32) of the qkv weight rows of sub-group hs.  A 1-KB
+        // piece is 16 rows x 64 bytes (lane = (row, position); position pos of row r holds chunk (pos + 2 (r >> 2)) & 3, the
+        // hoff placement); wave w issues pieces w, w + NWV, ... -- WPPW of them (the last ones may be missing: see WPC)
+        constexpr int WNPC = GM::WROWS / 16, WPPW = (WNPC + NWV - 1) / NWV;
+        const int wpc = (WNPC - wave + NWV - 1) / NWV;                           // pieces THIS wave issues per k-step
+        auto wring_fill = [&](int hs, int kk) {
+            if constexpr (GM::WLDS) {
+                const uint32_t dst0 = lds_addr(qkvt) + (kk % GM::WNBUF) * GM::WSTAGE;
+#pragma unroll
+                for (int j = 0; j < WPPW; ++j) {
+                    const int pc = wave + NWV * j;
+                    if (pc < WNPC) {
+                        const int r = 16 * pc + (lane >> 2), part = r / (32 * GS), rr = r - part * 32 * GS;
+                        const int ch = ((lane & 3) + 2 * (r >> 2)) & 3;
+                        glds16(p.wqkv + (long)(part * C + (head0 + hs * GS) * 32 + rr) * C + kk * 32 + ch * 8, dst0 + pc * 1024);
+                    }
+                }
+            }
+        };
+        // wait until this wave's pieces of k-step kk have landed while `later` younger k-steps stay in flight
+        auto wring_wait = [&](int later) {
+            if (wpc == WPPW) {
+                if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * WPPW) : "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WPPW) : "memory");
+                else vm_drain();
+            } else {
+                if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (WPPW - 1)) : "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WPPW - 1) : "memory");
+                else vm_drain();
+            }
+        };
         // ---- gather the rows (token order -> window order), LayerNorm, normalised tile -> LDS
         {
             constexpr int CPR = C / 8;                                       // 16-byte chunks per row
@@ -225,11 +269,13 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
             // ---- behind the first rows' statistics: the first weight fragments, the pair facts and the tables.  Requested any
                     // earlier they queue IN FRONT of nothing but share the start-up burst (every CU fetching ~75 KB of rows at once runs at
                     // ~11 B/cycle/CU) and the rows, which everything waits for, arrive later
+                    if constexpr (!GM::WLDS) {
 #pragma unroll
-                    for (int jj = 0; jj < NTQW; ++jj) {
-                        const T* w = wq_ptr(0, wave + NWV * jj);
+                        for (int jj = 0; jj < NTQW; ++jj) {
+                            const T* w = wq_ptr(0, wave + NWV * jj);
 #pragma unroll
-                        for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
+                            for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
+                        }
                     }
                     // packed pair facts of this wave's query tile (relative-position indices, border bits): 5 registers carried to the
                     // attention phase, expanded there
@@ -261,10 +307,12 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                         const int h = i / 176, e = i - h * 176;
                         tbl[i] = e < 169 ? p.bias_table[e * p.nH + head0 + h] * inv_scale : NEG_BIG;
                     }
-                    // rows of the q/k/v tiles beyond the projected rows (read as padded keys of the last window): finite
-                    for (int i = tid; i < 3 * GS * (QR - MR) * 4; i += NT) {
-                        const int ch = i & 3, r = (i >> 2) % (QR - MR), tl = (i >> 2) / (QR - MR);
-                        *reinterpret_cast<bf16x8*>(qkvt + tl * TILE + hoff(MR + r, ch)) = zero_vec<T>();
+                    // the ring's first requests go out LAST: hipcc does not see them, so its wait for any load it issued earlier
+                    // (the table values above are consumed at once) would otherwise wait for the ring too
+                    asm volatile("" ::: "memory");
+                    if constexpr (GM::WLDS) {
+#pragma unroll
+                        for (int kk = 0; kk < GM::WNBUF && kk < KSTEPS; ++kk) wring_fill(0, kk);      // the whole ring fills under the LayerNorm
                     }
                     asm volatile("" ::: "memory");
                 }
@@ -311,6 +359,96 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
 #pragma unroll
         for (int hs = 0; hs < NSUB; ++hs) {
             // ================= qkv projection of head sub-group hs: [MR, C] x [C, 96 GS]
+            if constexpr (GM::WLDS) {
+                // Weights through the LDS ring.  Tile assignment WITHOUT wave-dependent branches (a branch per tile keeps hipcc from
+                // overlapping a k-step's fragment reads with the previous k-step's MFMAs): every wave owns FULL whole column tiles
+                // (all MT row tiles each); the REM left-over column tiles are dealt out as single (row tile, column tile) pairs,
+                // LPW per wave (a wave without a last pair repeats pair LQ - 1 into an accumulator nobody stores).
+                constexpr int FULL = NTQ / NWV, REM = NTQ % NWV, LQ = REM * MT, LPW = (LQ + NWV - 1) / NWV;
+                f32x4 acc[MT][FULL > 0 ? FULL : 1], lacc[LPW > 0 ? LPW : 1];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < FULL; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                int lm[LPW > 0 ? LPW : 1], ln[LPW > 0 ? LPW : 1];
+#pragma unroll
+                for (int e = 0; e < LPW; ++e) {
+                    const int q = min(wave + NWV * e, LQ - 1);
+                    ln[e] = FULL * NWV + q / MT; lm[e] = q % MT;
+                    lacc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const uint32_t xa = lds_addr(xln), wa = lds_addr(qkvt);
+                // (k-slots in plain order here: a stage row is the 64 contiguous bytes of one k-step.)  The loop is software-
+                // pipelined ACROSS its barrier: the barrier in front of k-step kk's MFMAs certifies k-step kk + 1 (landed for every
+                // wave; every wave has its k-step-kk fragments in registers), the fragments of kk + 1 are requested, and only then
+                // are the MFMAs of kk issued -- the LDS latency and the LDS-DMA issue hide behind the matrix pipe
+                auto frags = [&](int kk, Frag (&fa)[MT], Frag (&la)[LPW > 0 ? LPW : 1], Frag (&fw)[FULL > 0 ? FULL : 1], Frag (&lw)[LPW > 0 ? LPW : 1]) {
+                    const uint32_t wst = wa + (kk % GM::WNBUF) * GM::WSTAGE;
+#pragma unroll
+                    for (int jj = 0; jj < FULL; ++jj) fw[jj] = lds_frag(wst + hoff(16 * (wave + NWV * jj) + c15, g));
+#pragma unroll
+                    for (int e = 0; e < LPW; ++e) lw[e] = lds_frag(wst + hoff(16 * ln[e] + c15, g));
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) fa[i] = lds_frag(xa + xoff<C>(16 * i + c15, 4 * kk + g));
+#pragma unroll
+                    for (int e = 0; e < LPW; ++e) la[e] = lds_frag(xa + xoff<C>(16 * lm[e] + c15, 4 * kk + g));
+                };
+                Frag fa[2][MT], la[2][LPW > 0 ? LPW : 1], fw[2][FULL > 0 ? FULL : 1], lw[2][LPW > 0 ? LPW : 1];
+                wring_wait(KSTEPS - 1 < GM::WNBUF - 1 ? KSTEPS - 1 : GM::WNBUF - 1);          // k-step 0 (the prologue filled the whole ring)
+                __syncthreads();
+                frags(0, fa[0], la[0], fw[0], lw[0]);
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const int cur = kk & 1, nxt = cur ^ 1;
+                    if (kk + 1 < KSTEPS) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's fragments of k-step kk are in registers
+                        wring_wait(KSTEPS - 2 - kk < GM::WNBUF - 2 ? KSTEPS - 2 - kk : GM::WNBUF - 2);      // its pieces of k-step kk + 1 have landed
+                        __syncthreads();
+#ifndef W2_ABL_NODMA
+                        if (kk + GM::WNBUF < KSTEPS) wring_fill(hs, kk + GM::WNBUF);           // into the buffer k-step kk just left
+#endif
+                        frags(kk + 1, fa[nxt], la[nxt], fw[nxt], lw[nxt]);
+                    }
+#ifdef W2_ABL_NOMMA
+#pragma unroll
+                    for (int jj = 0; jj < FULL; ++jj) asm volatile("" :: "v"(fw[cur][jj]));
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(fa[cur][i]));
+#pragma unroll
+                    for (int e = 0; e < LPW; ++e) { asm volatile("" :: "v"(lw[cur][e])); asm volatile("" :: "v"(la[cur][e])); }
+#else
+#pragma unroll
+                    for (int jj = 0; jj < FULL; ++jj)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[cur][jj], fa[cur][i], acc[i][jj], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < LPW; ++e)
+                        lacc[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lw[cur][e], la[cur][e], lacc[e], 0, 0, 0);
+#endif
+                }
+                W2_STAMP(12 + hs);                         // (wave 0) projection MFMAs issued
+                __syncthreads();                           // the last stage has been read: the region becomes the q/k/v tiles
+                // rows of the q/k/v tiles beyond the projected rows (read as padded keys of the last window): finite
+                for (int i = tid; i < 3 * GS * (QR - MR) * 4; i += NT) {
+                    const int ch = i & 3, r = (i >> 2) % (QR - MR), tl = (i >> 2) / (QR - MR);
+                    *reinterpret_cast<bf16x8*>(qkvt + tl * TILE + hoff(MR + r, ch)) = zero_vec<T>();
+                }
+                // + bias, to the q/k/v LDS tiles [part][head][row][32]
+                auto put = [&](int t, int i, const f32x4& v) {
+                    const int part = t / (2 * GS), within = t - part * 2 * GS;
+                    const f32x4 b4 = load4f(p.bqkv + part * C + (head0 + hs * GS) * 32 + within * 16 + 4 * g);
+                    char* tile = qkvt + (part * GS + (within >> 1)) * TILE;
+                    store4f(reinterpret_cast<T*>(tile + hoff(16 * i + c15, (within & 1) * 2 + (g >> 1)) + (g & 1) * 8), v + b4);
+                };
+#pragma unroll
+                for (int jj = 0; jj < FULL; ++jj)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) put(wave + NWV * jj, i, acc[i][jj]);
+#pragma unroll
+                for (int e = 0; e < LPW; ++e)
+                    if (wave + NWV * e < LQ) put(ln[e], lm[e], lacc[e]);
+            } else
             {
                 f32x4 acc[MT][NTQW];
                 f32x4 b4[NTQW];
@@ -328,11 +466,7 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk) {
                     Frag fa[MT];
-#ifdef W2_NO_AREAD
-                    const int ch = kchunk(0);              // (ablation build: A fragments read once)
-#else
                     const int ch = kchunk(kk);
-#endif
 #pragma unroll
                     for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const Frag*>(xln + xoff<C>(16 * i + c15, ch));
 #pragma unroll
@@ -342,11 +476,9 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                             for (int i = 0; i < MT; ++i)
                                 acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk % PD][jj], fa[i], acc[i][jj], 0, 0, 0);
                         }
-#ifndef W2_NO_WLOAD
                         if constexpr (PAIR && PD % 2 == 0) {
-                            // the two k-steps of a pair read the two halves of the same 128-byte lines: request them back to back
-                            // (the second request merges with the first's miss; issued one k-step apart the line has left the 32-KB
-                            // L1 again -- 72 KB of fragments are in flight per CU -- and every line crosses L2 -> L1 twice)
+                            // the two k-steps of a pair read the two halves of the same 128-byte lines: requested back to back
+                            // (issued one k-step apart the line has left the 32-KB L1 again and crosses L2 -> L1 twice)
                             if (kk & 1) {
                                 if (kk - 1 + PD < KSTEPS) fb[(kk - 1) % PD][jj] = *reinterpret_cast<const Frag*>(wrow[jj] + koff(kk - 1 + PD));
                                 if (kk + PD < KSTEPS) fb[kk % PD][jj] = *reinterpret_cast<const Frag*>(wrow[jj] + koff(kk + PD));
@@ -354,8 +486,12 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                         } else {
                             if (kk + PD < KSTEPS) fb[kk % PD][jj] = *reinterpret_cast<const Frag*>(wrow[jj] + koff(kk + PD));
                         }
-#endif
                     }
+                }
+                // rows of the q/k/v tiles beyond the projected rows (read as padded keys of the last window): finite
+                for (int i = tid; i < 3 * GS * (QR - MR) * 4; i += NT) {
+                    const int ch = i & 3, r = (i >> 2) % (QR - MR), tl = (i >> 2) / (QR - MR);
+                    *reinterpret_cast<bf16x8*>(qkvt + tl * TILE + hoff(MR + r, ch)) = zero_vec<T>();
                 }
                 W2_STAMP(12 + hs);                         // (wave 0) projection MFMAs issued
                 // + bias, to the q/k/v LDS tiles [part][head][row][32]
@@ -373,12 +509,14 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                 }
             }
             // weight fragments of what comes next: the next sub-group's first k-steps
-            if (hs + 1 < NSUB) {
+            if constexpr (!GM::WLDS) {
+                if (hs + 1 < NSUB) {
 #pragma unroll
-                for (int jj = 0; jj < NTQW; ++jj) {
-                    const T* w = wq_ptr(hs + 1, wave + NWV * jj);
+                    for (int jj = 0; jj < NTQW; ++jj) {
+                        const T* w = wq_ptr(hs + 1, wave + NWV * jj);
 #pragma unroll
-                    for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
+                        for (int d = 0; d < PD; ++d) fb[d][jj] = *reinterpret_cast<const Frag*>(w + koff(d));
+                    }
                 }
             }
             __syncthreads();
@@ -509,7 +647,10 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                     }
                 }
             }
-            if (hs + 1 < NSUB) __syncthreads();          // the q/k/v tiles are rewritten by the next sub-group
+            if (hs + 1 < NSUB) {
+                __syncthreads();                          // the q/k/v tiles are rewritten by the next sub-group
+                if constexpr (GM::WLDS) wring_fill(hs + 1, 0);
+            }
         }
 
         // ================= output-projection operands that do not depend on the other groups: ALL weight fragments of this
@@ -518,7 +659,10 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
         const int pm0 = MG > 1 ? (wave / NTP) * MTW : 0;
         auto pt = [&](int jj) -> int { return MG > 1 ? wave % NTP : wave + NWV * jj; };
         const bool pact = MG > 1 ? wave < MG * NTP : true;
-        Frag fpj[KSTEPS][NTPW];
+        // (PLDS: this group's rows of Wproj go to the q/k/v region by LDS-DMA once the attention phase has left it -- whole
+        // cache lines, no fragment registers -- and land while the groups wait for each other)
+        constexpr bool PLDS = GM::WLDS && NHG > 1 && OC * C * 2 <= GM::QB;
+        Frag fpj[PLDS ? 1 : KSTEPS][NTPW];
         f32x4 pb4[NTPW];
         bf16x4 resid[MTW][NTPW];             // shortcut values, converted where they are used (a conversion here would wait for the load)
         int tokm[MTW];
@@ -534,8 +678,10 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
             const int t = min(pt(jj), NTP - 1);
             const int n0 = (NHG > 1 ? hg * OC : 0) + 16 * t;
             const T* w = p.wproj + (long)(n0 + c15) * C;
+            if constexpr (!PLDS) {
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) fpj[ks][jj] = *reinterpret_cast<const Frag*>(w + koff(ks));
+                for (int ks = 0; ks < KSTEPS; ++ks) fpj[ks][jj] = *reinterpret_cast<const Frag*>(w + koff(ks));
+            }
             pb4[jj] = load4f(p.bproj + n0 + 4 * g);
 #pragma unroll
             for (int i = 0; i < MTW; ++i) resid[i][jj] = *reinterpret_cast<const bf16x4*>(p.x + (long)max(tokm[i], 0) * C + n0 + 4 * g);
@@ -559,6 +705,22 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
             vm_drain();
             __syncthreads();
             W2_STAMP(7);                                   // slice published
+            if constexpr (PLDS) {
+                // Wproj rows [hg OC, +OC) -> LDS image [OC][C] in the A-operand layout (xoff): piece = 1 KB of the image
+                constexpr int NPC = OC * C * 2 / 1024;
+                static_assert((OC * C * 2) % 1024 == 0, "projection weight image");
+                const uint32_t dst0 = lds_addr(qkvt);
+#pragma unroll
+                for (int j = 0; j < (NPC + NWV - 1) / NWV; ++j) {
+                    const int pc = wave + NWV * j;
+                    if (pc < NPC) {
+                        const int slot = pc * 64 + lane, r = slot / (C / 8), pos = slot - r * (C / 8);
+                        constexpr int GRP = (C / 8) % 16 == 0 ? 16 : ((C / 8) % 8 == 0 ? 8 : 4);
+                        const int ch = (pos & ~(GRP - 1)) | ((pos ^ r) & (GRP - 1));
+                        glds16(p.wproj + (long)(hg * OC + r) * C + ch * 8, dst0 + pc * 1024);
+                    }
+                }
+            }
             if (tid == 0) {
                 __hip_atomic_fetch_add(p.sync + set, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // wait for the other groups of the set (bounded: ~2 s, then the error word is set and the result is garbage)
@@ -589,6 +751,7 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                 }
                 // padded rows M..MR-1 of the tile keep the LayerNorm tile's zeros (the attention-output tile ends below them)
             }
+            if constexpr (PLDS) vm_drain();                // (the projection weights were requested before these loads: landed)
             __syncthreads();
             W2_STAMP(9);                                   // full rows in LDS
             // every reader counts itself out (the add is issued here, its result is looked at after the projection)
@@ -614,18 +777,28 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
 #pragma unroll
                 for (int jj = 0; jj < NTPW; ++jj) pacc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (pact) {
+                // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (two register sets)
+                Frag fa[2][MTW], fw[2][NTPW];
+                auto pfrags = [&](int ks, Frag (&a)[MTW], Frag (&w)[NTPW]) {
+                    const int ch = kchunk(ks);
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) a[i] = *reinterpret_cast<const Frag*>(atile + xoff<C>(min(16 * (pm0 + i), MR - 16) + c15, ch));
+#pragma unroll
+                    for (int jj = 0; jj < NTPW; ++jj) {
+                        if constexpr (PLDS) w[jj] = lds_frag(lds_addr(qkvt) + xoff<C>(16 * min(pt(jj), NTP - 1) + c15, ch));
+                        else w[jj] = fpj[ks][jj];
+                    }
+                };
+                pfrags(0, fa[0], fw[0]);
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const int ch = kchunk(ks);
-                    Frag fa[MTW];
-#pragma unroll
-                    for (int i = 0; i < MTW; ++i) fa[i] = *reinterpret_cast<const Frag*>(atile + xoff<C>(min(16 * (pm0 + i), MR - 16) + c15, ch));
+                    if (ks + 1 < KSTEPS) pfrags(ks + 1, fa[(ks + 1) & 1], fw[(ks + 1) & 1]);
 #pragma unroll
                     for (int jj = 0; jj < NTPW; ++jj) {
                         if (pt(jj) < NTP) {
 #pragma unroll
                             for (int i = 0; i < MTW; ++i)
-                                pacc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fpj[ks][jj], fa[i], pacc[i][jj], 0, 0, 0);
+                                pacc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks & 1][jj], fa[ks & 1][i], pacc[i][jj], 0, 0, 0);
                         }
                     }
                 }

@@ -113,19 +113,18 @@ _WMSA2 = os.environ.get("MVLT_WMSA2", "1") != "0"           # second design at s
 def _wmsa_mode(dtype, B, res, C, nH):
     """How the attention half of a block runs: 0 = four launches, 1 = mvlt_swin_wmsa_fwd (one window per workgroup), 2 =
     mvlt_swin_wmsa2_fwd (two windows x a head group per workgroup, the groups meet inside the launch).  Measured on MI355X
-    at B = 32 (scripts/bench_wmsa.py, profiles/r4_wmsa*): stage 2 (128 windows of C = 384) 30 us with the second design
-    against 52 us for the first or for four launches; stages 0 / 1 (2048 / 512 windows) both designs are 2x faster than four
-    launches.  MVLT_FUSED_WMSA=0 forces the four launches (the parity tests use it to compare the paths)."""
+    at B = 32, training mode (scripts/bench_wmsa.py, profiles/r4_wmsa2_*): stage 0 / 1 / 2 = 57.6 / 36.4 / 27.9 us with the
+    second design, 60.1 / 46.1 / 60.1 us with the first, ~94 / 62 / 52 us as four launches.  Small launches (fewer than 64
+    windows: the B = 2 configurations) keep the first design where it has enough windows, else the four launches.
+    MVLT_FUSED_WMSA=0 forces the four launches, MVLT_WMSA2=0 the first design (A/B measurements, parity tests)."""
     if _FUSED_WMSA == "0":
         return 0
     nwin = B * (res // 7) ** 2
-    if _WMSA2 and C >= 384 and nwin >= 64 and ops.swin_wmsa2_supported(dtype, B, res, C, nH):
+    if _WMSA2 and nwin >= 64 and ops.swin_wmsa2_supported(dtype, B, res, C, nH):
         return 2
     if not ops.swin_wmsa_supported(dtype, C, nH):
         return 0
     return 1 if (_FUSED_WMSA == "1" or nwin >= 512 or (nwin >= 256 and C <= 256)) else 0
-
-
 
 
 class _SwinFn(torch.autograd.Function):

@@ -16,3 +16,5 @@ for f in $ABL; do
   echo "=== ablation $f" >> gpurun_out/wmsa2_trace.txt; echo "=== ablation $f"
   STAGE=${STAGE:-2} timeout -k 10 120 python scripts/wmsa2_trace.py 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/wmsa2_trace.txt
 done
+# restore the product build (the diagnostic objects above are newer than the source: make alone would keep them)
+rm -f medical-vision-langauge-transformer_amd/csrc/wmsa2.o && make -C medical-vision-langauge-transformer_amd/csrc -j8 > /dev/null 2>&1 && echo "product build restored"
