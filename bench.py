@@ -341,7 +341,14 @@ def main():
     bucket_mb = int(os.environ.get("MVLT_DDP_BUCKET_MB", "64"))
     reducer = GradReducer(model, comm_dtype=comm, bucket_bytes=bucket_mb << 20) if use_dist else None
     step = PretrainStep(model, reducer=reducer, world_size=world)
-    batch_full = synthetic_batch(PER_GPU_BATCH, SEQ, "cuda", 1234 + rank, with_lengths=True)
+    lens = None
+    if world > 1:
+        # caption lengths of the GLOBAL batch (same draw on every rank), dealt to the ranks with equal sums: with packed rows a
+        # rank's step time follows its row count, and everybody waits at the all-reduce for the rank with the longest captions
+        from mvlt_amd.data import deal_balanced
+        gl = torch.randint(16, SEQ, (world * PER_GPU_BATCH,), generator=torch.Generator().manual_seed(4242)).tolist()
+        lens = [gl[i] for i in deal_balanced(list(range(len(gl))), gl, world)[rank]]
+    batch_full = synthetic_batch(PER_GPU_BATCH, SEQ, "cuda", 1234 + rank, with_lengths=True, lengths=lens)
     batch = batch_full[:4]                          # the reference signature: no caption lengths
 
     for _ in range(args.warmup):

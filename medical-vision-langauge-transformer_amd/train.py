@@ -7,16 +7,19 @@ import torch
 from .optim import FusedAdamW
 
 
-def synthetic_batch(B, T, device, seed, vocab=30522, itm=True, with_lengths=False):
+def synthetic_batch(B, T, device, seed, vocab=30522, itm=True, with_lengths=False, lengths=None):
     """image N(0,1) [B,3,224,224]; caption ids U{1000..vocab-1}, last real id = [END]=104,
     zero padded; <=10 MLM labels per sample (20%), 80% of them replaced by [MASK]=103;
-    ITM labels Bernoulli(0.5) (run_pretrain_rgc_roco_medicat.py:134-212)."""
+    ITM labels Bernoulli(0.5) (run_pretrain_rgc_roco_medicat.py:134-212).  ``lengths``: caption lengths to use instead of
+    drawing them (a data-parallel run deals the global batch's lengths to its ranks: data.deal_balanced)."""
     g = torch.Generator().manual_seed(seed)
     image = torch.randn(B, 3, 224, 224, generator=g)
     ids = torch.zeros(B, T, dtype=torch.long)
     labels = torch.full((B, T), -100, dtype=torch.long)
     for b in range(B):
         ln = int(torch.randint(16, T, (1,), generator=g))
+        if lengths is not None:
+            ln = int(lengths[b])
         row = torch.randint(1000, vocab, (ln,), generator=g)
         row[-1] = 104
         nm = min(10, max(1, round(0.2 * ln)))

@@ -54,3 +54,29 @@ def test_itm_pairs_follow_getitem():
             other = i if j == k else j
             assert other != k and cap(other) != cap(k) and (i == k or j == k)
     assert all(l == 1 for _, _, l in itm_pairs(list(range(50)), 50, cap, rng, itm_task=False))
+
+
+def test_length_balanced_sharding_keeps_the_global_batch():
+    """ShardSampler(lengths=, batch_size=): every global step draws the same members as DistributedSampler's stride, re-dealt so
+    that the ranks' caption-length sums (their packed encoder rows) differ by less than one caption."""
+    import random
+    from mvlt_amd.data import ShardSampler, deal_balanced
+    n, world, bs = 1000, 8, 32
+    rng = random.Random(3)
+    lengths = [rng.randint(16, 79) for _ in range(n)]
+    plain = [list(ShardSampler(n, world, r, seed=5)) for r in range(world)]
+    bal = [list(ShardSampler(n, world, r, seed=5, lengths=lengths, batch_size=bs)) for r in range(world)]
+    assert all(len(b) == len(p) for b, p in zip(bal, plain))
+    steps = len(plain[0]) // bs
+    worst_plain = worst_bal = 0
+    for s in range(steps):
+        members_plain = sorted(i for r in range(world) for i in plain[r][s * bs:(s + 1) * bs])
+        members_bal = sorted(i for r in range(world) for i in bal[r][s * bs:(s + 1) * bs])
+        assert members_plain == members_bal                      # same global batch
+        sums_p = [sum(lengths[i] for i in plain[r][s * bs:(s + 1) * bs]) for r in range(world)]
+        sums_b = [sum(lengths[i] for i in bal[r][s * bs:(s + 1) * bs]) for r in range(world)]
+        worst_plain = max(worst_plain, max(sums_p) - min(sums_p))
+        worst_bal = max(worst_bal, max(sums_b) - min(sums_b))
+    assert worst_bal <= 79 and worst_bal < worst_plain / 4, (worst_bal, worst_plain)
+    parts = deal_balanced(list(range(16)), [5, 1, 9, 3, 7, 7, 2, 8, 4, 6, 1, 1, 9, 9, 3, 5], 4)
+    assert sorted(i for p in parts for i in p) == list(range(16)) and all(len(p) == 4 for p in parts)
