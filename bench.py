@@ -30,7 +30,7 @@ PER_GPU_BATCH, SEQ = 32, 80
 
 DOMINANT_NAME = ("forward + dgrad GEMM family of the Swin blocks / BertLayers: gemm_kernel<bf16,{128|64},{128|96|64},row,{row|kmajor}>, "
                  "gemm_glds_kernel<{64|128},{64|96|128}>, gemm8_kernel (x W^T and dy W with fused epilogues; main stream) -- the "
-                 "family with the largest share of GPU time (~48 %, profiles/r3_bench_kernel_stats.csv)")
+                 "family with the largest share of GPU time (~45 %, profiles/r4_bench_kernel_stats.csv)")
 WGRAD_NAME = ("gemm_group_kernel<bf16,{128|64},{128|96},kmajor,kmajor> (grouped weight-gradient GEMMs dW_i = dY_i^T X_i "
               "+ bias gradients of one layer per launch; side stream, beside the dgrad chain)")
 DOMINANT = ("group", 1, 64, 128)   # gemm_group_kernel<bf16, BM=128|64, BN=128, A k-major, B k-major>: the grouped weight-
@@ -249,29 +249,34 @@ def other_configs(M):
 
 def profiled_traffic(key):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (cannot be collected inside this
-    process): profiles/r3_dominant_kernel_traffic.json {"family": {...}, "wgrad_group": {...}}, filled in from the
+    process): profiles/r4_dominant_kernel_traffic.json {"family": {...}, "wgrad_group": {...}}, filled in from the
     scripts/pmc.py passes over scripts/profile_step.py (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)."""
     f = os.path.join(ROOT, "profiles", "r3_dominant_kernel_traffic.json")
     try:
         with open(f) as fh:
             d = json.load(fh)
-        return d[key].get("traffic_bytes_per_launch"), "profiles/r3_dominant_kernel_traffic.json"
+        return d[key].get("traffic_bytes_per_launch"), "profiles/r4_dominant_kernel_traffic.json"
     except Exception:
         return None, None
 
 
 def roofline_entry(samples, name, traffic_key, every):
-    """samples: [(executed flops, ms)] of launches bracketed with HIP events inside the timed region."""
+    """samples: [(executed flops, ms, algorithmic bytes)] of launches bracketed with HIP events inside the timed region."""
     if not samples:
         return None
-    ms = sum(t for _, t in samples)
-    tflops = sum(f for f, _ in samples) / (ms * 1e-3) / 1e12
+    ms = sum(s[1] for s in samples)
+    tflops = sum(s[0] for s in samples) / (ms * 1e-3) / 1e12
     traffic, src = profiled_traffic(traffic_key)
+    algo = sum(s[2] for s in samples) / len(samples) if len(samples[0]) > 2 else None
     return {"bound": "mfma", "kernel": name, "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tflops / PEAK_BF16_TFLOPS, 4),
-            # HBM bytes per launch: rocprofv3 PMC passes of the same step (2*FETCH_SIZE + WRITE_SIZE), read from the
+            # HBM-side bytes per launch: rocprofv3 PMC passes of the same step (2*FETCH_SIZE + WRITE_SIZE), read from the
             # committed profile file named in traffic_source -- not measurable in-process
             "traffic": traffic, "traffic_source": src,
+            # algorithmic bytes per launch of the SAME sampled launches: weights once, activation rows in, output rows out,
+            # epilogue operands (residual / saved pre-activation); with the row count the kernels read on the device
+            "algorithmic_bytes": None if algo is None else int(algo),
+            "traffic_over_algorithmic": None if (algo is None or not traffic) else round(traffic / algo, 2),
             "launches": len(samples), "avg_launch_us": round(1e3 * ms / len(samples), 2),
             "flops": "executed: 2 M N K with the row count the kernels read on the device (ragged batches), not the dense bound",
             "sampling": f"1 in {every} launches of the family inside the timed region, HIP events on the launch stream"}
@@ -413,7 +418,7 @@ def main():
         roofline = roofline_entry(fam_samples, DOMINANT_NAME, "family", fam_every)
         roofline_wgrad = roofline_entry(native_samples, WGRAD_NAME, "wgrad_group", every)
         if roofline is None and kr is not None:          # ctypes host path (MVLT_NATIVE_HOST=0): only the grouped kernel is bracketed
-            roofline_wgrad = roofline_entry([(kr["tflops"] * 1e12 * kr["avg_us"] * 1e-6, kr["avg_us"] * 1e-3)] * kr["launches"],
+            roofline_wgrad = roofline_entry([(kr["tflops"] * 1e12 * kr["avg_us"] * 1e-6, kr["avg_us"] * 1e-3, 0.0)] * kr["launches"],
                                             WGRAD_NAME, "wgrad_group", every)
             roofline = roofline_wgrad
         gpp_exec = packed_gflop_per_pair(batch_full)

@@ -12,6 +12,7 @@
 #include <torch/extension.h>
 #include <hip/hip_runtime_api.h>
 #include <vector>
+#include <tuple>
 #include <cstdlib>
 #include <string>
 #include "../../include/mvlt_hip.h"
@@ -89,12 +90,13 @@ struct KernelTimer {
                                           // the side stream, which start behind a cross-stream wait, +2 % without and -5 % with
     std::vector<hipEvent_t> ev;
     std::vector<double> mn2;          // per sample: 2 * sum_i (the two dimensions that are not ragged)
+    std::vector<double> bfix, brow;   // per sample: ALGORITHMIC bytes = bfix + rows * brow (operands read once, outputs written once)
     std::vector<int> bound;           // per sample: host-known upper bound of the ragged dimension
     int* dev_rows = nullptr;          // pinned host: ragged dimension read from the device (-1: none, use the bound)
     size_t used = 0, cap = 0;
     bool sample() { return on && (count++ % every) == 0 && used < cap; }
-    void begin(void* stream, double mn2_, int bound_, const int32_t* rows_dev) {
-        mn2.push_back(mn2_); bound.push_back(bound_);
+    void begin(void* stream, double mn2_, int bound_, const int32_t* rows_dev, double bfix_ = 0.0, double brow_ = 0.0) {
+        mn2.push_back(mn2_); bound.push_back(bound_); bfix.push_back(bfix_); brow.push_back(brow_);
         dev_rows[used] = -1;
         if (rows_dev) (void)hipMemcpyAsync(&dev_rows[used], rows_dev, sizeof(int), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
         (void)hipEventRecord(ev[3 * used], static_cast<hipStream_t>(stream));
@@ -110,21 +112,22 @@ struct KernelTimer {
     void reset(int every_, size_t cap_) {
         for (auto e : ev) (void)hipEventDestroy(e);
         if (dev_rows) (void)hipHostFree(dev_rows);
-        ev.clear(); mn2.clear(); bound.clear(); dev_rows = nullptr; used = 0; count = 0;
+        ev.clear(); mn2.clear(); bound.clear(); bfix.clear(); brow.clear(); dev_rows = nullptr; used = 0; count = 0;
         on = cap_ > 0; every = std::max(1, every_); cap = cap_;
         if (!on) return;
         ev.resize(3 * cap);
         for (auto& e : ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate");
         TORCH_CHECK(hipHostMalloc(reinterpret_cast<void**>(&dev_rows), cap * sizeof(int), hipHostMallocDefault) == hipSuccess, "hipHostMalloc");
     }
-    std::vector<std::pair<double, double>> collect() {          // [(executed flops, milliseconds)]; call after a device synchronize
-        std::vector<std::pair<double, double>> out;
+    // [(executed flops, milliseconds, algorithmic bytes)]; call after a device synchronize
+    std::vector<std::tuple<double, double, double>> collect() {
+        std::vector<std::tuple<double, double, double>> out;
         for (size_t i = 0; i < used; ++i) {
             float ms = 0.f, over = 0.f;
             if (hipEventElapsedTime(&ms, ev[3 * i], ev[3 * i + 1]) != hipSuccess) continue;
             if (subtract_record_cost && hipEventElapsedTime(&over, ev[3 * i + 1], ev[3 * i + 2]) == hipSuccess && over < ms) ms -= over;
             const int rows = dev_rows[i] >= 0 ? std::min(dev_rows[i], bound[i]) : bound[i];
-            out.emplace_back(mn2[i] * rows, (double)ms);
+            out.emplace_back(mn2[i] * rows, (double)ms, bfix[i] + brow[i] * rows);
         }
         on = false;
         return out;
@@ -173,7 +176,13 @@ void gemm(int dtype, int M, int N, int K, const void* A, int64_t lda, bool ak, c
     const size_t need = mvlt_gemm_workspace_bytes(&p);
     if (need) { p.workspace = workspace(ws, need, like); p.workspace_bytes = (size_t)ws.buf.numel(); }
     const bool timed = !ak && g_timer_fam.sample();          // forward / dgrad products: rows (M) may be ragged
-    if (timed) g_timer_fam.begin(stream, 2.0 * N * K, M, e.m_dev);
+    if (timed) {
+        // algorithmic bytes of the product: the weight once, per row the activation row in and the output row out,
+        // plus what the fused epilogue reads / writes per row (residual, saved pre-activation, gelu' operand)
+        const double esz = dtype == MVLT_BF16 ? 2.0 : 4.0;
+        const double per_row = (K + N * (e.out_f32 ? 4.0 / esz : 1.0) + (e.residual ? N : 0) + (e.pre ? N : 0) + (e.aux ? N : 0)) * esz;
+        g_timer_fam.begin(stream, 2.0 * N * K, M, e.m_dev, (double)N * K * esz, per_row);
+    }
     ck(mvlt_gemm(&p, stream), "mvlt_gemm");
     if (timed) g_timer_fam.end(stream);
 }
@@ -213,7 +222,7 @@ void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws, con
         return;
     }
     MvltGemm arr[8];
-    double mn2 = 0;
+    double mn2 = 0, bfix = 0, brow = 0;        // algorithmic bytes: per reduction row both operand rows (bf16), once the f32 dW + db
     for (int i = 0; i < n; ++i) {
         const auto& it = items[i];
         Epi e; e.out_f32 = true; e.a_colsum = P<float>(it.db); e.m_dev = k_dev;
@@ -221,11 +230,13 @@ void wgrad_group(const std::vector<WItem>& items, void* stream, Scratch& ws, con
                   dp(*it.x), it.x->size(1), true, P(it.dw), it.x->size(1), e);
         arr[i].split_k = 1;
         mn2 += 2.0 * arr[i].M * arr[i].N;          // the reduction length (activation rows) is the ragged dimension here
+        brow += (double)(arr[i].M + arr[i].N) * it.dy->element_size();
+        bfix += ((double)arr[i].M * arr[i].N + arr[i].M) * 4.0;
     }
     const size_t need = mvlt_gemm_group_workspace_bytes(arr, n);          // k-slice slabs of the 8-wave engine
     if (need) { arr[0].workspace = workspace(ws, need, *items[0].dy); arr[0].workspace_bytes = (size_t)ws.buf.numel(); }
     const bool timed = g_timer.sample();
-    if (timed) g_timer.begin(stream, mn2, arr[0].K, k_dev);
+    if (timed) g_timer.begin(stream, mn2, arr[0].K, k_dev, bfix, brow);
     ck(mvlt_gemm_group(arr, n, stream), "mvlt_gemm_group");
     if (timed) g_timer.end(stream);
 }
@@ -504,8 +515,8 @@ void side_release() { g_side_keepalive.clear(); g_ws_side.retired.clear(); g_ws_
 void timer_begin(int64_t which, int64_t every, int64_t capacity) {
     (which == 0 ? g_timer : g_timer_fam).reset((int)every, (size_t)capacity);
 }
-// -> [(executed flops, milliseconds)] of the sampled launches; call after a device synchronize
-std::vector<std::pair<double, double>> timer_collect(int64_t which) { return (which == 0 ? g_timer : g_timer_fam).collect(); }
+// -> [(executed flops, milliseconds, algorithmic bytes)] of the sampled launches; call after a device synchronize
+std::vector<std::tuple<double, double, double>> timer_collect(int64_t which) { return (which == 0 ? g_timer : g_timer_fam).collect(); }
 
 }  // namespace
 
