@@ -450,7 +450,9 @@ def main():
                "executed_gflop_per_pair": round(gpp_exec, 1),
                "step_tflops_per_gpu": round(value / world * gpp_exec / 1e3, 2),
                "step_mfma_frac": round(value / world * gpp_exec / 1e3 / PEAK_BF16_TFLOPS, 4),
-               "roofline": roofline, "roofline_wgrad_group": roofline_wgrad, "blocks": blocks}
+               "roofline": roofline, "roofline_wgrad_group": roofline_wgrad, "blocks": blocks,
+               # sticky error words of the fused W-MSA kernels' in-launch hand-off (a bounded wait that ran out): must be 0
+               "wmsa2_sync_errors": ops.wmsa2_sync_errors()}
         if dense is not None:
             out.update(dense)
         if extra is not None:

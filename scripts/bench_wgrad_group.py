@@ -1,5 +1,5 @@
 """Stand-alone timing of the grouped weight-gradient launch (mvlt_gemm_group) on the step's layer shapes (B=32):
-    MVLT_GROUP_DEEP=0|2|3|4 python scripts/bench_wgrad_group.py"""
+    python scripts/bench_wgrad_group.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mvlt_amd  # noqa

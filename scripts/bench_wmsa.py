@@ -7,17 +7,7 @@ from mvlt_amd.indexing import batched_window_maps
 torch.manual_seed(0)
 dt = torch.bfloat16
 B = int(os.environ.get("B", 32))
-ONLY = os.environ.get("ONLY")          # "fused" -> only the fused kernels (for rocprofv3 passes)
-if os.environ.get("SWEEP"):            # one child process per kernel instantiation (MVLT_WMSA_CFG is read once)
-    import subprocess
-    for st, cfgs in ((0, ("0", "14")), (1, ("0", "24", "34", "28")), (2, ("0", "24", "44", "28"))):
-        for c in cfgs:
-            env = dict(os.environ, STAGE=str(st), MVLT_WMSA_CFG=c, ONLY="fused")
-            env.pop("SWEEP")
-            out = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True).stdout
-            print(f"cfg={c}: " + out.strip().replace("\n", f"\ncfg={c}: "), flush=True)
-    sys.exit(0)
-
+ONLY = os.environ.get("ONLY")          # "fused" -> only the fused kernels (skips the four-launch sequences)
 
 def timeit(f, n=20):
     for _ in range(3): f()
