@@ -385,8 +385,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
                                                    float bc1, float bc2_sqrt, float gscale) {
     // torch.optim.AdamW (single tensor path): p *= 1-lr*wd; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
     const long nv = n / 4;
+    // The fp32 master, both moments and the gradient are read and written once per step (28 of the 30 bytes per
+    // parameter): non-temporal accesses, so that the sweep does not push the bf16 shadow (the only thing the next forward
+    // reads) and the activations out of the caches: -0.07 ms per step (same-box A/B, 12.78 -> 12.70 ms).
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
-        f32x4 pp = load4f(p + 4 * i), gg = load4f(g + 4 * i), mm = load4f(m + 4 * i), vv = load4f(v + 4 * i);
+        f32x4 pp = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4 * i));
+        f32x4 gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + 4 * i));
+        f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + 4 * i));
+        f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + 4 * i));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float gr = gg[e] * gscale;
@@ -395,7 +401,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
             vv[e] = b2 * vv[e] + (1.0f - b2) * gr * gr;
             pp[e] -= (lr / bc1) * mm[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
         }
-        store4f(p + 4 * i, pp); store4f(m + 4 * i, mm); store4f(v + 4 * i, vv);
+        __builtin_nontemporal_store(pp, reinterpret_cast<f32x4*>(p + 4 * i));
+        __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m + 4 * i));
+        __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + 4 * i));
         if (sh) store4f(sh + 4 * i, pp);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
