@@ -36,7 +36,7 @@ enum { MVLT_OK = 0, MVLT_ERR_ARG = -1, MVLT_ERR_LAUNCH = -2, MVLT_ERR_UNSUPPORTE
  * signature; a binding compiles / hard-codes the value it was written against and compares it with what the
  * loaded library returns.  mvlt_sizeof(MVLT_STRUCT_*) lets a binding that mirrors the structs by hand (ctypes,
  * cgo, JNI) prove that its mirror has the size the library was compiled with (0 for an unknown id). */
-#define MVLT_ABI_VERSION 4
+#define MVLT_ABI_VERSION 5
 int mvlt_version(void);            /* MVLT_ABI_VERSION of the loaded library */
 const char* mvlt_arch(void);       /* "gfx950" */
 enum { MVLT_STRUCT_GEMM = 0, MVLT_STRUCT_LAYERNORM = 1, MVLT_STRUCT_LAYERNORM_BWD = 2, MVLT_STRUCT_LN_REDUCE_ITEM = 3,
@@ -223,6 +223,12 @@ typedef struct MvltAttn {
 } MvltAttn;
 int mvlt_attn_fwd(const MvltAttn* p, void* stream);
 int mvlt_attn_bwd(const MvltAttn* p, void* stream);   /* delta_ws: f32 [nseq,nH,L] */
+/* The same, and `event` (a hipEvent_t of the caller) completes with the call's LAST kernel: it rides on that dispatch as its
+ * stop event instead of a marker packet behind it (an event record costs the recording stream ~5 us, this form ~2.5 us:
+ * scripts/event_cost.hip).  For the fork of the weight-gradient stream, which follows the attention backward of every
+ * BertLayer / Swin block (modeling_bert.py:282-293 backward; visual_feature_extractor.py:224-254 backward): the caller
+ * then hipStreamWaitEvent()s on it.  Nothing is recorded when the call fails. */
+int mvlt_attn_bwd_ev(const MvltAttn* p, void* stream, void* event);
 
 /* ------------------------------------------------------------------ fused Swin (S)W-MSA (SURVEY.md 8b `swin_wmsa`)
  * The attention half of SwinTransformerBlock.forward in ONE launch (visual_feature_extractor.py:356-384 around

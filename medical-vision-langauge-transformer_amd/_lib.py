@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmvlt_hip.so")
 
 F32, BF16 = 0, 1
 OK = 0
-ABI_VERSION = 4          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
+ABI_VERSION = 5          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
 ERRORS = {-1: "MVLT_ERR_ARG", -2: "MVLT_ERR_LAUNCH", -3: "MVLT_ERR_UNSUPPORTED"}
 
 EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_DROPOUT = 1, 2, 4, 8
@@ -131,6 +131,7 @@ SYMBOLS = {
     "mvlt_layernorm_param_reduce_batch": (i32, [C.POINTER(MvltLnReduceItem), i32, vp]),
     "mvlt_attn_fwd": (i32, [C.POINTER(MvltAttn), vp]),
     "mvlt_attn_bwd": (i32, [C.POINTER(MvltAttn), vp]),
+    "mvlt_attn_bwd_ev": (i32, [C.POINTER(MvltAttn), vp, vp]),
     "mvlt_swin_wmsa_supported": (i32, [i32, i32, i32]),
     "mvlt_swin_wmsa_fwd": (i32, [C.POINTER(MvltSwinWmsa), vp]),
     "mvlt_swin_wmsa_bwd": (i32, [C.POINTER(MvltSwinWmsa), vp]),

@@ -20,6 +20,7 @@
 // position index are computed from (window, slot); the MVLBert key mask from
 // text ids; the seq2seq mask from (row, col, obj_end).
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "attn_frag.h"
 #include <cstdlib>
 
@@ -1184,11 +1185,21 @@ __global__ __launch_bounds__(AB2_NT) void bert_attn_bwd2_kernel(const AttnDev p)
     }
 }
 
+// mvlt_attn_bwd_ev: the caller's event rides on the LAST kernel of the call as that dispatch's own stop event
+// (hipExtLaunchKernelGGL) instead of a marker packet behind it: an event record costs the recording stream ~5 us, the
+// bound form ~2.5 us (scripts/event_cost.hip; the order seen by a stream waiting for the event is checked there too).
+thread_local hipEvent_t t_stop_event = nullptr;
+#define ATTN_LAUNCH_LAST(kernel, grid, block, shmem, stream, ...)                                                       \
+    do {                                                                                                                \
+        if (t_stop_event) { hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, t_stop_event, 0, __VA_ARGS__); t_stop_event = nullptr; } \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                       \
+    } while (0)
+
 static int bert_bwd_form() { return 1; }          // 1 = one-launch backward where it applies (bf16, <= 160 rows); else two launches
 static int launch_bert_bwd2(const AttnDev& d, hipStream_t s) {
     dim3 grid(d.nseq, d.nH);
     const bool s2s = d.mode == MVLT_ATTN_SEQ2SEQ, drop = d.drop_thresh != 0;
-#define AB2_LAUNCH(S, D) hipLaunchKernelGGL((bert_attn_bwd2_kernel<S, D>), grid, dim3(AB2_NT), AB2_SMEM, s, d)
+#define AB2_LAUNCH(S, D) ATTN_LAUNCH_LAST((bert_attn_bwd2_kernel<S, D>), grid, dim3(AB2_NT), AB2_SMEM, s, d)
     if (s2s) { if (drop) AB2_LAUNCH(true, true); else AB2_LAUNCH(true, false); }
     else { if (drop) AB2_LAUNCH(false, true); else AB2_LAUNCH(false, false); }
 #undef AB2_LAUNCH
@@ -1208,7 +1219,7 @@ int launch_split(const AttnDev& d, int dtype, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     }
     hipLaunchKernelGGL(k0, grid, dim3(256), sh, s, d);
-    hipLaunchKernelGGL(k1, grid, dim3(256), sh, s, d);
+    ATTN_LAUNCH_LAST(k1, grid, dim3(256), sh, s, d);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }
@@ -1228,7 +1239,7 @@ int launch(const AttnDev& d, bool bwd, int dtype, hipStream_t s) {
     if (bwd) {
         auto k = attn_bwd_kernel<T, HD, KT, SWIN>;
         if (sh > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(k, grid, dim3(256), sh, s, d);
+        ATTN_LAUNCH_LAST(k, grid, dim3(256), sh, s, d);
     } else {
         auto k = attn_fwd_kernel<T, HD, KT, SWIN>;
         if (sh > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -1259,8 +1270,8 @@ static int launch_swin_bwd2(const AttnDev& d, hipStream_t s) {
     dim3 grid(gx, d.nH);
     auto k0 = swin_attn_bwd2_kernel<false>;
     auto k1 = swin_attn_bwd2_kernel<true>;
-    if (d.shift != 0) hipLaunchKernelGGL(k1, grid, dim3(256), SW2_SMEM, s, d);
-    else hipLaunchKernelGGL(k0, grid, dim3(256), SW2_SMEM, s, d);
+    if (d.shift != 0) ATTN_LAUNCH_LAST(k1, grid, dim3(256), SW2_SMEM, s, d);
+    else ATTN_LAUNCH_LAST(k0, grid, dim3(256), SW2_SMEM, s, d);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }
@@ -1326,3 +1337,13 @@ int run(const MvltAttn* p, bool bwd, void* stream) {
 
 extern "C" int mvlt_attn_fwd(const MvltAttn* p, void* stream) { return run(p, false, stream); }
 extern "C" int mvlt_attn_bwd(const MvltAttn* p, void* stream) { return run(p, true, stream); }
+extern "C" int mvlt_attn_bwd_ev(const MvltAttn* p, void* stream, void* event) {
+    MVLT_CHECK(event, MVLT_ERR_ARG);
+    t_stop_event = reinterpret_cast<hipEvent_t>(event);
+    const int rc = run(p, true, stream);
+    if (t_stop_event) {                              // no kernel took it (an error return): nothing is recorded
+        t_stop_event = nullptr;
+        if (rc == MVLT_OK) return hipEventRecord(reinterpret_cast<hipEvent_t>(event), reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? MVLT_OK : MVLT_ERR_LAUNCH;
+    }
+    return rc;
+}

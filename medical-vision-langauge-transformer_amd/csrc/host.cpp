@@ -61,12 +61,15 @@ hipEvent_t next_event() {
     return e;
 }
 // experiments: MVLT_SIDE=0 issues the weight gradients on the main stream (no overlap with the dgrad chain)
-// side stream waits for everything queued on the main stream so far
-void fork_side(Streams& s) {
+// Fork behind the attention backward of a layer: its gradient is the last operand the layer's weight gradients need (the
+// products behind it only feed the dgrad chain), and the event completes with that kernel itself (mvlt_attn_bwd_ev: no marker
+// packet on the main stream, ~2.5 instead of ~5 us of main-stream time per layer; scripts/event_cost.hip).
+void attn_bwd_fork(const MvltAttn& p, Streams& s) {
     hipEvent_t e = next_event();
-    TORCH_CHECK(hipEventRecord(e, static_cast<hipStream_t>(s.main)) == hipSuccess, "hipEventRecord");
+    ck(mvlt_attn_bwd_ev(&p, s.main, e), "mvlt_attn_bwd_ev");
     TORCH_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(s.side), e, 0) == hipSuccess, "hipStreamWaitEvent");
 }
+
 
 // ----------------------------------------------------------------------------------------------- workspaces
 struct Scratch { Tensor buf; std::vector<Tensor> retired; };
@@ -375,14 +378,13 @@ Tensor bert_layer_bwd(const Tensor& dx, const std::vector<Tensor>& sv, const Ptr
     { MvltAttn p; fill_attn(p, qkv, a, (int)H, dp(ctx), fp(lse), (float)p_a, sd, (uint32_t)(8 * layer + 0));
       Tensor delta = at::empty_like(lse);
       p.dout = dp(dctx); p.dqkv = dp(dqkv); p.delta_ws = fp(delta);
-      ck(mvlt_attn_bwd(&p, st), "mvlt_attn_bwd"); }
-    Tensor dxin = empty2(rows, H, x);
-    { Epi e; e.m_dev = rd; e.residual = dp(dy1); e.ldr = H; if (nb) { e.pf = P(w[6]); e.pf_bytes = w[7]; } dgrad(dqkv, w[0], (int)H, dxin, e, st); }
+      attn_bwd_fork(p, ss); }
     // weight / bias gradients on the side stream (off the critical path)
-    fork_side(ss);
     for (const Tensor* t : std::initializer_list<const Tensor*>{&dz2, &act, &dh, &x1, &dz1, &ctx, &dqkv, &x}) g_side_keepalive.push_back(*t);
     wgrad_group({{&dz2, &act, g[6], g[7]}, {&dh, &x1, g[4], g[5]}, {&dz1, &ctx, g[2], g[3]}, {&dqkv, &x, g[0], g[1]}},
                 ss.side, g_ws_side, rd);
+    Tensor dxin = empty2(rows, H, x);
+    { Epi e; e.m_dev = rd; e.residual = dp(dy1); e.ldr = H; if (nb) { e.pf = P(w[6]); e.pf_bytes = w[7]; } dgrad(dqkv, w[0], (int)H, dxin, e, st); }
     return dxin;
 }
 
@@ -491,17 +493,16 @@ std::vector<Tensor> swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>&
       p.qkv = dp(qkv); p.out = dp(ao); p.lse = fp(lse); p.scale = (float)scale;
       p.bias_table = P<float>(f[4]); p.nW = nW; p.win_res = res; p.shift = shift;
       p.dout = dp(dao); p.dqkv = dp(dqkv); p.dbias_table = P<float>(g[6]);
-      ck(mvlt_attn_bwd(&p, st), "mvlt_attn_bwd"); }
+      attn_bwd_fork(p, ss); }
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&dy2, &act, &dh, &xn2, &dyw, &ao, &dqkv, &xn1w}) g_side_keepalive.push_back(*t);
+    wgrad_group({{&dy2, &act, g[11], g[12]}, {&dh, &xn2, g[9], g[10]}, {&dyw, &ao, g[4], g[5]}, {&dqkv, &xn1w, g[2], g[3]}},
+                ss.side, g_ws_side);
     Tensor dxn1w = empty2(rows, C, x);
     { Epi e; if (nb) { e.pf = P(w[6]); e.pf_bytes = w[7]; } dgrad(dqkv, w[0], C, dxn1w, e, st); }
     Tensor dx0 = empty2(rows, C, x), dy2n;
     { LnBranch br;
       if (s2_next) { dy2n = empty2(rows, C, x); br.dz = dp(dy2n); br.rowscale = P<float>(s2_next); br.rps = Lt; }
       ln_bwd(dxn1w, n2w, x, fp(stat1), fp(stat1) + rows, (int)rows, C, f[0], g[0], g[1], dp(dx1), dx0, br, st); }
-    fork_side(ss);
-    for (const Tensor* t : std::initializer_list<const Tensor*>{&dy2, &act, &dh, &xn2, &dyw, &ao, &dqkv, &xn1w}) g_side_keepalive.push_back(*t);
-    wgrad_group({{&dy2, &act, g[11], g[12]}, {&dh, &xn2, g[9], g[10]}, {&dyw, &ao, g[4], g[5]}, {&dqkv, &xn1w, g[2], g[3]}},
-                ss.side, g_ws_side);
     if (s2_next) return {dx0, dy2n};
     return {dx0};
 }

@@ -594,7 +594,9 @@ def attn_fwd(qkv, mode, nseq, Lq, nH, hd, scale, **kw):
     return out, lse
 
 
-def attn_bwd(dout, qkv, out, lse, mode, nseq, Lq, nH, hd, scale, dbias_table=None, **kw):
+def attn_bwd(dout, qkv, out, lse, mode, nseq, Lq, nH, hd, scale, dbias_table=None, event=None, **kw):
+    """event: a hipEvent_t handle (int) that completes with the call's last kernel (mvlt_attn_bwd_ev: the fork of the
+    weight-gradient stream without a marker packet on this stream)."""
     _need_cuda(qkv, dout)
     assert dout.is_contiguous() and dout.shape == out.shape
     dqkv = torch.empty_like(qkv)
@@ -606,7 +608,10 @@ def attn_bwd(dout, qkv, out, lse, mode, nseq, Lq, nH, hd, scale, dbias_table=Non
     if dbias_table is not None:
         assert dbias_table.dtype == torch.float32
         p.dbias_table = _p(dbias_table)
-    L.check(L.lib().mvlt_attn_bwd(C.byref(p), _stream()), "mvlt_attn_bwd")
+    if event is not None:
+        L.check(L.lib().mvlt_attn_bwd_ev(C.byref(p), _stream(), C.c_void_p(event)), "mvlt_attn_bwd_ev")
+    else:
+        L.check(L.lib().mvlt_attn_bwd(C.byref(p), _stream()), "mvlt_attn_bwd")
     return dqkv
 
 

@@ -16,11 +16,27 @@ import random; random.seed(5678)
 for i in range(warm):
     l = step(batch)
 torch.cuda.synchronize()
+if os.environ.get("HOLD_MS"):
+    # hold the GPU with a long streaming job while the host enqueues all the steps: the traced timeline then shows dependency and
+    # launch gaps only, not the tracer's slower host (scripts/step_timeline.py)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    junk = torch.zeros(1 << 28, device="cuda")            # 1 GiB: one add_ moves 2 GiB (~0.4 ms)
+    a.record(); junk.add_(1.0); b.record(); torch.cuda.synchronize()
+    n_hold = int(float(os.environ["HOLD_MS"]) / a.elapsed_time(b)) + 1
+    a.record()
+    for _ in range(n_hold):
+        junk.add_(1.0)
+    b.record()
 t0 = time.time()
 for i in range(steps):
     l = step(batch)
+t_enq = time.time() - t0
+e_end = torch.cuda.Event(enable_timing=True); e_end.record()
 torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
+if os.environ.get("HOLD_MS"):
+    print(f"held {a.elapsed_time(b):.1f} ms; host enqueued {steps} steps in {t_enq*1e3:.1f} ms; GPU time behind the hold "
+          f"{b.elapsed_time(e_end) / steps:.3f} ms per step (host ahead while the enqueue time is below the hold)", flush=True)
 print(f"B={B} ms/step={dt*1e3:.2f} pairs/s={B/dt:.1f} loss={l.item():.4f} mem={torch.cuda.max_memory_allocated()/2**30:.2f}GiB", flush=True)
 # host enqueue time: run steps without waiting for the GPU
 torch.cuda.synchronize()

@@ -645,6 +645,53 @@ def test_bert_attention(ops, dt, T, seq2seq, p):
     assert rel(dqkv, qr.grad) < tol(dt) * 3
 
 
+@pytest.mark.parametrize("case", ["swin_bf16", "swin_f32", "bert_bf16_131", "bert_f32_131", "bert_bf16_179"])
+def test_attention_backward_with_stop_event(ops, case):
+    """mvlt_attn_bwd_ev: same gradient as mvlt_attn_bwd on every backward path (one-launch bf16 kernels, the generic f32
+    kernel, the two-launch form of long rows), and a second stream that waits for the caller's event -- bound to the call's
+    last kernel, no marker packet -- sees the complete gradient."""
+    import ctypes
+    from mvlt_amd._lib import ATTN_SWIN, ATTN_BIDIR
+    hip = ctypes.CDLL("libamdhip64.so")
+    ev = ctypes.c_void_p()
+    assert hip.hipEventCreateWithFlags(ctypes.byref(ev), ctypes.c_uint(0x2)) == 0          # hipEventDisableTiming
+    dt = torch.float32 if "f32" in case else torch.bfloat16
+    if case.startswith("swin"):
+        res, nH, B = 14, 12, 32
+        nW = (res // 7) ** 2
+        qkv = rnd((B * nW * 49, 3 * nH * 32), dt, 60)
+        table = (0.5 * torch.randn(169, nH, generator=torch.Generator().manual_seed(61))).cuda()
+        args = (ATTN_SWIN, B * nW, 49, nH, 32, 32 ** -0.5)
+        kw = dict(bias_table=table, nW=nW, win_res=res, shift=3)
+        bkw = lambda: dict(kw, dbias_table=torch.zeros_like(table))
+    else:
+        T = 128 if case.endswith("179") else 80
+        B, nH, n_img = 8, 12, 49
+        Lq = n_img + 2 + T
+        qkv = rnd((B * Lq, 3 * nH * 64), dt, 62)
+        ids = torch.zeros(B, T, dtype=torch.long)
+        for b in range(B):
+            ids[b, :(b * 37) % (T + 1)] = 7
+        args = (ATTN_BIDIR, B, Lq, nH, 64, 0.125)
+        kw = dict(text_ids=ids.cuda(), obj_end=n_img + 1, dropout=(0.1, 5, 3))
+        bkw = lambda: dict(kw)
+    out, lse = ops.attn_fwd(qkv, *args, **kw)
+    dout = rnd(out.shape, dt, 63)
+    want = ops.attn_bwd(dout, qkv, out, lse, *args, **bkw())
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        got = ops.attn_bwd(dout, qkv, out, lse, *args, event=ev.value, **bkw())
+        assert hip.hipStreamWaitEvent(ctypes.c_void_p(side.cuda_stream), ev, 0) == 0
+        with torch.cuda.stream(side):
+            seen = got.clone()                     # ordered behind the event only
+        side.synchronize()
+        assert hip.hipEventQuery(ev) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(seen, want) and torch.equal(got, want)
+        got.record_stream(side)
+    assert hip.hipEventDestroy(ev) == 0
+
+
 @pytest.mark.parametrize("seq2seq", [False, True])
 def test_bert_attention_backward_full_batch_per_sequence(ops, seq2seq):
     """bf16 MVLBert attention backward at the step's size (B=32, 12 heads, L=131, dropout 0.1, every caption length
