@@ -350,6 +350,10 @@ int mvlt_tanh_fwd(int dtype, const void* x, void* y, int64_t n, void* stream);
 int mvlt_tanh_bwd(int dtype, const void* y, const void* dy, void* dx, int64_t n, void* stream);
 int mvlt_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint32_t tag, void* stream);
 int mvlt_droppath_scale(float* scale, int B, float p, uint64_t seed, uint32_t tag, void* stream);
+/* every DropPath scale of a forward pass in one launch (visual_feature_extractor.py:30-44 for each of the 2 x 24 residual
+ * branches): scale [rows, B] f32, row r keeps sample b with probability 1 - probs[r] (device f32 [rows], each < 1) and
+ * holds 1 / (1 - probs[r]) or 0; row r draws with tag + r */
+int mvlt_droppath_scales(float* scale, const float* probs, int rows, int B, uint64_t seed, uint32_t tag, void* stream);
 
 /* ------------------------------------------------------------------ losses
  * F.cross_entropy(logits, labels, ignore_index=-100) (model.py:410,418):

@@ -152,6 +152,7 @@ SYMBOLS = {
     "mvlt_tanh_bwd": (i32, [i32, vp, vp, vp, i64, vp]),
     "mvlt_dropout_mask": (i32, [vp, i64, f32, u64, u32, vp]),
     "mvlt_droppath_scale": (i32, [vp, i32, f32, u64, u32, vp]),
+    "mvlt_droppath_scales": (i32, [vp, vp, i32, i32, u64, u32, vp]),
     "mvlt_ce_fwd": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
     "mvlt_ce_bwd": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, f32, vp, vp, vp]),
     "mvlt_ce_fwd_ragged": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]),

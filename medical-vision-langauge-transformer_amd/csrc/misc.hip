@@ -279,6 +279,15 @@ __global__ void droppath_kernel(float* scale, int B, uint32_t thresh, float inv_
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) scale[b] = rng_keep(seed, tag, (uint32_t)b, thresh) ? inv_keep : 0.f;
 }
+// all the DropPath scales of a forward pass in one launch: row r (one residual branch of one block) drops with probs[r]
+__global__ void droppath_rows_kernel(float* scale, const float* probs, int rows, int B, uint64_t seed, uint32_t tag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * B) return;
+    const int r = i / B, b = i - r * B;
+    const float p = probs[r];
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    scale[i] = (p <= 0.f || rng_keep(seed, tag + (uint32_t)r, (uint32_t)b, thresh)) ? 1.0f / (1.0f - p) : 0.f;
+}
 
 // ------------------------------------------------------------------ column sums
 constexpr int COLSUM_ROWS = 128;   // partial rows
@@ -853,6 +862,12 @@ extern "C" int mvlt_droppath_scale(float* scale, int B, float p, uint64_t seed, 
     MVLT_CHECK(scale && B > 0 && p >= 0.f && p < 1.f, MVLT_ERR_ARG);
     hipLaunchKernelGGL(droppath_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, STREAM(stream), scale, B,
                        (uint32_t)((double)p * 4294967296.0), 1.0f / (1.0f - p), seed, tag);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+extern "C" int mvlt_droppath_scales(float* scale, const float* probs, int rows, int B, uint64_t seed, uint32_t tag, void* stream) {
+    MVLT_CHECK(scale && probs && rows > 0 && B > 0 && (long)rows * B < (1L << 30), MVLT_ERR_ARG);
+    hipLaunchKernelGGL(droppath_rows_kernel, dim3(ceil_div(rows * B, 256)), dim3(256), 0, STREAM(stream), scale, probs, rows, B, seed, tag);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }

@@ -550,7 +550,11 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
             itm_loss = _LinearCEFn.apply(_token(self.ITM_mlp, dev), pooled, self.ITM_mlp,
                                          image_text_label.reshape(-1).to(torch.int64).contiguous(),
                                          torch.is_grad_enabled())
-        return mlm_loss if itm_loss is None else mlm_loss.mean() + itm_loss.mean()
+        if itm_loss is None:
+            return mlm_loss
+        # model.py:419 takes .mean() of both: they are scalars already (a mean over ONE element is a reduction launch forward
+        # and a scaling launch backward each)
+        return (mlm_loss if mlm_loss.dim() == 0 else mlm_loss.mean()) + (itm_loss if itm_loss.dim() == 0 else itm_loss.mean())
 
 
 class MVLBertForVQA(MVLBertPretrainedModel):

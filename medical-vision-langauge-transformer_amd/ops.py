@@ -904,6 +904,15 @@ def droppath_scale(B, p, seed, tag, device):
     return s
 
 
+def droppath_scales(probs, B, seed, tag=0):
+    """probs: f32 [rows] on the device -> [rows, B] scales (1/(1-p) kept, 0 dropped), one launch for a whole forward pass."""
+    _need_cuda(probs)
+    assert probs.dtype == torch.float32 and probs.is_contiguous()
+    s = torch.empty((probs.numel(), B), dtype=torch.float32, device=probs.device)
+    L.check(L.lib().mvlt_droppath_scales(_p(s), _p(probs), probs.numel(), B, int(seed), int(tag), _stream()), "mvlt_droppath_scales")
+    return s
+
+
 # ----------------------------------------------------------------------------- loss / optimizer / decode
 def ce_fwd(logits, V, labels, rows_dev=None):
     """logits [rows, ld>=V]; returns (loss_sum, count, lse) device tensors (mean = sum/count).

@@ -27,7 +27,7 @@ from . import ops
 from . import _lib as L
 from .arena import Arena
 from .indexing import batched_window_maps, relative_position_index, shift_attn_mask
-from .runtime import backward_begin, compute_dtype_of
+from .runtime import backward_begin, compute_dtype_of, next_seed
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -255,8 +255,11 @@ class SwinTransformer(nn.Module):
             if probs is None or probs.device != img.device:
                 probs = torch.tensor([b.drop_path_prob for _, b in self._blocks() for _ in (0, 1)], device=img.device)
                 self.__dict__["_dp_probs"] = probs          # cached: a per-step H2D copy would stall the host
-            keep = (torch.rand(2 * nblk, B, device=img.device) >= probs[:, None]).float()
-            dp = (keep / (1.0 - probs[:, None])).contiguous()
+            if img.is_cuda:      # one launch (counter RNG, like the dropout masks) instead of rand / compare / cast / sub / div
+                dp = ops.droppath_scales(probs, B, next_seed(), 0x44500000)
+            else:
+                keep = (torch.rand(2 * nblk, B, device=img.device) >= probs[:, None]).float()
+                dp = (keep / (1.0 - probs[:, None])).contiguous()
             self.last_droppath = dp
         bi = 0
         for layer in self.layers:

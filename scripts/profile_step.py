@@ -46,6 +46,27 @@ for i in range(steps):
 t_host = (time.time() - t0) / steps
 torch.cuda.synchronize()
 print(f"host enqueue ms/step={t_host*1e3:.2f}", flush=True)
+if os.environ.get("STAMPS"):
+    # where the step's time goes on the main stream, un-traced: events around forward / backward / optimizer of the same loop as
+    # PretrainStep, the GPU held first so that the host is ahead (an event record costs ~5 us of stream time: 4 per step)
+    E = lambda: torch.cuda.Event(enable_timing=True)
+    ns = 6
+    ev = [[E() for _ in range(4)] for _ in range(ns)]
+    junk = torch.zeros(1 << 28, device="cuda")
+    for _ in range(200): junk.add_(1.0)
+    for i in range(ns):
+        ev[i][0].record()
+        loss = step.model(*batch[:4], text_lengths=batch[4]) if len(batch) > 4 else step.model(*batch)
+        ev[i][1].record()
+        loss.backward()
+        ev[i][2].record()
+        step.opt.step()
+        ev[i][3].record()
+    torch.cuda.synchronize()
+    for i in range(ns):
+        f, b, o = (ev[i][j].elapsed_time(ev[i][j + 1]) for j in range(3))
+        gap = ev[i][3].elapsed_time(ev[i + 1][0]) if i + 1 < ns else 0.0
+        print(f"step {i}: forward {f:.3f}  backward {b:.3f}  optimizer {o:.3f}  -> next step {gap:.3f} ms", flush=True)
 if os.environ.get("CPROF"):
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable()

@@ -15,7 +15,14 @@ ad = [e for s, e, q, k in rows if k.startswith('adamw')]
 per = max(1, round(len(ad) / (len(ad) // max(1, len(ad) // n)))) if ad else 1
 # adamw launches per step may be > 1: take the last launch of each step = the one followed by a non-adamw kernel
 cuts = [rows[i][1] for i in range(len(rows) - 1) if rows[i][3].startswith('adamw') and not rows[i + 1][3].startswith('adamw')]
-cuts = cuts[-(n + 1):] if len(cuts) > n else cuts
+# behind a hold (profile_step.py HOLD_MS=..): the host's lead shrinks under the tracer, so take the FIRST n steps after the hold
+hold_end = max([e for s, e, q, k in rows if 'OnSelf_add<float>' in k and e - s > 200_000] or [0])
+if hold_end:
+    first = [c for c in cuts if c > hold_end]
+    before = [c for c in cuts if c <= hold_end]
+    cuts = ([hold_end] + first)[: n + 1]
+else:
+    cuts = cuts[-(n + 1):] if len(cuts) > n else cuts
 t0, t1 = cuts[0], cuts[-1]; nst = len(cuts) - 1
 sel = [r for r in rows if r[0] >= t0 and r[1] <= t1 + 1]
 print(f"{nst} steps, {(t1 - t0) / 1e6 / nst:.3f} ms per step, {len(sel) / nst:.0f} launches per step")

@@ -859,6 +859,14 @@ def test_rows_transform_cast_unary(ops, dt):
     s = ops.droppath_scale(1000, 0.3, 11, 12, z.device)
     assert all(v == 0.0 or abs(v - 1 / 0.7) < 1e-6 for v in s.unique().tolist())
     assert 0.6 < (s > 0).float().mean().item() < 0.8
+    probs = torch.tensor([0.0, 0.1, 0.5, 0.3], device="cuda")
+    sc = ops.droppath_scales(probs, 4000, 21, 5)                     # every DropPath row of a forward pass in one launch
+    assert sc.shape == (4, 4000) and bool((sc[0] == 1.0).all())
+    for r, p in enumerate(probs.tolist()):
+        assert all(v == 0.0 or abs(v - 1 / (1 - p)) < 1e-6 for v in sc[r].unique().tolist())
+        assert abs((sc[r] > 0).float().mean().item() - (1 - p)) < 0.04
+    assert torch.equal(sc, ops.droppath_scales(probs, 4000, 21, 5)) and not torch.equal(sc, ops.droppath_scales(probs, 4000, 22, 5))
+    assert torch.equal(sc[3], ops.droppath_scale(4000, 0.3, 21, 5 + 3, probs.device))      # row r == the one-row form with tag + r
 
 
 @pytest.mark.parametrize("dt", DT)

@@ -665,7 +665,7 @@ def test_optimizer_overlapped_with_backward_equals_plain_step(M, specs, monkeypa
         load_formula(model, specs["tiny_pretrain"])
         model = M.set_compute_dtype(model.cuda().train(), F32)
         M.manual_seed(7)              # counter RNG of the dropout sites
-        torch.manual_seed(3)          # DropPath keep masks come from torch's generator (like timm's DropPath)
+        torch.manual_seed(3)          # (DropPath keep decisions come from the same counter RNG since round 4)
         init = {k: p.detach().clone() for k, p in model.named_parameters()}
         red = ddp.GradReducer(model, bucket_bytes=64 << 10) if ddp_sim else None
         step = PretrainStep(model, lr=1e-4, reducer=red, world_size=2 if ddp_sim else 1, overlap_optimizer=overlap)
@@ -826,7 +826,7 @@ def test_config2_step_is_bit_reproducible_except_the_atomic_accumulations(M, mon
 
     def run():
         M.manual_seed(777)          # counter RNG of the dropout masks
-        torch.manual_seed(778)      # DropPath keep decisions (swin.py draws them with torch.rand on the device)
+        torch.manual_seed(778)      # (DropPath keep decisions come from the same counter RNG since round 4)
         model.zero_grad(set_to_none=True)
         loss = model(*batch)
         loss.backward()
