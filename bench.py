@@ -251,11 +251,11 @@ def profiled_traffic(key):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (cannot be collected inside this
     process): profiles/r4_dominant_kernel_traffic.json {"family": {...}, "wgrad_group": {...}}, filled in from the
     scripts/pmc.py passes over scripts/profile_step.py (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)."""
-    f = os.path.join(ROOT, "profiles", "r3_dominant_kernel_traffic.json")
+    name = "profiles/r4_dominant_kernel_traffic.json"
     try:
-        with open(f) as fh:
+        with open(os.path.join(ROOT, name)) as fh:
             d = json.load(fh)
-        return d[key].get("traffic_bytes_per_launch"), "profiles/r4_dominant_kernel_traffic.json"
+        return d[key].get("traffic_bytes_per_launch"), name
     except Exception:
         return None, None
 
