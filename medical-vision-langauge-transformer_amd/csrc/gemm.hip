@@ -130,7 +130,7 @@ MVLT_DEV typename Mma<T>::Frag tile_frag(const T* lds, int row0, int kb) {
 }
 
 // one output tile (bx, by) of one k-split bz
-template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2, int DEEP = 0>
+template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2, int DEEP = 0, bool WIDE = false>
 MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const int bz, T* sA, T* sB) {
     using GA = TileGeom<T, BM, AK>;
     using GB = TileGeom<T, BN, BK_>;
@@ -309,7 +309,7 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
 
     // acc[i][j][r] <-> n = nb + 4*(lane>>4) + r, m = mb + (lane & 15)
     if (!p.atomic_out && p.split_k <= 1 && p.epi_vec && (p.N & 3) == 0) {
-        tile_epilogue<T, FM, FN>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);          // loads hoisted out of the store sequence
+        tile_epilogue<T, FM, FN, WIDE>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);          // loads hoisted out of the store sequence
         return;
     }
 #pragma unroll
@@ -362,7 +362,7 @@ MVLT_DEV void glds_fill(const bf16_t* const (&src)[R / 32], bf16_t* lds_tile, in
 // [64 k][BN] with the 32-byte units XOR-swizzled by kswz<BN>(k) (the layout tile_frag<T, BN, true> transposes out of with
 // ds_read_b64_tr_b16); one LDS-DMA instruction covers 1 KB = 8 (BN = 64) / 4 (BN = 128) k-rows, the swizzle again on the
 // source side.  With transposing reads in the loop the DMA is issued through inline asm (glds16_asm, gemm_dev.h).
-template <int BM, int BN, bool BKM>
+template <int BM, int BN, bool BKM, bool WIDE>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     using T = bf16_t;
     constexpr int BKE = 64, FM = BM / 32, FN = BN / 32;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
         }
     }
     if (p.split_k <= 1 && p.epi_vec && (p.N & 3) == 0) {
-        tile_epilogue<T, FM, FN>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);          // loads hoisted out of the store sequence
+        tile_epilogue<T, FM, FN, WIDE>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);          // loads hoisted out of the store sequence
     } else {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     asm volatile("" :: "v"(pfv));
 }
 
-template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2>
+template <typename T, int BM, int BN, bool AK, bool BK_, bool PF2, bool WIDE = false>
 __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     __shared__ __attribute__((aligned(16))) T sA[TileGeom<T, BM, AK>::ELEMS];
     __shared__ __attribute__((aligned(16))) T sB[TileGeom<T, BN, BK_>::ELEMS];
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     if (orig < gx * gy) {
         const int t = xcd_remap(orig, gx * gy);
         const int by = t / gx;
-        gemm_body<T, BM, BN, AK, BK_, PF2>(q, t - by * gx, by, blockIdx.z, sA, sB);
+        gemm_body<T, BM, BN, AK, BK_, PF2, 0, WIDE>(q, t - by * gx, by, blockIdx.z, sA, sB);
     }
     asm volatile("" :: "v"(pfv));
 }
@@ -724,6 +724,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDev p_in) 
 
 template <typename T, int BM, int BN, bool PF2>
 int launch_layout2(const GemmDev& d, bool ak, bool bk, dim3 grid, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {          // bf16 rows out, 16 bytes per lane (GemmDev.wide): forward / dgrad products only
+        if (d.wide && !ak) {
+            if (bk) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true, PF2, true>), grid, dim3(256), 0, s, d);
+            else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false, PF2, true>), grid, dim3(256), 0, s, d);
+            return 0;
+        }
+    }
     if (!ak && !bk) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false, PF2>), grid, dim3(256), 0, s, d);
     else if (!ak && bk) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true, PF2>), grid, dim3(256), 0, s, d);
     else if (ak && bk) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true, PF2>), grid, dim3(256), 0, s, d);
@@ -855,6 +862,7 @@ static int fill_dev(const MvltGemm* p, const Plan& pl, GemmDev& d) {
     if (epi & MVLT_EPI_SAVE_PRE) ev = ev && aligned16(p->pre);
     if (epi & MVLT_EPI_MUL_GELU_GRAD) ev = ev && aligned16(p->aux);
     d.epi_vec = ev;
+    d.wide = sizeof(T) == 2 && ev && !(epi & (MVLT_EPI_OUT_F32 | MVLT_EPI_ACCUM)) && p->N % 8 == 0 && p->ldc % 8 == 0 && pl.split <= 1;
     return MVLT_OK;
 }
 
@@ -894,18 +902,21 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
         const bool bkm_ok = !bk || ((pl.bn == 64 || pl.bn == 128) && p->N % 8 == 0 && p->N >= 8);
         if (glds_on && !ak && bkm_ok && p->K % 64 == 0 && kspan % 64 == 0 && d.a_vec && d.b_vec) {
             bool done = true;
+#define GLDS_GO(BM_, BN_, BKM_) do { if (d.wide) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, BKM_, true>), grid, dim3(256), 0, s, d); \
+                                     else hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, BKM_, false>), grid, dim3(256), 0, s, d); } while (0)
             if (bk) {
-                if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, true>), grid, dim3(256), 0, s, d);
-                else if (pl.bm == 64 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<64, 128, true>), grid, dim3(256), 0, s, d);
-                else if (pl.bm == 64 && pl.bn == 64) hipLaunchKernelGGL((gemm_glds_kernel<64, 64, true>), grid, dim3(256), 0, s, d);
+                if (pl.bm == 128 && pl.bn == 128) GLDS_GO(128, 128, true);
+                else if (pl.bm == 64 && pl.bn == 128) GLDS_GO(64, 128, true);
+                else if (pl.bm == 64 && pl.bn == 64) GLDS_GO(64, 64, true);
                 else done = false;
             }
-            else if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, false>), grid, dim3(256), 0, s, d);
-            else if (pl.bm == 128 && pl.bn == 96) hipLaunchKernelGGL((gemm_glds_kernel<128, 96, false>), grid, dim3(256), 0, s, d);
-            else if (pl.bm == 64 && pl.bn == 128) hipLaunchKernelGGL((gemm_glds_kernel<64, 128, false>), grid, dim3(256), 0, s, d);
-            else if (pl.bm == 64 && pl.bn == 96) hipLaunchKernelGGL((gemm_glds_kernel<64, 96, false>), grid, dim3(256), 0, s, d);
-            else if (pl.bm == 64 && pl.bn == 64) hipLaunchKernelGGL((gemm_glds_kernel<64, 64, false>), grid, dim3(256), 0, s, d);
+            else if (pl.bm == 128 && pl.bn == 128) GLDS_GO(128, 128, false);
+            else if (pl.bm == 128 && pl.bn == 96) GLDS_GO(128, 96, false);
+            else if (pl.bm == 64 && pl.bn == 128) GLDS_GO(64, 128, false);
+            else if (pl.bm == 64 && pl.bn == 96) GLDS_GO(64, 96, false);
+            else if (pl.bm == 64 && pl.bn == 64) GLDS_GO(64, 64, false);
             else done = false;
+#undef GLDS_GO
             if (done) {
                 MVLT_LAUNCH_CHECK();
                 if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);

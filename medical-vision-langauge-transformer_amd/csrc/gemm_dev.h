@@ -20,6 +20,7 @@ struct GemmDev {
     const int* m_dev;                    // optional: valid storage rows of A on the device (MvltGemm.m_dev)
     int atomic_out;                      // grouped weight gradients with in-launch split-K: f32 atomicAdd onto zeroed C
     int a_kmajor;                        // A is k-major (weight gradients): m_dev then limits the reduction, not the rows
+    int wide;                            // bf16 output rows whose 8-column chunks are 16-byte aligned: kernels built with WIDE stores
 };
 
 // Ragged batches planned on the GPU: the launch is sized for the upper bound, the kernel reads the real count.
@@ -124,7 +125,18 @@ template <> struct Raw4<float> { using type = f32x4; };
 MVLT_DEV f32x4 raw4_to_f(const bf16x4& v) { f32x4 r; r[0] = (float)v[0]; r[1] = (float)v[1]; r[2] = (float)v[2]; r[3] = (float)v[3]; return r; }
 MVLT_DEV f32x4 raw4_to_f(const f32x4& v) { return v; }
 
-template <typename T, int FM, int FN>
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// two fragments' four bf16 values of this lane -> the 16 bytes it stores after the exchange (see tile_epilogue)
+MVLT_DEV u32x4 pair16(const f32x4& a, const f32x4& b) {
+    union { bf16x4 h; unsigned u[2]; } pa, pb;
+    pa.h[0] = (bf16_t)a[0]; pa.h[1] = (bf16_t)a[1]; pa.h[2] = (bf16_t)a[2]; pa.h[3] = (bf16_t)a[3];
+    pb.h[0] = (bf16_t)b[0]; pb.h[1] = (bf16_t)b[1]; pb.h[2] = (bf16_t)b[2]; pb.h[3] = (bf16_t)b[3];
+    const auto x = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
+    const auto y = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
+    return u32x4{x[0], y[0], x[1], y[1]};
+}
+
+template <typename T, int FM, int FN, bool WIDE = false>
 MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base, f32x4 (&acc)[FM][FN]) {
     using R4 = typename Raw4<T>::type;
     const int lane = threadIdx.x & 63;
@@ -172,6 +184,10 @@ MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base
         if (has_map) asm volatile("" : "+v"(r.mo));
     };
     const bool rowloads = has_res || has_aux || has_map || has_scale;
+    // WIDE (chosen by the host, GemmDev.wide): bf16 output rows (and saved pre-activation rows) leave 16 bytes per lane.  A
+    // compile-time choice: with both store forms behind a run-time flag the 64 x 128 kernels lost more in their longer
+    // epilogue code than the wide stores won (30.7 vs 27.0 us on 2900 x 3072 x 768; 25.4 us with the choice compiled in)
+    constexpr bool wide = WIDE && sizeof(T) == 2;
     RowPre cur, nxt;
     if (rowloads) preload(0, nxt);
 #pragma unroll
@@ -182,14 +198,12 @@ MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base
             if (i + 1 < FM) preload(i + 1, nxt);          // next row block's loads go out before this one's stores
             pin(cur);
         } else { cur.mo = m; cur.sc = 1.0f; }
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
+        // value of fragment j after the fused epilogue (vp: before the GELU, for MVLT_EPI_SAVE_PRE)
+        auto value = [&](int j, f32x4& vp) -> f32x4 {
             const int n = n_base + j * 16 + nq;
-            const bool live = m < p.M && n < p.N;
             f32x4 v = acc[i][j] + bias_v[j];
-            const long co = (long)cur.mo * p.ldc + n;
+            vp = v;
             if (epi & MVLT_EPI_GELU) {
-                if ((epi & MVLT_EPI_SAVE_PRE) && live) store4f(reinterpret_cast<T*>(p.pre) + co, v);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
             }
@@ -208,6 +222,43 @@ MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base
                 for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(a[e]);
             }
             if (has_res) v += raw4_to_f(cur.res[j]);
+            return v;
+        };
+        const bool save_pre = (epi & MVLT_EPI_GELU) && (epi & MVLT_EPI_SAVE_PRE);
+        int j0 = 0;
+        if constexpr (sizeof(T) == 2) {
+            // bf16 rows: fragments j, j + 1 leave together, 16 bytes per lane (one store instruction instead of two: the tail
+            // of a wide-output product is bound by store ISSUE, 15-22 % of the launch, cdna_hip_programming.md T21).  A lane
+            // owns columns 4g .. 4g + 3 of both fragments (g = lane / 16); v_permlane16_swap trades fragment j of the odd
+            // groups for fragment j + 1 of the even ones, after which group g holds eight consecutive columns of ONE
+            // fragment: 16 (j + (g & 1)) + 8 (g >> 1) .. + 7.
+            if constexpr (wide) {
+                const int g = lane >> 4;
+#pragma unroll
+                for (; j0 + 1 < FN; j0 += 2) {
+                    const int n = n_base + (j0 + (g & 1)) * 16 + 8 * (g >> 1);
+                    const long co = (long)cur.mo * p.ldc + n;
+                    const bool live = m < p.M && n < p.N;
+                    f32x4 pa, pb;
+                    const f32x4 va = value(j0, pa), vb = value(j0 + 1, pb);
+                    if (save_pre) {
+                        const u32x4 w = pair16(pa, pb);
+                        if (live) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.pre) + co) = w;
+                    }
+                    const u32x4 w = pair16(va, vb);
+                    if (live) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + co) = w;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            if (j < j0) continue;
+            const int n = n_base + j * 16 + nq;
+            const bool live = m < p.M && n < p.N;
+            const long co = (long)cur.mo * p.ldc + n;
+            f32x4 vp;
+            f32x4 v = value(j, vp);
+            if (save_pre && live) store4f(reinterpret_cast<T*>(p.pre) + co, vp);
             if (live) {
                 if (epi & MVLT_EPI_OUT_F32) {
                     float* o = reinterpret_cast<float*>(p.C) + co;
