@@ -309,7 +309,8 @@ MVLT_DEV void gemm_body(const GemmDev& p_in, const int bx, const int by, const i
 
     // acc[i][j][r] <-> n = nb + 4*(lane>>4) + r, m = mb + (lane & 15)
     if (!p.atomic_out && p.split_k <= 1 && p.epi_vec && (p.N & 3) == 0) {
-        tile_epilogue<T, FM, FN, WIDE>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);          // loads hoisted out of the store sequence
+        if constexpr (WIDE && sizeof(T) == 2 && FN % 2 == 0) tile_epilogue_wide<T, FM, FN>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);
+        else tile_epilogue<T, FM, FN>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);          // loads hoisted out of the store sequence
         return;
     }
 #pragma unroll
@@ -443,7 +444,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
         }
     }
     if (p.split_k <= 1 && p.epi_vec && (p.N & 3) == 0) {
-        tile_epilogue<T, FM, FN, WIDE>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);          // loads hoisted out of the store sequence
+        if constexpr (WIDE && sizeof(T) == 2 && FN % 2 == 0) tile_epilogue_wide<T, FM, FN>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);
+        else tile_epilogue<T, FM, FN>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);          // loads hoisted out of the store sequence
     } else {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -862,7 +864,10 @@ static int fill_dev(const MvltGemm* p, const Plan& pl, GemmDev& d) {
     if (epi & MVLT_EPI_SAVE_PRE) ev = ev && aligned16(p->pre);
     if (epi & MVLT_EPI_MUL_GELU_GRAD) ev = ev && aligned16(p->aux);
     d.epi_vec = ev;
-    d.wide = sizeof(T) == 2 && ev && !(epi & (MVLT_EPI_OUT_F32 | MVLT_EPI_ACCUM)) && p->N % 8 == 0 && p->ldc % 8 == 0 && pl.split <= 1;
+    // 16-byte row operands (tile_epilogue_wide): bf16 rows out, every row operand in 8-column chunks that are 16-byte aligned;
+    // tiles of 64 / 128 columns only (fragment PAIRS)
+    d.wide = sizeof(T) == 2 && ev && !(epi & (MVLT_EPI_OUT_F32 | MVLT_EPI_ACCUM)) && p->N % 8 == 0 && p->ldc % 8 == 0 && pl.split <= 1 &&
+             pl.bn != 96 && (!(epi & MVLT_EPI_RESIDUAL) || p->ldr % 8 == 0) && (!(epi & MVLT_EPI_BIAS) || aligned16(p->bias));
     return MVLT_OK;
 }
 

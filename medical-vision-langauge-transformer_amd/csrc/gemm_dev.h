@@ -20,7 +20,7 @@ struct GemmDev {
     const int* m_dev;                    // optional: valid storage rows of A on the device (MvltGemm.m_dev)
     int atomic_out;                      // grouped weight gradients with in-launch split-K: f32 atomicAdd onto zeroed C
     int a_kmajor;                        // A is k-major (weight gradients): m_dev then limits the reduction, not the rows
-    int wide;                            // bf16 output rows whose 8-column chunks are 16-byte aligned: kernels built with WIDE stores
+    int wide;                            // bf16 rows out with 16-byte aligned 8-column chunks (and operands): kernels built with WIDE
 };
 
 // Ragged batches planned on the GPU: the launch is sized for the upper bound, the kernel reads the real count.
@@ -125,18 +125,7 @@ template <> struct Raw4<float> { using type = f32x4; };
 MVLT_DEV f32x4 raw4_to_f(const bf16x4& v) { f32x4 r; r[0] = (float)v[0]; r[1] = (float)v[1]; r[2] = (float)v[2]; r[3] = (float)v[3]; return r; }
 MVLT_DEV f32x4 raw4_to_f(const f32x4& v) { return v; }
 
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-// two fragments' four bf16 values of this lane -> the 16 bytes it stores after the exchange (see tile_epilogue)
-MVLT_DEV u32x4 pair16(const f32x4& a, const f32x4& b) {
-    union { bf16x4 h; unsigned u[2]; } pa, pb;
-    pa.h[0] = (bf16_t)a[0]; pa.h[1] = (bf16_t)a[1]; pa.h[2] = (bf16_t)a[2]; pa.h[3] = (bf16_t)a[3];
-    pb.h[0] = (bf16_t)b[0]; pb.h[1] = (bf16_t)b[1]; pb.h[2] = (bf16_t)b[2]; pb.h[3] = (bf16_t)b[3];
-    const auto x = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
-    const auto y = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
-    return u32x4{x[0], y[0], x[1], y[1]};
-}
-
-template <typename T, int FM, int FN, bool WIDE = false>
+template <typename T, int FM, int FN>
 MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base, f32x4 (&acc)[FM][FN]) {
     using R4 = typename Raw4<T>::type;
     const int lane = threadIdx.x & 63;
@@ -184,10 +173,6 @@ MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base
         if (has_map) asm volatile("" : "+v"(r.mo));
     };
     const bool rowloads = has_res || has_aux || has_map || has_scale;
-    // WIDE (chosen by the host, GemmDev.wide): bf16 output rows (and saved pre-activation rows) leave 16 bytes per lane.  A
-    // compile-time choice: with both store forms behind a run-time flag the 64 x 128 kernels lost more in their longer
-    // epilogue code than the wide stores won (30.7 vs 27.0 us on 2900 x 3072 x 768; 25.4 us with the choice compiled in)
-    constexpr bool wide = WIDE && sizeof(T) == 2;
     RowPre cur, nxt;
     if (rowloads) preload(0, nxt);
 #pragma unroll
@@ -198,12 +183,14 @@ MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base
             if (i + 1 < FM) preload(i + 1, nxt);          // next row block's loads go out before this one's stores
             pin(cur);
         } else { cur.mo = m; cur.sc = 1.0f; }
-        // value of fragment j after the fused epilogue (vp: before the GELU, for MVLT_EPI_SAVE_PRE)
-        auto value = [&](int j, f32x4& vp) -> f32x4 {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
             const int n = n_base + j * 16 + nq;
+            const bool live = m < p.M && n < p.N;
             f32x4 v = acc[i][j] + bias_v[j];
-            vp = v;
+            const long co = (long)cur.mo * p.ldc + n;
             if (epi & MVLT_EPI_GELU) {
+                if ((epi & MVLT_EPI_SAVE_PRE) && live) store4f(reinterpret_cast<T*>(p.pre) + co, v);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
             }
@@ -222,43 +209,6 @@ MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base
                 for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(a[e]);
             }
             if (has_res) v += raw4_to_f(cur.res[j]);
-            return v;
-        };
-        const bool save_pre = (epi & MVLT_EPI_GELU) && (epi & MVLT_EPI_SAVE_PRE);
-        int j0 = 0;
-        if constexpr (sizeof(T) == 2) {
-            // bf16 rows: fragments j, j + 1 leave together, 16 bytes per lane (one store instruction instead of two: the tail
-            // of a wide-output product is bound by store ISSUE, 15-22 % of the launch, cdna_hip_programming.md T21).  A lane
-            // owns columns 4g .. 4g + 3 of both fragments (g = lane / 16); v_permlane16_swap trades fragment j of the odd
-            // groups for fragment j + 1 of the even ones, after which group g holds eight consecutive columns of ONE
-            // fragment: 16 (j + (g & 1)) + 8 (g >> 1) .. + 7.
-            if constexpr (wide) {
-                const int g = lane >> 4;
-#pragma unroll
-                for (; j0 + 1 < FN; j0 += 2) {
-                    const int n = n_base + (j0 + (g & 1)) * 16 + 8 * (g >> 1);
-                    const long co = (long)cur.mo * p.ldc + n;
-                    const bool live = m < p.M && n < p.N;
-                    f32x4 pa, pb;
-                    const f32x4 va = value(j0, pa), vb = value(j0 + 1, pb);
-                    if (save_pre) {
-                        const u32x4 w = pair16(pa, pb);
-                        if (live) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.pre) + co) = w;
-                    }
-                    const u32x4 w = pair16(va, vb);
-                    if (live) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + co) = w;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            if (j < j0) continue;
-            const int n = n_base + j * 16 + nq;
-            const bool live = m < p.M && n < p.N;
-            const long co = (long)cur.mo * p.ldc + n;
-            f32x4 vp;
-            f32x4 v = value(j, vp);
-            if (save_pre && live) store4f(reinterpret_cast<T*>(p.pre) + co, vp);
             if (live) {
                 if (epi & MVLT_EPI_OUT_F32) {
                     float* o = reinterpret_cast<float*>(p.C) + co;
@@ -270,6 +220,140 @@ MVLT_DEV void tile_epilogue(const GemmDev& p, const int m_base, const int n_base
                     store4f(o, v);
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same epilogue with 16 bytes per lane on every row operand (bf16 output, saved pre-activation, residual, gelu' operand):
+// the tail of a wide-output product is bound by the ISSUE of its row loads / stores, not by their bytes (8-byte stores:
+// 15-22 % of the launch; cdna_hip_programming.md T21).  A lane of a 16 x 16 accumulator fragment owns columns 4g .. 4g + 3
+// of one row (g = lane / 16).  For a PAIR of fragments (j, j + 1) v_permlane16_swap trades fragment j of the odd lane groups
+// for fragment j + 1 of the even ones; afterwards group g holds EIGHT consecutive columns of one fragment,
+//     16 (j + (g & 1)) + 8 (g >> 1) .. + 7      (first register quartet: the lower four, second: the upper four),
+// and everything behind it -- bias, GELU, dropout index, row scale, gelu' operand, residual, stores -- runs in that layout.
+// Chosen by the host per launch (GemmDev.wide) as a compile-time variant of the kernels: with both forms behind a run-time
+// flag the 64 x 128 kernels lost more in their longer epilogue code than the stores won (30.7 vs 27.0 us on 2900 x 3072 x
+// 768; 25.4 us with the choice compiled in).  Same arithmetic, same order as tile_epilogue.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+MVLT_DEV void swap16(f32x4& a, f32x4& b) {
+    // inline asm: fed vector elements, hipcc (ROCm 7.2) miscompiles __builtin_amdgcn_permlane16_swap (one dword loaded, the result
+    // splat over the vector).  s_nop 1 = the two wait states between a VALU write of an operand and the swap's read.
+    float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5\n\t"
+                 "v_permlane16_swap_b32 %6, %7"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3));
+    a = f32x4{a0, a1, a2, a3}; b = f32x4{b0, b1, b2, b3};
+}
+MVLT_DEV void unpack8(const u32x4& w, f32x4& lo, f32x4& hi) {
+    const bf16x8 h = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lo[e] = (float)h[e]; hi[e] = (float)h[4 + e]; }
+}
+MVLT_DEV u32x4 pack8(const f32x4& lo, const f32x4& hi) {
+    bf16x8 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = (bf16_t)lo[e]; h[4 + e] = (bf16_t)hi[e]; }
+    return __builtin_bit_cast(u32x4, h);
+}
+
+template <typename T, int FM, int FN>
+MVLT_DEV void tile_epilogue_wide(const GemmDev& p, const int m_base, const int n_base, f32x4 (&acc)[FM][FN]) {
+    static_assert(sizeof(T) == 2 && FN % 2 == 0, "bf16 rows, fragment pairs");
+    constexpr int NP = FN / 2;
+    const int lane = threadIdx.x & 63;
+    const int mr = lane & 15, g = lane >> 4;
+    const int cofs = 16 * (g & 1) + 8 * (g >> 1);          // this lane's chunk inside the 32 columns of a fragment pair
+    const int epi = p.epi;
+    const bool has_bias = (epi & MVLT_EPI_BIAS) != 0, has_res = (epi & MVLT_EPI_RESIDUAL) != 0,
+               has_aux = (epi & MVLT_EPI_MUL_GELU_GRAD) != 0, has_map = (epi & MVLT_EPI_ROWMAP) != 0,
+               has_scale = (epi & MVLT_EPI_ROWSCALE) != 0;
+    f32x4 bias_lo[NP], bias_hi[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { bias_lo[q] = f32x4{0.f, 0.f, 0.f, 0.f}; bias_hi[q] = bias_lo[q]; }
+    if (has_bias) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const float* b = p.bias + min(n_base + 32 * q + cofs, p.N - 8);
+            bias_lo[q] = *reinterpret_cast<const f32x4*>(b); bias_hi[q] = *reinterpret_cast<const f32x4*>(b + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { asm volatile("" : "+v"(bias_lo[q])); asm volatile("" : "+v"(bias_hi[q])); }
+    }
+    struct RowPre { int mo; float sc; u32x4 res[NP]; u32x4 aux[NP]; };
+    auto preload = [&](int i, RowPre& r) {
+        const int m = min(m_base + i * 16 + mr, p.M - 1);
+        r.mo = m; r.sc = 1.0f;
+        if (has_map) r.mo = p.rowmap[m];
+        if (has_scale) r.sc = p.rowscale[r.mo / p.rps];
+        if (has_res) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                r.res[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.residual) + (long)r.mo * p.ldr + min(n_base + 32 * q + cofs, p.N - 8));
+        }
+        if (has_aux) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                r.aux[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (long)r.mo * p.ldc + min(n_base + 32 * q + cofs, p.N - 8));
+        }
+    };
+    auto pin = [&](RowPre& r) {
+        if (has_res) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(r.res[q]));
+        }
+        if (has_aux) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(r.aux[q]));
+        }
+        if (has_scale) asm volatile("" : "+v"(r.sc));
+        if (has_map) asm volatile("" : "+v"(r.mo));
+    };
+    const bool rowloads = has_res || has_aux || has_map || has_scale;
+    RowPre cur, nxt;
+    if (rowloads) preload(0, nxt);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m_base + i * 16 + mr;
+        if (rowloads) {
+            cur = nxt;
+            if (i + 1 < FM) preload(i + 1, nxt);          // next row block's loads go out before this one's stores
+            pin(cur);
+        } else { cur.mo = m; cur.sc = 1.0f; }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int n = n_base + 32 * q + cofs;
+            const bool live = m < p.M && n < p.N;           // (N % 8 == 0: a chunk is inside or outside as a whole)
+            f32x4 lo = acc[i][2 * q], hi = acc[i][2 * q + 1];
+            swap16(lo, hi);
+            lo += bias_lo[q]; hi += bias_hi[q];
+            const long co = (long)cur.mo * p.ldc + n;
+            if (epi & MVLT_EPI_GELU) {
+                if ((epi & MVLT_EPI_SAVE_PRE) && live) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.pre) + co) = pack8(lo, hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] = gelu_f(lo[e]); hi[e] = gelu_f(hi[e]); }
+            }
+            if (epi & MVLT_EPI_DROPOUT) {
+                const uint32_t base = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = rng_keep(p.seed, p.tag, base + e, p.drop_thresh) ? lo[e] * p.drop_scale : 0.0f;
+                    hi[e] = rng_keep(p.seed, p.tag, base + 4 + e, p.drop_thresh) ? hi[e] * p.drop_scale : 0.0f;
+                }
+            }
+            if (has_scale) { lo *= cur.sc; hi *= cur.sc; }
+            if (has_aux) {
+                f32x4 alo, ahi;
+                unpack8(cur.aux[q], alo, ahi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] *= gelu_grad_f(alo[e]); hi[e] *= gelu_grad_f(ahi[e]); }
+            }
+            if (has_res) {
+                f32x4 rlo, rhi;
+                unpack8(cur.res[q], rlo, rhi);
+                lo += rlo; hi += rhi;
+            }
+            if (live) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + co) = pack8(lo, hi);
         }
     }
 }
