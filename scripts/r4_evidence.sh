@@ -1,0 +1,22 @@
+#!/bin/bash
+# Final evidence of round 4 on one box: counter passes over the step's GEMM kernels (family traffic / MFMA busy), the traced bench
+# with its kernel summary and the live-vs-trace check, the per-step kernel table and timeline, then the un-profiled bench line.
+set -e
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ev; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+python3 $R/scripts/pmc.py --out $O/pmc --match gemm --passes sq1,fetch,write \
+  --family "family=gemm_kernel|gemm_glds_kernel|gemm8_kernelILi.ELi.ELb0|gemm8_kernel<., ., false" --family "wgrad_group=gemm_group_kernel" \
+  --json $O/r4_dominant_kernel_traffic.json -- python3 $R/bench.py --no-extra --no-cpu-baseline --steps 4 --warmup 2 > $O/r4_step_gemm_pmc.txt 2>$O/pmc.err
+echo pmc done
+rocprofv3 --kernel-trace --stats -d $O/trace -o b --output-format csv -- python3 $R/bench.py --no-extra --no-cpu-baseline --steps 30 --warmup 10 > $O/traced_bench.json 2>$O/trace.err
+echo trace done
+cd $R
+python scripts/roofline_vs_trace.py $(find $O/trace -name "*kernel_trace.csv" | head -1) $O/traced_bench.json 10 30 > $O/r4_roofline_vs_trace.txt 2>&1 || true
+cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/r4_bench_kernel_stats.csv
+cd /tmp
+PACK=0 MLM_CAP=0 STEPS=10 WARM=5 rocprofv3 --kernel-trace -d $O/step -o s --output-format csv -- python3 $R/scripts/profile_step.py > $O/step.log 2>&1
+cd $R
+python scripts/step_kernels.py $O/step 10 60 > $O/r4_step_kernels.txt
+PACK=0 MLM_CAP=0 STAMPS=1 STEPS=3 WARM=10 python scripts/profile_step.py 2>&1 | grep -v "^[WE]2026\|amdgpu.ids" > $O/r4_step_phases.txt
+python bench.py > $O/r4_bench.json 2> $O/bench.err
+tail -c 400 $O/r4_bench.json
