@@ -8,7 +8,7 @@
 #include <cstdlib>
 
 namespace {
-constexpr int LN_PARTS_STRIDE = 256;   // == LN_BWD_PARTS: row stride between the dgamma and dbeta partial blocks
+constexpr int LN_PARTS_STRIDE = 512;   // == LN_BWD_PARTS: row stride between the dgamma and dbeta partial blocks
 
 struct LnDev {
     int rows, C; float eps;
@@ -329,14 +329,17 @@ __global__ __launch_bounds__(256) void ln_acc_fwd_kernel(float* acc, const float
     }
 }
 
-constexpr int LN_BWD_PARTS = 256;
-constexpr int LN_BWD_WAVES = 16;
+constexpr int LN_BWD_PARTS = 512;
 static int ln_bwd_waves(int C) {
-    int nw = 16;                                   // per-wave partial rows: nw * 2 * C floats of LDS, keep <= 64 KB
+    int nw = 8;                                    // per-wave partial rows: nw * 2 * C floats of LDS, keep <= 64 KB
     while (nw > 1 && (size_t)nw * 2 * C * sizeof(float) > 64 * 1024) nw >>= 1;
     return nw;
 }
-static int ln_bwd_parts() { return LN_BWD_PARTS; }     // 1024-thread blocks: 16 waves per CU hide the load latency, still 256 partial rows
+// Block size of the backward kernel: 8 waves and up to 512 blocks (= partial parameter-gradient rows).  Stand-alone the 16-wave /
+// 256-block form is as fast; inside the step the backward runs beside the weight-gradient groups, whose workgroups hold most of
+// a CU's registers and LDS, and a 1024-thread block with 49 KB of LDS waits for ALL of that to come free on one CU at once:
+// 12.19 ms per step with 16 waves / 256 blocks, 11.86 with 8 / 512, 11.91 with 4 / 1024 (same box, interleaved).
+static int ln_bwd_parts() { return LN_BWD_PARTS; }
 
 // lanes per row of the instantiation dispatch() picks for a width (the ONE place that decides it: the number of partial
 // parameter-gradient rows a backward launch writes follows from it)
