@@ -181,8 +181,11 @@ def test_gemm8_automatic_mode_takes_only_big_products(ops, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", DT)
-def test_gemm_epilogues(ops, dt):
-    M, N, K = 300, 192, 96
+@pytest.mark.parametrize("M,N,K", [(300, 192, 96),         # 96-wide tiles: 8 bytes per lane (tile_epilogue)
+                                   (300, 256, 96),         # bf16: 64-wide tiles, one fragment pair per wave (tile_epilogue_wide)
+                                   (4100, 1024, 96),       # bf16: 64 x 128 tiles, two pairs, a ragged last row tile
+                                   (300, 252, 96)])        # N % 8 != 0: back to the 8-byte form on 128-wide tiles
+def test_gemm_epilogues(ops, dt, M, N, K):
     A, W = rnd((M, K), dt, 5), rnd((N, K), dt, 6, 0.2)
     bias = rnd((N,), torch.float32, 7)
     res = rnd((M, N), dt, 8)
@@ -193,7 +196,7 @@ def test_gemm_epilogues(ops, dt):
     assert rel(pre, base) < tol(dt) and rel(out, F.gelu(base)) < tol(dt)
     # bias + rowscale + residual with output row scatter (Swin proj)
     perm = torch.randperm(M, generator=torch.Generator().manual_seed(1)).int().cuda()
-    rs = torch.tensor([0.0, 1.25, 1.25], device="cuda")
+    rs = torch.tensor([0.0, 1.25, 1.25] * (M // 300 + 1), device="cuda")[: (M + 99) // 100]
     out = ops.gemm(A, W, bias=bias, rowscale=(rs, 100), residual=res, rowmap=perm)
     exp = res.float().clone()
     sc = rs[(perm.long() // 100)]
