@@ -338,7 +338,7 @@ def layernorm_acc_fwd(acc, bias, residual, gamma, beta, eps, dtype, out=None):
     return y
 
 
-_GROUP_LONG_K = int(os.environ.get("MVLT_GROUP_LONG_K", "8192"))
+_GROUP_LONG_K = 8192
 # MVLT_DETERMINISTIC=1: no float-atomic k-slices in the GEMM path (the 4-wave fallback of the Swin stage-0/1 weight
 # gradients takes split-K slabs + the deterministic reduce; greedy decoding does not split its reductions).  Still
 # accumulated with float atomics under the flag: the relative-position-bias-table gradient (swin_attn_bwd2_kernel) and the
