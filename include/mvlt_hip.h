@@ -36,7 +36,7 @@ enum { MVLT_OK = 0, MVLT_ERR_ARG = -1, MVLT_ERR_LAUNCH = -2, MVLT_ERR_UNSUPPORTE
  * signature; a binding compiles / hard-codes the value it was written against and compares it with what the
  * loaded library returns.  mvlt_sizeof(MVLT_STRUCT_*) lets a binding that mirrors the structs by hand (ctypes,
  * cgo, JNI) prove that its mirror has the size the library was compiled with (0 for an unknown id). */
-#define MVLT_ABI_VERSION 5
+#define MVLT_ABI_VERSION 6
 int mvlt_version(void);            /* MVLT_ABI_VERSION of the loaded library */
 const char* mvlt_arch(void);       /* "gfx950" */
 enum { MVLT_STRUCT_GEMM = 0, MVLT_STRUCT_LAYERNORM = 1, MVLT_STRUCT_LAYERNORM_BWD = 2, MVLT_STRUCT_LN_REDUCE_ITEM = 3,
@@ -278,12 +278,22 @@ int mvlt_swin_wmsa_bwd_supported(int dtype, int C, int nH);
  * projection -- still ONE launch, and 256 workgroups at stage 2 of a B = 32 step where the first design has 128.
  * Same MvltSwinWmsa fields as mvlt_swin_wmsa_fwd (head_split ignored) with two differences: attn_out is REQUIRED (it is
  * the exchange buffer; eval callers pass scratch), and sync_ws is an int32 workspace of mvlt_swin_wmsa2_sync_words(B, res)
- * words that the caller zeroes ONCE when it allocates it: the kernel leaves it zeroed; the last word is a sticky error
- * flag (a bounded wait ran out: never expected).  One launch at a time per sync_ws (launches on one stream are fine).
+ * words that the caller zeroes ONCE when it allocates it: every launch leaves its counters zeroed.  Layout (independent
+ * of B, so one workspace serves every launch of a stream): word 0 = STICKY ERROR COUNT, words 1..15 unused, then
+ * {arrivals, readers done} per window pair.  One workspace per stream (launches that may overlap must not share counters).
+ * Failure mode: the groups of a window pair wait for each other inside the launch, which needs them co-resident (the
+ * launch is persistent with at most one workgroup per CU, grid <= #CUs and a multiple of the group count).  A wait is
+ * bounded (2 s by default, mvlt_swin_wmsa2_set_timeout_ms); when it runs out the kernel adds 1 to word 0 AND writes NaN
+ * into that unit's rows of y, so the failure reaches the loss even when nobody reads the word.  Callers read word 0 where
+ * they synchronise anyway (PretrainStep does, one step late, without a sync) and raise.
  * Replaces visual_feature_extractor.py:224-254, 356-384 exactly like mvlt_swin_wmsa_fwd. */
 int mvlt_swin_wmsa2_supported(int dtype, int B, int res, int C, int nH);
 int mvlt_swin_wmsa2_sync_words(int B, int res);
 int mvlt_swin_wmsa2_fwd(const MvltSwinWmsa* p, int32_t* sync_ws, void* stream);
+int mvlt_swin_wmsa2_set_timeout_ms(int ms);    /* bound of the hand-off wait, process-wide; 0 restores the default (2000) */
+/* Diagnostic: `blocks` workgroups of 256 threads, each holding lds_bytes of LDS, spin for `usec` microseconds (100 MHz
+ * real-time clock) and exit.  The tests use it to take CUs away from a launch that needs its workgroups co-resident. */
+int mvlt_debug_hold_cus(int blocks, int lds_bytes, int usec, void* stream);
 
 /* ------------------------------------------------------------------ data movement / embeddings
  * PatchEmbed im2col (visual_feature_extractor.py:562): img f32 NCHW [B,3,S,S]
@@ -332,7 +342,10 @@ int mvlt_label_plan(const int64_t* labels, const int64_t* text_row, int N, int32
 int mvlt_rows_scatter(int dtype, const void* in, void* out, int rows, int C, const int32_t* rowmap,
                       const int32_t* count, void* stream);
 int mvlt_embed_fwd(const MvltEmbed* p, void* stream);
-int mvlt_embed_bwd(const MvltEmbed* p, void* stream);  /* dword/dpos/dtype_emb are ACCUMULATED (zero them first) */
+/* backward: ONLY dword is accumulated (float atomics over the batch's token ids, the [CLS] / [SEP] rows included): zero it
+ * first.  dpos / dtype_emb are OVERWRITTEN with ordered batch sums -- a second call does not add to the first -- and rows
+ * outside the range in use are zeroed only when pos_rows / type_rows are given (see the struct). */
+int mvlt_embed_bwd(const MvltEmbed* p, void* stream);
 
 /* out[i,:] = scale[i_src / rows_per_scale] * mask(in[src,:]) where src = rowmap ? rowmap[i] : i;
  * dropout mask (p>0) indexed by src*C + c.  Used for DropPath / dropout backward

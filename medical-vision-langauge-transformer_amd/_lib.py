@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmvlt_hip.so")
 
 F32, BF16 = 0, 1
 OK = 0
-ABI_VERSION = 5          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
+ABI_VERSION = 6          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
 ERRORS = {-1: "MVLT_ERR_ARG", -2: "MVLT_ERR_LAUNCH", -3: "MVLT_ERR_UNSUPPORTED"}
 
 EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_DROPOUT = 1, 2, 4, 8
@@ -139,6 +139,8 @@ SYMBOLS = {
     "mvlt_swin_wmsa2_supported": (i32, [i32, i32, i32, i32, i32]),
     "mvlt_swin_wmsa2_sync_words": (i32, [i32, i32]),
     "mvlt_swin_wmsa2_fwd": (i32, [C.POINTER(MvltSwinWmsa), vp, vp]),
+    "mvlt_swin_wmsa2_set_timeout_ms": (i32, [i32]),
+    "mvlt_debug_hold_cus": (i32, [i32, i32, i32, vp]),
     "mvlt_im2col_patch": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "mvlt_pack_plan": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "mvlt_label_plan": (i32, [vp, vp, i32, vp, vp, vp, vp]),

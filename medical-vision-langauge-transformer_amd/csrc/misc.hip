@@ -1024,3 +1024,26 @@ extern "C" int mvlt_zero_batch(const MvltZeroItem* items, int n, void* stream) {
     }
     return MVLT_OK;
 }
+
+// Diagnostic (tests only): workgroups that occupy CUs -- each holds `lds_bytes` of LDS and spins on the 100 MHz real-time
+// clock for `usec` microseconds.  Every wave reaches the exit condition by itself (a clock bound, no inter-block waiting).
+namespace {
+__global__ __launch_bounds__(256) void hold_cus_kernel(long long ticks, int lds_bytes, unsigned* never) {
+    extern __shared__ __attribute__((aligned(16))) char hold_smem[];
+    if (lds_bytes >= 4) reinterpret_cast<volatile int*>(hold_smem)[threadIdx.x % (lds_bytes / 4)] = (int)threadIdx.x;
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (lds_bytes >= 4 && reinterpret_cast<volatile int*>(hold_smem)[0] == 0x7fffffff && never) *never = 1;
+}
+}  // namespace
+
+extern "C" int mvlt_debug_hold_cus(int blocks, int lds_bytes, int usec, void* stream) {
+    MVLT_CHECK(blocks >= 1 && blocks <= 4096 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && usec >= 0 && usec <= 5000000, MVLT_ERR_ARG);
+    auto k = hold_cus_kernel;
+    if (lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return MVLT_ERR_LAUNCH;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), (size_t)lds_bytes, STREAM(stream), (long long)usec * 100, lds_bytes, (unsigned*)nullptr);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}

@@ -16,7 +16,8 @@
 //     of proj + bias + DropPath + shortcut.  Nothing depends on dispatch order or XCD placement; what the wait needs is
 //     that the groups of a set are co-resident: the launch is persistent with at most one workgroup per CU
 //     (grid <= 256, a multiple of the group count; LDS use forces one per CU), units dealt round-robin, so the groups
-//     of a set are always in flight together.  Spins are bounded (error word in the sync workspace).
+//     of a set are always in flight together.  Spins are bounded: when one runs out the unit's rows of y become NaN and
+//     the sticky error count (word 0 of the sync workspace) is raised -- a failure is loud, never silent.
 //   * counters clean up after themselves (the last group to finish READING resets them), so no memset per launch.
 //
 // Phases of a unit (8 waves):
@@ -32,6 +33,7 @@
 #include "common.h"
 #include "attn_frag.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 using namespace mvlt_attn;
@@ -46,8 +48,17 @@ struct Wmsa2Dev {
     const float* bias_table; float scale;
     const float* rowscale;
     T* xn; T* ao; T* qkv; float* lse; float* mean; float* rstd;
-    int* sync;               // [nsets] arrivals, [nsets] readers done, [1] error word
+    int* sync;               // hand-off workspace (layout below)
+    long long spin_ticks;    // bound of the hand-off wait in ticks of the 100 MHz real-time clock
 };
+
+// Hand-off workspace (int32 words).  The layout does not depend on the batch size, so one workspace serves every launch of a
+// stream: word 0 = sticky error count (bounded waits that ran out since the words were last cleared), words 1..15 unused,
+// then per window set {arrivals, readers done}; both counters are back at 0 when a launch has finished.
+#define W2_SYNC_ERROR 0
+#define W2_SYNC_ARRIVE(set) (16 + 2 * (set))
+#define W2_SYNC_DONE(set) (17 + 2 * (set))
+#define W2_TBL_FLAG 175      // pad entry of the LDS bias table (indices 170..175 are never addressed)
 
 template <int C, int W, int G, int GS> struct W2Geom {
     static constexpr int M = 49 * W, MT = (M + 15) / 16, MR = MT * 16;
@@ -692,6 +703,7 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
 
         const char* atile;                                 // A operand of the projection: [MR][C]
         int done_ticket = -1;
+        bool poison = false;                               // the hand-off wait of this unit ran out
         if constexpr (NHG > 1) {
             // ---- this group's [M, OC] slice -> attn_out, write-through
             {
@@ -722,18 +734,24 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                 }
             }
             if (tid == 0) {
-                __hip_atomic_fetch_add(p.sync + set, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // wait for the other groups of the set (bounded: ~2 s, then the error word is set and the result is garbage)
-                const long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
-                while (__hip_atomic_load(p.sync + set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NHG) {
+                __hip_atomic_fetch_add(p.sync + W2_SYNC_ARRIVE(set), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // wait for the other groups of the set.  Bounded (p.spin_ticks of the 100 MHz clock, ~2 s by default): when it
+                // runs out the sticky error word (word 0 of the workspace, whatever the batch size) is set and this unit's rows
+                // of y are written as NaN, so a caller that never reads the word still sees a poisoned loss
+                const long long t0 = __builtin_amdgcn_s_memrealtime();
+                float bad = 0.0f;
+                while (__hip_atomic_load(p.sync + W2_SYNC_ARRIVE(set), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NHG) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000LL) {
-                        __hip_atomic_store(p.sync + 2 * nsets, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > p.spin_ticks) {
+                        __hip_atomic_fetch_add(p.sync + W2_SYNC_ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        bad = 1.0f;
                         break;
                     }
                 }
+                tbl[W2_TBL_FLAG] = bad;                    // (a pad entry of the bias table: rewritten with the table per unit)
             }
             __syncthreads();
+            poison = tbl[W2_TBL_FLAG] != 0.0f;
             W2_STAMP(8);                                   // all groups arrived
             // ---- all heads of the set's rows: sc1 loads (L1 bypassed: another CU wrote them) -> LDS, A-operand layout
             {
@@ -755,7 +773,7 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
             __syncthreads();
             W2_STAMP(9);                                   // full rows in LDS
             // every reader counts itself out (the add is issued here, its result is looked at after the projection)
-            if (tid == NT - 64) done_ticket = __hip_atomic_fetch_add(p.sync + nsets + set, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == NT - 64) done_ticket = __hip_atomic_fetch_add(p.sync + W2_SYNC_DONE(set), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atile = xln;
         } else {
             // all heads are here: (training) the attention output -> HBM for the proj weight gradient
@@ -816,6 +834,7 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                             f32x4 v;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = (pacc[i][jj][e] + pb4[jj][e]) * rsm[i] + (float)resid[i][jj][e];
+                            if (poison) v = f32x4{NAN, NAN, NAN, NAN};
                             store4f(p.y + (long)tokm[i] * C + n, v);
                         }
                     }
@@ -825,8 +844,8 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
         if constexpr (NHG > 1) {
             // the last reader of the set re-arms its counters for the next launch
             if (tid == NT - 64 && done_ticket == NHG - 1) {
-                __hip_atomic_store(p.sync + set, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.sync + nsets + set, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.sync + W2_SYNC_ARRIVE(set), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.sync + W2_SYNC_DONE(set), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();                                   // the LDS tiles are rewritten by the next unit
@@ -868,9 +887,18 @@ extern "C" int mvlt_swin_wmsa2_supported(int dtype, int B, int res, int C, int n
     return C == 384 || C == 192 || C == 96;
 }
 
-// sync_ws: int32 [2 * (B nW / 2) + 1], zeroed ONCE by the caller when it is allocated (the kernel leaves it zeroed);
-// the last word is a sticky error flag (a bounded wait ran out: never expected)
-extern "C" int mvlt_swin_wmsa2_sync_words(int B, int res) { return 2 * (B * (res / 7) * (res / 7) / 2) + 1; }
+// sync_ws: int32 [16 + 2 * (B nW / 2)], zeroed ONCE by the caller when it is allocated (every launch leaves its counters
+// zeroed).  Word 0 is the sticky error count: a bounded hand-off wait ran out (never expected; the unit's rows of y are NaN).
+// One workspace per stream: launches that may run concurrently must not share counters.
+extern "C" int mvlt_swin_wmsa2_sync_words(int B, int res) { return 16 + 2 * (B * (res / 7) * (res / 7) / 2); }
+
+// Bound of the hand-off wait (default 2000 ms; the tests shorten it to provoke the failure path).  Process-wide setting.
+static std::atomic<long long> g_w2_spin_ticks{200000000LL};
+extern "C" int mvlt_swin_wmsa2_set_timeout_ms(int ms) {
+    MVLT_CHECK(ms >= 0, MVLT_ERR_ARG);
+    g_w2_spin_ticks.store(ms > 0 ? (long long)ms * 100000LL : 200000000LL);
+    return MVLT_OK;
+}
 
 extern "C" int mvlt_swin_wmsa2_fwd(const MvltSwinWmsa* p, int32_t* sync_ws, void* stream) {
     MVLT_CHECK(p && p->x && p->y && p->w2n && p->ln_gamma && p->ln_beta, MVLT_ERR_ARG);
@@ -892,6 +920,7 @@ extern "C" int mvlt_swin_wmsa2_fwd(const MvltSwinWmsa* p, int32_t* sync_ws, void
     d.xn = reinterpret_cast<T*>(p->xn_win); d.ao = reinterpret_cast<T*>(p->attn_out); d.qkv = reinterpret_cast<T*>(p->qkv_win);
     d.lse = p->lse; d.mean = p->mean; d.rstd = p->rstd;
     d.sync = sync_ws;
+    d.spin_ticks = g_w2_spin_ticks.load();
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (p->C) {
         // 8 waves: 12 (three per SIMD, 168 registers) measured the same 30 us at stage 2 and spills

@@ -25,7 +25,7 @@ exchange step BASELINE.json asks for.  Design for 8 x MI355X on one node
   (default on) all-reduces the 4-byte label count in the forward pass and every
   rank divides its summed loss by N_global / world instead of its own count
   (only in forwards that record a graph: torch.no_grad() forwards and
-  ``GradReducer.no_sync()`` take no collective and keep the per-rank mean;
+  ``GradReducer.no_label_sync()`` take no collective and keep the per-rank mean;
   heads other than MVLBertForPretraining always use per-rank means):
   the averaged loss and gradients then equal the single-process global-batch
   step exactly (the ITM loss is a mean over samples, equal per rank: unchanged);
@@ -157,9 +157,11 @@ class GradReducer:
             self.model.__dict__.pop("_mvlt_label_sync", None)
         return ar
 
-    def no_sync(self):
-        """Context manager: forwards inside it take no collective (the MLM loss falls back to the per-rank mean) -- for a
-        gradient-mode forward that not every rank runs.  Gradients of a backward() inside it are still exchanged."""
+    def no_label_sync(self):
+        """Context manager: forwards inside it take no label-count collective (the MLM loss falls back to the per-rank
+        mean) -- for a gradient-mode forward that not every rank runs.  NOT torch DDP's no_sync(): gradients of a backward()
+        inside it ARE still exchanged (this engine overwrites gradients per backward pass, it does not accumulate them, so
+        there is no gradient-accumulation mode to skip the exchange for)."""
         import contextlib
 
         @contextlib.contextmanager
@@ -185,7 +187,7 @@ class GradReducer:
         self.handles, self.launched, self.done = [], [], set()
         self.pending_casts = []
         self.rode_along = []
-        self.closed = []          # buckets whose gradients are all queued, not yet exchanged: (lo, hi, side-stream event)
+        self.closed = []          # buckets whose gradients are all queued, not yet exchanged: (lo, hi, side-stream event, ranges)
 
     def _idle_ok(self, p) -> bool:
         # may this gradient-less parameter's stale slot ride along in a merged collective?  Only when nothing suggests its
@@ -212,12 +214,16 @@ class GradReducer:
         ops.LnReduceQueue.flush_all()             # (main stream) LayerNorm gamma / beta gradients of the bucket
         ev = torch.cuda.Event()
         ev.record(ops.side_stream(arena.flat.device))
-        self.closed.append((lo, hi, ev))
+        # the bucket's CONTENT is fixed at the same instant as the event and the LayerNorm flush: a parameter of [lo, hi) that
+        # is marked between now and the (later) launch was not covered by either, so it must not be swept into this
+        # collective -- it falls to _finish, which joins the side stream in full
+        ranges = plan_ranges(arena, lo, hi, self.done, self.gap_elems, self._idle_ok, self.rode_along)
+        self.closed.append((lo, hi, ev, ranges))
         while len(self.closed) > self.lag:
-            a, b, e = self.closed.pop(0)
-            self._launch(arena, a, b, side_event=e)
+            a, b, e, r = self.closed.pop(0)
+            self._launch(arena, a, b, side_event=e, ranges=r)
 
-    def _launch(self, arena: Arena, lo: int, hi: int, side_event=None) -> None:
+    def _launch(self, arena: Arena, lo: int, hi: int, side_event=None, ranges=None) -> None:
         fork = None
         if arena.flat.is_cuda:
             from . import ops
@@ -233,7 +239,8 @@ class GradReducer:
                     fork = self._fork_stream = torch.cuda.Stream(device=arena.flat.device)
                 fork.wait_stream(torch.cuda.current_stream())
                 fork.wait_stream(ops.side_stream(arena.flat.device))
-        ranges = plan_ranges(arena, lo, hi, self.done, self.gap_elems, self._idle_ok, self.rode_along)
+        if ranges is None:
+            ranges = plan_ranges(arena, lo, hi, self.done, self.gap_elems, self._idle_ok, self.rode_along)
         op = dist.ReduceOp.AVG if (self.average and self._avg_op) else dist.ReduceOp.SUM
 
         def reduce_ranges(rs):
@@ -286,8 +293,8 @@ class GradReducer:
             # reduced in place while (or before) its gradient arrived, and would be reduced again below
             raise RuntimeError(f"mvlt_amd.ddp: {len(late)} parameter(s) received a gradient after their arena slot had left in "
                                "a merged bucket; construct GradReducer(merge_gap_elems=0) for models with data-dependent branches")
-        for a, b, e in self.closed:              # buckets still waiting for their turn (main-stream mode)
-            self._launch(arena, a, b, side_event=e)
+        for a, b, e, r in self.closed:           # buckets still waiting for their turn (main-stream mode)
+            self._launch(arena, a, b, side_event=e, ranges=r)
         self.closed = []
         self._launch(arena, 0, arena.total)
         self.pending_hi = 0

@@ -405,7 +405,16 @@ class MVLBertPretrainedModel(nn.Module):
         super().__init__()
         self.config = config
 
+    @staticmethod
+    def check_device_errors():
+        """Raise if an in-launch hand-off of the fused Swin attention (mvlt_swin_wmsa2_fwd) ever timed out on this process'
+        devices (ops.DeviceHandoffError; the affected activations are NaN).  Synchronises the device: call it where the caller
+        synchronises anyway (after loss.item(), before writing a checkpoint)."""
+        ops.wmsa2_check(sync=True)
+
     def save_pretrained(self, path):
+        if any(p.is_cuda for p in self.parameters()):
+            self.check_device_errors()          # (the copy to the host below synchronises anyway) never persist poisoned weights
         os.makedirs(path, exist_ok=True)
         torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, os.path.join(path, "pytorch_model.bin"))
         with open(os.path.join(path, "config.json"), "w") as f:
@@ -540,7 +549,7 @@ class MVLBertForPretraining(MVLBertPretrainedModel):
                                         # the label-count all-reduce is a COLLECTIVE: only a forward that records a graph (one
                                         # every rank runs and follows with backward()) takes it; no_grad forwards -- rank-0
                                         # validation, an uneven last evaluation batch -- keep the per-rank mean and never touch
-                                        # the process group (GradReducer.no_sync() switches it off for grad-mode forwards too)
+                                        # the process group (GradReducer.no_label_sync() switches it off for grad-mode forwards too)
                                         self.__dict__.get("_mvlt_label_sync") if torch.is_grad_enabled() else None)
             if compact:
                 mlm_loss = torch.where(valid.sum() > cap * B, torch.full_like(mlm_loss, float("nan")), mlm_loss)

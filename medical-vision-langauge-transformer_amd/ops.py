@@ -679,22 +679,82 @@ def swin_wmsa2_supported(dtype, B, res, C_, nH):
     return bool(L.lib().mvlt_swin_wmsa2_supported(_DT[dtype], B, res, C_, nH))
 
 
-_WMSA2_SYNC = {}
+_WMSA2_SYNC = {}          # (device, stream) -> int32 hand-off workspace
+_WMSA2_PINNED = {}        # key -> (pinned int32 [1], event): asynchronous copies of the error count
 
 
 def wmsa2_sync_ws(device, words):
-    """The int32 hand-off workspace of mvlt_swin_wmsa2_fwd: zeroed once here, left zeroed by every launch (the kernel's
-    counters re-arm themselves).  One per device; launches are serialised by the compute stream."""
-    ws = _WMSA2_SYNC.get(device)
+    """The int32 hand-off workspace of mvlt_swin_wmsa2_fwd for the CURRENT stream of `device`: zeroed once here, every
+    launch leaves its counters zeroed; word 0 is the sticky error count (include/mvlt_hip.h).  One workspace per (device,
+    stream): launches of one stream are serialised, launches of different streams never share counters."""
+    st = _stream_cache[0]          # (pinned by the engines for the duration of a pass: torch.cuda.current_stream costs ~5 us)
+    key = (torch.device(device), (st.value or 0) if st is not None else torch.cuda.current_stream(device).cuda_stream)
+    ws = _WMSA2_SYNC.get(key)
     if ws is None or ws.numel() < words:
         ws = torch.zeros(max(words, 4096), dtype=torch.int32, device=device)
-        _WMSA2_SYNC[device] = ws
+        _WMSA2_SYNC[key] = ws
     return ws
 
 
+class DeviceHandoffError(RuntimeError):
+    """A bounded in-launch wait of mvlt_swin_wmsa2_fwd ran out: the head groups of a window pair were not co-resident
+    (something else held the CUs / the LDS).  The affected rows of the block output are NaN."""
+
+
+def _wmsa2_raise(n):
+    raise DeviceHandoffError(
+        f"mvlt_swin_wmsa2_fwd: {n} hand-off wait(s) between head-group workgroups ran out (the groups of a window pair were "
+        "not resident together -- another kernel or process was holding CUs / LDS).  The affected rows of the block output "
+        "were written as NaN.  Set MVLT_WMSA2=0 to use the kernels without an in-launch hand-off.")
+
+
 def wmsa2_sync_errors():
-    """Sticky error words of the hand-off workspaces (0 = no bounded wait ever ran out).  Forces a device sync."""
-    return sum(int(ws.ne(0).sum().item()) for ws in _WMSA2_SYNC.values())
+    """Sum of the sticky error counts of all hand-off workspaces (0 = no bounded wait ever ran out).  Forces a device sync."""
+    return sum(int(ws[0].item()) for ws in _WMSA2_SYNC.values())
+
+
+def wmsa2_check(sync=True):
+    """Raise DeviceHandoffError if a hand-off wait ran out.  sync=True reads the error counts now (a device sync: use it
+    where the caller synchronises anyway -- loss.item(), save_pretrained).  sync=False costs no sync: it looks at the copies
+    queued by the PREVIOUS call (pinned host memory, ready when their event has completed) and queues fresh ones behind
+    the work issued so far, so a failure surfaces one call late."""
+    if sync:
+        n = wmsa2_sync_errors()
+        if n:
+            _wmsa2_raise(n)
+        return
+    for key, ws in _WMSA2_SYNC.items():
+        slot = _WMSA2_PINNED.get(key)
+        if slot is None:
+            slot = _WMSA2_PINNED[key] = [torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+        host, ev = slot
+        if ev is not None and ev.query() and int(host[0]):
+            _wmsa2_raise(int(host[0]))
+        if ev is None or ev.query():          # (never rewrite the pinned word while a copy into it is in flight)
+            host.copy_(ws[:1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(key[0]))
+            slot[1] = ev
+
+
+def wmsa2_clear_errors():
+    """Zero the error counts and the counters (after a reported failure; the caller has synchronised)."""
+    torch.cuda.synchronize()
+    for ws in _WMSA2_SYNC.values():
+        ws.zero_()
+    for slot in _WMSA2_PINNED.values():
+        slot[0].zero_()
+        slot[1] = None
+
+
+def wmsa2_set_timeout_ms(ms):
+    L.check(L.lib().mvlt_swin_wmsa2_set_timeout_ms(int(ms)), "mvlt_swin_wmsa2_set_timeout_ms")
+
+
+def debug_hold_cus(blocks, lds_bytes, usec, stream=None):
+    """Diagnostic: occupy CUs with spinning workgroups on `stream` (default: the current one)."""
+    st = stream.cuda_stream if stream is not None else _stream()
+    L.check(L.lib().mvlt_debug_hold_cus(int(blocks), int(lds_bytes), int(usec), st), "mvlt_debug_hold_cus")
 
 
 def swin_wmsa2_fwd(x, w2n, B, res, nH, shift, gamma, beta, eps, wqkv, bqkv, wproj, bproj, table, scale,

@@ -4,6 +4,7 @@ import random
 
 import torch
 
+from . import ops
 from .optim import FusedAdamW
 
 
@@ -56,4 +57,7 @@ class PretrainStep:
         loss = self.model(*batch[:4], text_lengths=batch[4]) if len(batch) > 4 else self.model(*batch)
         loss.backward()
         self.opt.step()
+        # in-launch hand-offs (mvlt_swin_wmsa2_fwd) that timed out poison the loss with NaN AND raise here, one step late:
+        # the error counts travel to pinned host memory behind the step's kernels, no device sync (ops.wmsa2_check)
+        ops.wmsa2_check(sync=False)
         return loss

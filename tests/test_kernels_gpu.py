@@ -554,12 +554,15 @@ def test_swin_wmsa_fused_forward(ops, dt, res, C_, shift, B, dp):
 
 @pytest.mark.parametrize("res,C_,shift,B,dp", [(14, 384, 3, 3, True), (14, 384, 0, 2, False), (14, 384, 3, 32, True),
                                               (28, 192, 3, 2, True), (28, 192, 0, 5, False), (56, 96, 3, 1, False),
-                                              (56, 96, 0, 2, True), (14, 384, 5, 1, False)])
+                                              (56, 96, 0, 2, True), (14, 384, 5, 1, False),
+                                              (14, 384, 3, 48, True), (14, 384, 0, 64, False)])
 def test_swin_wmsa2_forward(ops, res, C_, shift, B, dp):
     """mvlt_swin_wmsa2_fwd (two windows per workgroup, head groups across workgroups meeting through attn_out inside the one
     launch) against the fp32 torch statement and the unfused kernel sequence; B = 32 is the stage-2 launch of config #2 (256
     workgroups, every CU waits on three others), B = 3 / 5 leave a partly filled grid; the launch is repeated to show the
-    hand-off counters re-arm themselves."""
+    hand-off counters re-arm themselves; B = 48 / 64 at stage 2 run the PERSISTENT multi-round path (384 / 512 units on a grid
+    of 256: a workgroup walks several units, re-using its LDS tiles, the Wproj image, the ring prologue and the counters;
+    384 is not a multiple of the grid)."""
     from mvlt_amd._lib import ATTN_SWIN
     from mvlt_amd.indexing import batched_window_maps
     dt = torch.bfloat16
@@ -603,6 +606,80 @@ def test_swin_wmsa2_forward(ops, res, C_, shift, B, dp):
     assert ops.wmsa2_sync_errors() == 0
     ws = ops.wmsa2_sync_ws(x.device, 1)
     assert int(ws.abs().sum().item()) == 0
+
+
+def _wmsa2_case(ops, B, res=14, C_=384, shift=3, seed=160):
+    from mvlt_amd.indexing import batched_window_maps
+    dt = torch.bfloat16
+    nH = C_ // 32
+    x = rnd((B * res * res, C_), dt, seed)
+    g1 = (1.0 + 0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(seed + 1))).cuda()
+    b1 = (0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(seed + 2))).cuda()
+    wqkv = rnd((3 * C_, C_), dt, seed + 3, C_ ** -0.5)
+    bqkv = (0.1 * torch.randn(3 * C_, generator=torch.Generator().manual_seed(seed + 4))).cuda()
+    wproj = rnd((C_, C_), dt, seed + 5, C_ ** -0.5)
+    bproj = (0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(seed + 6))).cuda()
+    table = (0.5 * torch.randn(169, nH, generator=torch.Generator().manual_seed(seed + 7))).cuda()
+    w2n, _ = batched_window_maps(B, res, res, 7, shift, x.device)
+    return (x, w2n, B, res, nH, shift, g1, b1, 1e-5, wqkv, bqkv, wproj, bproj, table, 32 ** -0.5), w2n
+
+
+def test_swin_wmsa2_beside_a_kernel_that_holds_cus(ops):
+    """The hand-off of mvlt_swin_wmsa2_fwd needs the four head-group workgroups of a window pair resident together.  Here other
+    streams hold CUs while the stage-2 launch of config #2 (256 workgroups, one per CU) runs -- what the single-workgroup plan
+    kernels on the side stream do in the training step, made much worse: (a) one long single-workgroup kernel with a large
+    LDS footprint, (b) 64 of them.  The launch only gets the CUs late; the result must be bit-identical to the undisturbed
+    launch and no wait may run out."""
+    args, _ = _wmsa2_case(ops, 32)
+    y0, _ = ops.swin_wmsa2_fwd(*args)
+    torch.cuda.synchronize()
+    other = torch.cuda.Stream()
+    for blocks in (1, 64):
+        ops.debug_hold_cus(blocks, 100 * 1024, 3000, stream=other)          # 3 ms, 100 KB of LDS each: no wmsa2 workgroup fits beside one
+        for _ in range(4):
+            y, _ = ops.swin_wmsa2_fwd(*args)
+            assert torch.equal(y, y0)
+        torch.cuda.synchronize()
+    assert ops.wmsa2_sync_errors() == 0
+    ops.wmsa2_check(sync=True)
+    ws = ops.wmsa2_sync_ws(args[0].device, 1)
+    assert int(ws.abs().sum().item()) == 0
+
+
+def test_swin_wmsa2_timeout_is_loud(ops):
+    """A hand-off wait that runs out must not pass silently: the unit's rows of y are NaN, the sticky
+    error count (word 0 of the workspace) is raised, ops.wmsa2_check raises both in its synchronous and in its one-call-late
+    asynchronous form, and after wmsa2_clear_errors the next launch is clean again.  Provoked by mis-arming the arrival
+    counter of ONE window pair (so its four groups never see each other) with the wait shortened to 20 ms."""
+    args, w2n = _wmsa2_case(ops, 8)
+    x = args[0]
+    y0, _ = ops.swin_wmsa2_fwd(*args)
+    assert ops.wmsa2_sync_errors() == 0
+    ws = ops.wmsa2_sync_ws(x.device, 1)
+    bad_set = 5
+    try:
+        ops.wmsa2_set_timeout_ms(20)
+        ws[16 + 2 * bad_set] = -1000                      # arrivals of pair `bad_set` can never reach the group count
+        y, _ = ops.swin_wmsa2_fwd(*args)
+        torch.cuda.synchronize()
+        assert ops.wmsa2_sync_errors() == 4               # the four head groups of the pair
+        rows = w2n[bad_set * 98:(bad_set + 1) * 98].long()          # token rows of the pair's two windows
+        assert bool(torch.isnan(y[rows].float()).all())
+        keep = torch.ones(y.shape[0], dtype=torch.bool, device=y.device)
+        keep[rows] = False
+        assert torch.equal(y[keep], y0[keep])             # every other pair is untouched
+        with pytest.raises(ops.DeviceHandoffError):
+            ops.wmsa2_check(sync=True)
+        ops.wmsa2_check(sync=False)                       # queues the copy of the error count ...
+        torch.cuda.synchronize()
+        with pytest.raises(ops.DeviceHandoffError):
+            ops.wmsa2_check(sync=False)                   # ... and the next call sees it, without a device sync of its own
+    finally:
+        ops.wmsa2_set_timeout_ms(0)
+        ops.wmsa2_clear_errors()
+    y2, _ = ops.swin_wmsa2_fwd(*args)
+    assert torch.equal(y2, y0) and ops.wmsa2_sync_errors() == 0
+    ops.wmsa2_check(sync=True)
 
 
 def bert_ref(qkv, B, Lq, nH, mask_add, scale, keep=None, p=0.0):
