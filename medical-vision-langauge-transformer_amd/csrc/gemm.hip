@@ -19,6 +19,8 @@
 extern "C" __attribute__((visibility("hidden"))) int mvlt_gemm8_try(const void* dev_blocks, int n, int a_kmajor, int b_kmajor, int big_only,
                                                                     float* const* colsum, void* ws, size_t ws_bytes, void* stream);
 extern "C" __attribute__((visibility("hidden"))) size_t mvlt_gemm8_group_workspace(const void* dev_blocks, int n);
+// row-streaming kernel for the HBM-bound Swin stage-0 / 1 products (rowstream.hip): 1 = taken, 0 = not eligible, -1 = error
+extern "C" __attribute__((visibility("hidden"))) int mvlt_rowstream_try(const void* dev_block, int b_kmajor, void* stream);
 // MVLT_G8: unset / 2 = automatic (single products that fill the chip with 256 x 256 tiles: MLM decoder, large batches),
 // 0 = never, 1 = wherever it is eligible, weight-gradient groups included (experiments: slower than the 4-wave kernels on
 // the B=32 step's mid-size products)
@@ -888,6 +890,15 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     dim3 grid(ceil_div(p->N, pl.bn), ceil_div(p->M, pl.bm), d.split_k);
     const bool ak = p->a_kmajor != 0, bk = p->b_kmajor != 0;
     if constexpr (sizeof(T) == 2) {
+        // weight-stationary row streaming for the HBM-bound Swin stage-0 / 1 products (100 k / 25 k rows, K, N <= 384)
+        if (!ak && d.split_k <= 1 && p->M >= 24576 && p->N <= 768 && p->K <= 384) {
+            const int rcs = mvlt_rowstream_try(&d, bk ? 1 : 0, s);
+            if (rcs < 0) return MVLT_ERR_LAUNCH;
+            if (rcs > 0) {
+                if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
+                return MVLT_OK;
+            }
+        }
         // 8-wave ping-pong engine (gemm8.hip) for wide outputs: MVLT_G8 = 0 never / 1 wherever it is eligible
         const int g8m = g8_mode();
         if (g8m && !ak && d.split_k <= 1) {

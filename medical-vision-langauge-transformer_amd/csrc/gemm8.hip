@@ -84,14 +84,18 @@ template <bool KM> MVLT_DEV bf16x8 g8_frag(const char* half, int row0, int kb, i
 // stores pays a store latency per fragment (+23 us on the BERT FFN-in product).  Here every load of a row block is
 // issued BEFORE the stores of the previous row block: the bias values (4 column groups per lane) once per tile, the
 // per-row values and the residual / aux fragments one row block ahead.
-template <int NH, int EPI>
+// WIDE (g8_tile_epilogue_wide): the 8 values are the lane's eight consecutive columns of the chunk layout
+// (n_base + 128 c + 16 (g & 1) + 8 (g >> 1), g = lane / 16), [0] the lower four, [1] the upper four.
+template <int NH, int EPI, bool WIDE>
 MVLT_DEV void g8_load_bias(const GemmDev& p, const int n_base, const int lane, f32x4 (&bias_v)[NH][2]) {
     if constexpr ((EPI & MVLT_EPI_BIAS) != 0) {
+        const int g = lane >> 4;
 #pragma unroll
         for (int c = 0; c < NH; ++c)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int n = min(n_base + c * 128 + j * 16 + 4 * (lane >> 4), p.N - 4);          // N % 4 == 0 (launcher)
+                const int n = WIDE ? min(n_base + c * 128 + 16 * (g & 1) + 8 * (g >> 1), p.N - 8) + 4 * j          // N % 8 == 0 (GemmDev.wide)
+                                   : min(n_base + c * 128 + j * 16 + 4 * g, p.N - 4);                               // N % 4 == 0 (launcher)
                 bias_v[c][j] = *reinterpret_cast<const f32x4*>(p.bias + n);
             }
     }
@@ -200,6 +204,96 @@ MVLT_DEV void g8_tile_epilogue(const GemmDev& p, const int m_base, const int n_b
     }
 }
 
+// The same epilogue with 16 bytes per lane on every row operand (gemm_dev.h tile_epilogue_wide has the derivation): the two
+// 16-column fragments (j = 0, 1) of a quadrant's column block trade halves through v_permlane16_swap, after which a lane
+// holds EIGHT consecutive columns of one row -- 16 instead of 32 row stores per lane and tile (32 instead of 64 with a saved
+// pre-activation), every row load 16 bytes.  The store tail of the 256 x 256 tile is bound by the ISSUE of these
+// instructions, not by their bytes (cdna_hip_programming.md T21).  Chosen per launch (GemmDev.wide).
+template <int MH, int NH, int EPI>
+MVLT_DEV void g8_tile_epilogue_wide(const GemmDev& p, const int m_base, const int n_base, const int lane, f32x4 (&acc)[MH][NH][4][2],
+                                    const f32x4 (&bias_v)[NH][2]) {
+    static_assert((EPI & (MVLT_EPI_OUT_F32 | MVLT_EPI_DROPOUT)) == 0, "bf16 rows out");
+    constexpr bool HAS_ROWLOAD = (EPI & (MVLT_EPI_ROWMAP | MVLT_EPI_ROWSCALE)) != 0;
+    constexpr bool HAS_FRAGLOAD = (EPI & (MVLT_EPI_RESIDUAL | MVLT_EPI_MUL_GELU_GRAD)) != 0;
+    constexpr int NRB = MH * 4;
+    const int mr = lane & 15, g = lane >> 4;
+    const int cofs = 16 * (g & 1) + 8 * (g >> 1);
+    auto col_of = [&](int c) { return n_base + c * 128 + cofs; };
+    auto row_of = [&](int rb) { return m_base + (rb >> 2) * 128 + (rb & 3) * 16 + mr; };
+    f32x4 bv[NH][2];
+    if constexpr ((EPI & MVLT_EPI_BIAS) != 0) {
+#pragma unroll
+        for (int c = 0; c < NH; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { bv[c][j] = bias_v[c][j]; asm volatile("" : "+v"(bv[c][j])); }
+    }
+    struct RowPre { int mo; float sc; u32x4 res[NH]; u32x4 aux[NH]; };
+    auto preload = [&](int rb, RowPre& r) {
+        const int m = min(row_of(rb), p.M - 1);
+        r.mo = m; r.sc = 1.0f;
+        if constexpr ((EPI & MVLT_EPI_ROWMAP) != 0) r.mo = p.rowmap[m];
+        if constexpr ((EPI & MVLT_EPI_ROWSCALE) != 0) r.sc = p.rowscale[r.mo / p.rps];
+        if constexpr (HAS_FRAGLOAD) {
+#pragma unroll
+            for (int c = 0; c < NH; ++c) {
+                const int n = min(col_of(c), p.N - 8);
+                if constexpr ((EPI & MVLT_EPI_RESIDUAL) != 0)
+                    r.res[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.residual) + (long)r.mo * p.ldr + n);
+                if constexpr ((EPI & MVLT_EPI_MUL_GELU_GRAD) != 0)
+                    r.aux[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.aux) + (long)r.mo * p.ldc + n);
+            }
+        }
+    };
+    auto pin = [&](RowPre& r) {
+        if constexpr (HAS_FRAGLOAD) {
+#pragma unroll
+            for (int c = 0; c < NH; ++c) {
+                if constexpr ((EPI & MVLT_EPI_RESIDUAL) != 0) asm volatile("" : "+v"(r.res[c]));
+                if constexpr ((EPI & MVLT_EPI_MUL_GELU_GRAD) != 0) asm volatile("" : "+v"(r.aux[c]));
+            }
+        }
+        if constexpr ((EPI & MVLT_EPI_ROWSCALE) != 0) asm volatile("" : "+v"(r.sc));
+    };
+    RowPre cur, nxt, nx2;
+    if constexpr (HAS_ROWLOAD || HAS_FRAGLOAD) { preload(0, nxt); preload(1, nx2); }
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+        const int m = row_of(rb);
+        if constexpr (HAS_ROWLOAD || HAS_FRAGLOAD) {
+            cur = nxt; nxt = nx2;
+            if (rb + 2 < NRB) preload(rb + 2, nx2);
+            pin(cur);
+        } else { cur.mo = m; cur.sc = 1.0f; }
+#pragma unroll
+        for (int c = 0; c < NH; ++c) {
+            const int n = col_of(c);
+            const bool live = m < p.M && n < p.N;                          // (N % 8 == 0: a chunk is inside or outside as a whole)
+            f32x4 lo = acc[rb >> 2][c][rb & 3][0], hi = acc[rb >> 2][c][rb & 3][1];
+            swap16(lo, hi);
+            if constexpr ((EPI & MVLT_EPI_BIAS) != 0) { lo += bv[c][0]; hi += bv[c][1]; }
+            const long co = (long)cur.mo * p.ldc + n;
+            if constexpr ((EPI & MVLT_EPI_GELU) != 0) {
+                if constexpr ((EPI & MVLT_EPI_SAVE_PRE) != 0) { if (live) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.pre) + co) = pack8(lo, hi); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] = gelu_f(lo[e]); hi[e] = gelu_f(hi[e]); }
+            }
+            if constexpr ((EPI & MVLT_EPI_ROWSCALE) != 0) { lo *= cur.sc; hi *= cur.sc; }
+            if constexpr ((EPI & MVLT_EPI_MUL_GELU_GRAD) != 0) {
+                f32x4 alo, ahi;
+                unpack8(cur.aux[c], alo, ahi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] *= gelu_grad_f(alo[e]); hi[e] *= gelu_grad_f(ahi[e]); }
+            }
+            if constexpr ((EPI & MVLT_EPI_RESIDUAL) != 0) {
+                f32x4 rlo, rhi;
+                unpack8(cur.res[c], rlo, rhi);
+                lo += rlo; hi += rhi;
+            }
+            if (live) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + co) = pack8(lo, hi);
+        }
+    }
+}
+
 constexpr int G8_GROUP_MAX = 8;
 struct G8Group {
     int n; GemmDev g[G8_GROUP_MAX]; const void* zero_page;
@@ -226,7 +320,7 @@ template <int MH, int NH> struct G8Issue {
     int ord;                    // ordinal of the issue unit in this workgroup's list
 };
 
-template <int MH, int NH, bool AKM, bool BKM, int EPI>
+template <int MH, int NH, bool AKM, bool BKM, int EPI, bool WIDE = false>
 __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
     using Cfg = G8Cfg<MH, NH>;
     constexpr int BM = 128 * MH, BN = 128 * NH, HPK = Cfg::HPK, RING_KT = Cfg::RING_KT;
@@ -393,7 +487,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
         // bias values of this lane's 2 NH column groups: loaded now, used after the K loop (a load issued in the epilogue
         // would queue behind the ring's in-flight LDS-DMA: vmcnt completes in order)
         f32x4 bias_v[NH][2];
-        g8_load_bias<NH, EPI>(p, bx * BN + wc * 32, lane, bias_v);
+        g8_load_bias<NH, EPI, WIDE>(p, bx * BN + wc * 32, lane, bias_v);
         f32x4 acc[MH][NH][4][2];
 #pragma unroll
         for (int a = 0; a < MH; ++a)
@@ -558,7 +652,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
             }
         }
         if (finish) {
-            g8_tile_epilogue<MH, NH, EPI>(p, by * BM + wr * 64, bx * BN + wc * 32, lane, acc, bias_v);
+            if constexpr (WIDE) g8_tile_epilogue_wide<MH, NH, EPI>(p, by * BM + wr * 64, bx * BN + wc * 32, lane, acc, bias_v);
+            else g8_tile_epilogue<MH, NH, EPI>(p, by * BM + wr * 64, bx * BN + wc * 32, lane, acc, bias_v);
             if constexpr (AKM && BKM) {
                 float* db = gp.colsum[0];
 #pragma unroll
@@ -581,15 +676,26 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
 // 512 zero bytes for the reduction rows beyond a ragged K (k-major A operand)
 __device__ __attribute__((aligned(256))) unsigned char g8_zero_page[512];
 
-template <int MH, int NH, bool AKM, bool BKM, int EPI>
-int g8_launch(const G8Group& gp, long units, hipStream_t s) {
+template <int MH, int NH, bool AKM, bool BKM, int EPI, bool WIDE = false>
+int g8_launch1(const G8Group& gp, long units, hipStream_t s) {
     constexpr int sh = G8Cfg<MH, NH>::LDS + 64;                           // ring + the products' effective sizes + ticket
-    static const bool attr = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel<MH, NH, AKM, BKM, EPI>),
+    static const bool attr = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel<MH, NH, AKM, BKM, EPI, WIDE>),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, sh) == hipSuccess; }();
     if (!attr) return -1;
     const int grid = units < 256 ? (int)units : 256;
-    hipLaunchKernelGGL((gemm8_kernel<MH, NH, AKM, BKM, EPI>), dim3(grid), dim3(512), sh, s, gp);
+    hipLaunchKernelGGL((gemm8_kernel<MH, NH, AKM, BKM, EPI, WIDE>), dim3(grid), dim3(512), sh, s, gp);
     return hipGetLastError() == hipSuccess ? 1 : -1;
+}
+// forward / dgrad products with bf16 rows out: the 16-byte epilogue when EVERY product of the list qualifies (GemmDev.wide)
+template <int MH, int NH, bool AKM, bool BKM, int EPI>
+int g8_launch(const G8Group& gp, long units, hipStream_t s) {
+    if constexpr (!AKM && (EPI & MVLT_EPI_OUT_F32) == 0) {
+        const char* we = getenv("MVLT_G8_WIDE"); const bool wide_on = !we || atoi(we) != 0;   // (A/B switch)
+        bool wide = wide_on;
+        for (int i = 0; i < gp.n; ++i) wide = wide && gp.g[i].wide;
+        if (wide) return g8_launch1<MH, NH, AKM, BKM, EPI, true>(gp, units, s);
+    }
+    return g8_launch1<MH, NH, AKM, BKM, EPI, false>(gp, units, s);
 }
 
 const void* g8_zero_ptr() {

@@ -218,6 +218,66 @@ def test_gemm_epilogues(ops, dt, M, N, K):
     assert rel(out, hf.grad) < tol(dt)
 
 
+# (K, N, b_kmajor, epilogue): the nine products mvlt_gemm routes to the row-streaming kernel (csrc/rowstream.hip)
+_ROWSTREAM = [(96, 384, False, "gelu_pre"), (96, 384, False, "gelu"), (384, 96, False, "scale_res"), (384, 96, False, "res"),
+              (192, 768, False, "gelu_pre"), (96, 384, True, "aux"), (384, 96, True, ""), (96, 96, True, ""), (288, 96, True, ""),
+              (192, 768, True, "aux"), (192, 192, True, "")]
+
+
+@pytest.mark.parametrize("K,N,bk,epi", _ROWSTREAM)
+@pytest.mark.parametrize("M", [25088, 24576 + 16 * 37 + 5])
+def test_rowstream_products(ops, K, N, bk, epi, M, monkeypatch):
+    """The HBM-bound Swin stage-0 / 1 products (Mlp fc1 / fc2 forward, the dgrads of fc1 / fc2 / proj / qkv:
+    visual_feature_extractor.py:135-141, 231, 252) on the weight-stationary row-streaming kernel, against the fp32 torch
+    statement on the same bf16 operands; M = 25088 is stage 1 of a B = 32 step, the other M is not a multiple of 16 (row
+    ranges of the persistent workgroups end inside a 32-row stage, the last fragment is partial).  Every epilogue the Swin
+    block issues on these shapes: bias + GELU (+ saved pre-activation), bias + DropPath row scale + residual, x gelu'(aux)."""
+    monkeypatch.setenv("MVLT_ROWSTREAM", "0x1FF")          # every shape on (the default routes the stage-0 shapes only)
+    dt = torch.bfloat16
+    A = rnd((M, K), dt, 31)
+    W = rnd((K, N) if bk else (N, K), dt, 32, K ** -0.5)
+    base = A.float() @ (W.float() if bk else W.float().t())
+    kw, exp, pre = {}, base, None
+    if epi in ("gelu_pre", "gelu", "scale_res", "res"):
+        kw["bias"] = rnd((N,), torch.float32, 33)
+        exp = base + kw["bias"]
+    if epi.startswith("gelu"):
+        kw["gelu"] = True
+        if epi == "gelu_pre":
+            pre = kw["save_pre"] = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+        pre_exp, exp = exp, F.gelu(exp)
+    if epi in ("scale_res", "res"):
+        res = kw["residual"] = rnd((M, N), dt, 34)
+        if epi == "scale_res":
+            rps = 784
+            rs = (0.5 + (torch.arange((M + rps - 1) // rps, device="cuda") % 3).float())
+            kw["rowscale"] = (rs, rps)
+            exp = exp * rs[torch.arange(M, device="cuda") // rps][:, None]
+        exp = exp + res.float()
+    if epi == "aux":
+        h = kw["mul_gelu_grad"] = rnd((M, N), dt, 35)
+        hf = h.float()
+        exp = base * (0.5 * (1 + torch.erf(hf / 2 ** 0.5)) + hf * torch.exp(-0.5 * hf * hf) / (2 * 3.141592653589793) ** 0.5)
+    out = torch.full((M + 1, N), float("nan"), dtype=dt, device="cuda")          # a guard row behind the output
+    ops.gemm(A, W, b_kmajor=bk, out=out[:M], **kw)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out[M]).all())                                        # nothing written past the last row
+    assert rel(out[:M], exp) < tol(dt)
+    # every row, not only the norm: a workgroup's range boundary or a wrong column chunk would hide in a relative norm
+    err = (out[:M].float() - exp).abs().amax(1)
+    assert float(err.max()) < 0.05 * float(exp.abs().max()) + 0.05
+    if pre is not None:
+        assert rel(pre, pre_exp) < tol(dt)
+    # the tile kernels on the same product (shape switched off): same arithmetic, another summation order over K at most
+    monkeypatch.setenv("MVLT_ROWSTREAM", "0")
+    out2 = torch.empty((M, N), dtype=dt, device="cuda")
+    kw2 = dict(kw)
+    if pre is not None:
+        kw2["save_pre"] = torch.empty((M, N), dtype=dt, device="cuda")
+    ops.gemm(A, W, b_kmajor=bk, out=out2, **kw2)
+    assert rel(out[:M], out2) < 2e-3
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("widths,R", [([(768, 3072), (3072, 768), (768, 768), (2304, 768)], 1573),      # one BERT layer, ragged R
                                       ([(384, 1536), (1536, 384), (384, 384), (1152, 384)], 6272),      # one Swin stage-2 block
