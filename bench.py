@@ -18,6 +18,8 @@ import random
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the HIP runtime starts (mvlt_amd/__init__.py says why)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -247,6 +249,28 @@ def other_configs(M):
     return res
 
 
+def one_rank_rccl(steps=40, warmup=10):
+    """the same step with the gradient reducer and RCCL on ONE rank (MVLT_FORCE_DDP=1), in a child process.
+    What a 1-GPU lease can show of the multi-GPU path: bucket issue, stream joins and RCCL's kernel beside the backward pass.
+    MVLT_DDP_NULL_COLLECTIVE=1 is the same run without the collective itself: the difference to the plain step is the reducer's
+    own cost, the rest is RCCL's one-rank pass over the 836 MB gradient arena (a copy a real ring does not make)."""
+    import subprocess
+    out = {}
+    for key, extra in (("ms_per_step", {}), ("ms_per_step_without_the_collective", {"MVLT_DDP_NULL_COLLECTIVE": "1"})):
+        env = dict(os.environ, MVLT_FORCE_DDP="1", **extra)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup),
+                                "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=240)
+            line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith('{"metric"')), None)
+            out[key] = json.loads(line)["ms_per_step"] if line else None
+        except Exception as e:          # the headline must not depend on this extra
+            out[key] = None
+            out["error"] = repr(e)[:200]
+    out["workload"] = ("config #2 step with GradReducer over RCCL on one rank (MVLT_FORCE_DDP=1): 64 MiB buckets exchanged one bucket "
+                       "late on the main stream; second figure: reducer without the collective")
+    return out
+
+
 def profiled_traffic(key):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (cannot be collected inside this
     process): profiles/r4_dominant_kernel_traffic.json {"family": {...}, "wgrad_group": {...}}, filled in from the
@@ -459,6 +483,12 @@ def main():
             out.update(extra)
         if world == 1 and not args.no_extra:
             out["other_configs"] = other_configs(M)
+            if not use_dist:
+                out["other_configs"]["one_rank_rccl"] = one_rank_rccl()
+                if out["other_configs"]["one_rank_rccl"].get("ms_per_step"):
+                    o = out["other_configs"]["one_rank_rccl"]
+                    o["plain_step_ms"] = out["ms_per_step"]
+                    o["reducer_overhead_ms"] = round((o.get("ms_per_step_without_the_collective") or 0) - out["ms_per_step"], 3) if o.get("ms_per_step_without_the_collective") else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         line = json.dumps(out)

@@ -35,6 +35,7 @@ exchange step BASELINE.json asks for.  Design for 8 x MI355X on one node
 """
 from __future__ import annotations
 
+import os
 import random
 from typing import List, Tuple
 
@@ -84,6 +85,11 @@ def plan_ranges(arena: Arena, lo: int, hi: int, done: set, gap_elems: int = GAP_
             out.append([o, e])
         gap, gap_ok = [], True
     return [(a, b) for a, b in out]
+
+
+# MVLT_DDP_NULL_COLLECTIVE=1 (diagnostic, one rank only): the reducer runs -- buckets, events, stream joins, LayerNorm flushes --
+# but issues no collective: what is left over a run without a reducer is the reducer's own cost
+_NULL_COLLECTIVE = os.environ.get("MVLT_DDP_NULL_COLLECTIVE", "0") == "1"
 
 
 class GradReducer:
@@ -138,6 +144,14 @@ class GradReducer:
         self.prev_marked = None    # ids of the parameters that received a gradient in the previous completed backward pass
         self.rode_along: list = []  # ids of gradient-less parameters swept into a merged collective in this pass
         self.on_bucket = None      # optional consumer (ranges, handles) of a launched bucket: optim.FusedAdamW overlap
+        import sys
+        pkg = sys.modules.get(__name__.rsplit(".", 1)[0])
+        if getattr(pkg, "HWQ_SET_LATE", False) and not allow_cpu:
+            import warnings
+            warnings.warn("mvlt_amd.ddp: the HIP runtime was initialised before GPU_MAX_HW_QUEUES could be raised (default 4 hardware "
+                          "queues): with RCCL's streams beside the step's two, streams share a queue and serialise (~1 ms per step, "
+                          "profiles/r5_ddp_one_rank.md).  Export GPU_MAX_HW_QUEUES=8, or import mvlt_amd before the first CUDA call / "
+                          "before init_process_group(device_id=...).", RuntimeWarning, stacklevel=2)
         self.attach()
 
     def attach(self) -> Arena:
@@ -244,6 +258,8 @@ class GradReducer:
         op = dist.ReduceOp.AVG if (self.average and self._avg_op) else dist.ReduceOp.SUM
 
         def reduce_ranges(rs):
+            if _NULL_COLLECTIVE:          # diagnostic (scripts/r5_ddp_overhead.sh): everything but the collective itself
+                return []
             return [dist.all_reduce(arena.grad[a:b], op=op, group=self.pg, async_op=True) for a, b in rs]
 
         if self.comm_dtype == torch.float32 and fork is not None and self.on_bucket is None:
