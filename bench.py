@@ -31,8 +31,8 @@ PER_GPU_BATCH, SEQ = 32, 80
 
 
 DOMINANT_NAME = ("forward + dgrad GEMM family of the Swin blocks / BertLayers: gemm_kernel<bf16,{128|64},{128|96|64},row,{row|kmajor}>, "
-                 "gemm_glds_kernel<{64|128},{64|96|128}>, gemm8_kernel (x W^T and dy W with fused epilogues; main stream) -- the "
-                 "family with the largest share of GPU time (~45 %, profiles/r4_bench_kernel_stats.csv)")
+                 "gemm_glds_kernel<{64|128},{64|96|128}>, gemm8_kernel, rowstream_kernel (x W^T and dy W with fused epilogues; main "
+                 "stream) -- the family with the largest share of GPU time (~45 %, profiles/r5_bench_kernel_stats.csv)")
 WGRAD_NAME = ("gemm_group_kernel<bf16,{128|64},{128|96},kmajor,kmajor> (grouped weight-gradient GEMMs dW_i = dY_i^T X_i "
               "+ bias gradients of one layer per launch; side stream, beside the dgrad chain)")
 DOMINANT = ("group", 1, 64, 128)   # gemm_group_kernel<bf16, BM=128|64, BN=128, A k-major, B k-major>: the grouped weight-
@@ -230,6 +230,23 @@ def other_configs(M):
                              "note": "floor = 217 MB of bf16 weights streamed per step (SURVEY 8d) at the 8 TB/s HBM peak; the step is "
                                      "a chain of ~100 dependent small kernels, i.e. latency bound"}
     del cap
+    # config #1: SLAKE Med-VQA forward, B = 2, T = 80 / 23 (the reference's CPU-runnable case, run_vqa.py): latency of one call
+    vq = M.MVLBertForVQA(M.MVLBertConfigforVQA()).cuda().eval()
+    c1 = {}
+    with torch.no_grad():
+        for T in (80, 23):
+            im, q = torch.randn(2, 3, 224, 224, device="cuda"), torch.randint(1000, 30000, (2, T), device="cuda")
+            for _ in range(5):
+                vq(im, q, None)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(30):
+                vq(im, q, None)
+            torch.cuda.synchronize()
+            c1[f"ms_per_call_T{T}"] = round((time.perf_counter() - t0) / 30 * 1e3, 3)
+    c1["workload"] = ("Med-VQA forward (MVLBertForVQA.forward), Swin-S + BERT-base, batch 2, 224 px, question length 80 / 23, bf16, eval: "
+                      "~330 dependent launches, device-latency bound (a replayed HIP graph of the call, config.eval_cuda_graph, takes the same time)")
+    res["config1_vqa_forward"] = c1
+    del vq
     c5 = M.MVLBertPretrainConfig().use_swin_base()
     c5.ITM_task = True
     m5 = M.MVLBertForPretraining(c5).cuda().train()

@@ -511,6 +511,11 @@ std::vector<Tensor> swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>&
 void lnq_flush(int64_t stream) { g_lnq.flush(P(stream)); }
 int64_t lnq_pending() { return (int64_t)g_lnq.items.size(); }
 void side_release() { g_side_keepalive.clear(); g_ws_side.retired.clear(); g_ws_main.retired.clear(); }
+// a HIP graph has recorded the addresses of the current scratch buffers: keep them alive for the life of the process
+std::vector<Tensor> g_pinned_scratch;
+void scratch_pin() {
+    for (Scratch* s : {&g_ws_main, &g_ws_side}) if (s->buf.defined()) g_pinned_scratch.push_back(s->buf);
+}
 
 // which: 0 = grouped weight-gradient launches, 1 = forward / dgrad products issued by the layer calls
 void timer_begin(int64_t which, int64_t every, int64_t capacity) {
@@ -530,6 +535,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("lnq_flush", &lnq_flush);
     m.def("lnq_pending", &lnq_pending);
     m.def("side_release", &side_release);
+    m.def("scratch_pin", &scratch_pin);
     m.def("timer_begin", &timer_begin);
     m.def("timer_collect", &timer_collect);
     // the ABI this extension was COMPILED against (not what the library it happens to bind reports): ops.host()

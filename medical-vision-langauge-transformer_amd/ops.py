@@ -138,12 +138,23 @@ def join_side(device):
         _host.side_release()
 
 
+_pinned_scratch = []
+
+
+def pin_scratch():
+    """A HIP graph is about to record (or has recorded) the addresses of the scratch workspaces: never free them."""
+    _pinned_scratch.extend(_ws.values())
+    if _host is not None:
+        _host.scratch_pin()
+
+
 class pin_stream:
     """Context manager: resolve torch's current stream once for a whole forward/backward pass."""
 
     def __enter__(self):
         self.prev = (_stream_cache[0], _stream_cache[1])
-        _stream_cache[0], _stream_cache[1] = C.c_void_p(torch.cuda.current_stream().cuda_stream), None
+        # (inside a HIP-graph capture the scratch buffers keep their "graph" tag: their addresses are recorded)
+        _stream_cache[0], _stream_cache[1] = C.c_void_p(torch.cuda.current_stream().cuda_stream), ("graph" if self.prev[1] == "graph" else None)
 
     def __exit__(self, *a):
         _stream_cache[0], _stream_cache[1] = self.prev

@@ -448,6 +448,10 @@ def hash_models(M):
             g = sd[gn].grad
             out[f"grad_{name}_{gn}"] = g.reshape(-1)[:256].clone()
             out[f"gradnorm_{name}_{gn}"] = g.double().norm().float()
+            # 4096 elements spread over the whole tensor (round 5): a 256-element head moves by several per cent with any
+            # change of an upstream summation order in bf16; a strided sample of the whole tensor does not
+            flat = g.reshape(-1)
+            out[f"gradstride_{name}_{gn}"] = flat[::max(1, flat.numel() // 4096)][:4096].clone()
         head = "MLM_head_seq2seq" if name == "seq2seq" else "MLM_head_bidir"
         out[f"gradnorm_{name}_decoder"] = sd[f"{head}.predictions.decoder.weight"].grad.double().norm().float()
         with torch.no_grad():

@@ -81,3 +81,69 @@ def test_two_ranks_equal_the_single_process_global_batch(tmp_path, monkeypatch, 
         after = {k: p.detach().cpu() for k, p in model.named_parameters()}
         badp = [(k, rel_err(ddp["params_after"][k], after[k])) for k in after if rel_err(ddp["params_after"][k], after[k]) > 1e-5]
         assert not badp, badp[:10]
+
+
+def test_parameter_marked_after_its_bucket_closed_is_not_swept_into_that_bucket(monkeypatch):
+    """ADVICE r4 (ddp.py:236): in the default main-stream mode a bucket is exchanged ONE bucket late.  Its content must be
+    fixed when it CLOSES (the side-stream event and the LayerNorm flush are taken then): a parameter of its range that is
+    marked between the close and the later launch -- an out-of-watermark-order arrival -- is covered by neither, so it must
+    not leave in that collective; _finish exchanges it behind a full join of the side stream.  Driven here through the
+    arena's own hooks with a recording stand-in for all_reduce (one rank over gloo, CUDA arena)."""
+    import torch.distributed as dist
+    import mvlt_amd as M
+    from mvlt_amd import ddp as D
+    from mvlt_amd.arena import Arena
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ddp_gpu_worker import build_model
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("MVLT_DDP_FORK", "0")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        model = build_model(M)
+        red = D.GradReducer(model, bucket_bytes=256 << 10, merge_gap_elems=0)
+        assert not red.use_fork and red.lag == 1
+        ar = Arena.of(model, torch.float32)
+        calls = []          # (tag, lo, hi) of every collective, in issue order
+
+        class _H:
+            def wait(self):
+                return None
+
+        def fake_all_reduce(t, op=None, group=None, async_op=False):
+            lo = (t.data_ptr() - ar.grad.data_ptr()) // 4
+            calls.append((fake_all_reduce.tag, lo, lo + t.numel()))
+            return _H()
+        fake_all_reduce.tag = "pass"
+        monkeypatch.setattr(D.dist, "all_reduce", fake_all_reduce)
+        # the backward pass marks parameters in descending arena order; hold one back
+        params = [p for p in reversed(ar.params) if p.requires_grad]
+        total = ar.total
+        late = next(p for p in params if total - ar.offset[id(p)] > red.bucket_elems // 2 and p.numel() > 1000)      # inside the FIRST bucket
+        ar._in_backward = True
+        ar.begin_backward()
+        closed_before = None
+        for p in params:
+            if p is late:
+                continue
+            ar.mark(p)
+            if closed_before is None and len(red.closed) + len(red.launched) > 0:
+                # the first bucket has just closed (nothing launched yet in lagged mode): the straggler arrives NOW
+                assert len(red.launched) == 0 and len(red.closed) == 1
+                closed_before = red.closed[0][:2]
+                ar.mark(late)
+        assert closed_before is not None and closed_before[0] <= ar.offset[id(late)] < closed_before[1]
+        fake_all_reduce.tag = "finish"
+        from mvlt_amd.runtime import backward_end
+        backward_end(ar)
+        torch.cuda.synchronize()
+        lo = ar.offset[id(late)]
+        cover = [c for c in calls if c[1] <= lo < c[2]]
+        assert len(cover) == 1, cover                  # exchanged exactly once ...
+        assert cover[0][0] == "finish", cover          # ... by _finish, not by the lagged launch of the bucket that had closed
+        # every other marked parameter exactly once as well
+        for p in params:
+            o = ar.offset[id(p)]
+            assert sum(1 for c in calls if c[1] <= o < c[2]) == 1
+    finally:
+        dist.destroy_process_group()

@@ -31,7 +31,9 @@ HASH_GRAD = {F32: 5e-3, BF16: 8e-2}
 # bf16, first 256 elements of a gradient tensor: a 256-element slice of a 590k-element gradient moves between 0.03 and 0.10
 # with any change of a summation order upstream (measured across kernel variants of rounds 3-4: LayerNorm reduction order,
 # fused / unfused W-MSA) while the whole-tensor norm stays within 2e-3 -- the slice bound says "the right values", the
-# norm bound (HASH_GRAD, unchanged) says how exactly
+# norm bound (HASH_GRAD, unchanged) says how exactly.  Round 5: the 8e-2 bound (HASH_GRAD) is ALSO held element-wise
+# on 4,096 elements sampled with a stride over the whole tensor (golden `gradstride_*`), which does not have the head's
+# sensitivity to a single upstream summation order
 HASH_GRAD_SLICE = {F32: 5e-3, BF16: 0.12}
 
 
@@ -307,10 +309,12 @@ def test_full_pretrain_vs_reference_on_well_conditioned_weights(M, golden, specs
             gr = params[pn].grad
             e_norm = abs(gr.double().norm().item() - g[k].item()) / g[k].item()
             e_head = rel_err(gr.reshape(-1)[:256].cpu(), g[f"grad_{name}_{pn}"])
-            if e_norm > HASH_GRAD[cd] or e_head > HASH_GRAD_SLICE[cd]:
-                bad.append((pn, e_norm, e_head))
+            flat = gr.reshape(-1)
+            e_str = rel_err(flat[::max(1, flat.numel() // 4096)][:4096].cpu(), g[f"gradstride_{name}_{pn}"])
+            if e_norm > HASH_GRAD[cd] or e_head > HASH_GRAD_SLICE[cd] or e_str > HASH_GRAD[cd]:
+                bad.append((pn, e_norm, e_head, e_str))
             if os.environ.get("MVLT_TEST_VERBOSE"):
-                print(f"{name} {pn}: norm err {e_norm:.2e}, first-256 err {e_head:.2e}")
+                print(f"{name} {pn}: norm err {e_norm:.2e}, first-256 err {e_head:.2e}, 4096 strided {e_str:.2e}")
         assert not bad, bad
         head = "MLM_head_" + name
         gd = params[f"{head}.predictions.decoder.weight"].grad.double().norm().item()
@@ -369,6 +373,42 @@ def test_vqa_forward_config1(M, golden, specs, cd):
         assert rel_err(logits.cpu(), g[f"vqa_logits_T{T}"]) < ACT[cd] * 2
         assert rel_err(prob.cpu(), g[f"vqa_prob_T{T}"]) < ACT[cd] * 2
         assert torch.equal(prob.argmax(-1).cpu(), g[f"vqa_prob_T{T}"].argmax(-1))
+
+
+def test_vqa_forward_replayed_graph_equals_eager(M, specs):
+    """config.eval_cuda_graph = True (runtime.GraphedEval): the Med-VQA inference call of config #1 captured as a HIP graph and
+    replayed -- bit-identical to the eager call, for fresh inputs, for a second input shape, and after the weights changed
+    (the arena's storage does not move; the bf16 compute copy is refreshed before each replay)."""
+    model = M.MVLBertForVQA(M.MVLBertConfigforVQA())
+    load_formula(model, specs["vqa"])
+    model = M.set_compute_dtype(model.cuda().eval(), BF16)
+    batches = {T: [tuple(t.cuda() for t in synth_batch(2, T, seed=300 + 7 * i + T)[:2]) for i in range(4)] for T in (23, 80)}
+    with torch.no_grad():
+        eager = {T: [tuple(o.clone() for o in model(im, q, None)) for im, q in bs] for T, bs in batches.items()}
+        model.config.eval_cuda_graph = True
+        for rep in range(2):                       # two warm-up calls per shape, then capture, then replays
+            for T, bs in batches.items():
+                for (im, q), ref in zip(bs, eager[T]):
+                    prob, logits = model(im, q, None)
+                    assert torch.equal(prob, ref[0]) and torch.equal(logits, ref[1])
+        ge = model.__dict__["_mvlt_graphed"]
+        assert len(ge.graphs) == 2                 # one graph per input shape; later calls replayed
+        # new weights through load_state_dict: same storage, the bf16 compute copy is refreshed before the replay
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        sd["final_mlp.1.weight"] *= 0.5
+        sd["MVLBert.encoder.layer.3.intermediate.dense.weight"] *= 1.25
+        model.load_state_dict(sd)
+        im, q = batches[80][0]
+        g_out = model(im, q, None)
+        model.config.eval_cuda_graph = False
+        e_out = model(im, q, None)
+        assert torch.equal(g_out[0], e_out[0]) and torch.equal(g_out[1], e_out[1])
+        assert not torch.equal(e_out[1], eager[80][0][1])
+    # training-mode / autograd calls never take the graph
+    model.config.eval_cuda_graph = True
+    model.train()
+    prob, logits = model(im, q, None)
+    assert logits.requires_grad
 
 
 @pytest.mark.parametrize("size", ["tiny", "full"])
