@@ -328,6 +328,41 @@ def test_full_pretrain_vs_reference_on_well_conditioned_weights(M, golden, specs
             assert rel_err(pooled.float().cpu(), g[f"pooled_{name}"]) < HASH_ACT[cd]
 
 
+def _teacher_forced_picks_ok(O, sd, scfg, bcfg, image, ids, tol=0.02, eos=None):
+    """bf16 greedy decoding against the f32 reference computation, pick by pick: for every sample and
+    step t the oracle (pinned to the reference) is run on the BUILD's own prefix ids[:, :t] + [MASK] (teacher forcing: one
+    full-sequence recompute per step for the whole batch) and the build's pick must be the oracle's argmax, or a near-tie: its
+    f32 logit within `tol` x (top logit - mean logit) of the top -- about the size of bf16 rounding carried through the
+    network on these logits.  A flip is therefore allowed only where the reference's own margin is below bf16 resolution,
+    and every later pick is still pinned (to the reference computation on the sequence actually generated).
+    Returns (exact picks, near-tie picks, violations [(sample, step, margin, spread)])."""
+    feat = O.conv_layer(image, sd, scfg)
+    B, n = ids.shape
+    exact = near = 0
+    bad = []
+    alive = torch.ones(B, dtype=torch.bool)
+    for t in range(n):
+        inp = torch.cat([ids[:, :t], torch.full((B, 1), bcfg.mask_token_id)], 1)
+        o = O.mvlbert_forward(sd, bcfg, inp, feat, True)
+        L = O.mlm_head(o["hidden"][:, -1], sd, "MLM_head_seq2seq", bcfg).double()
+        top = L.max(-1).values
+        got = L.gather(1, ids[:, t:t + 1]).squeeze(1)
+        spread = top - L.mean(-1)
+        for b in range(B):
+            if not alive[b]:
+                continue                      # finished samples emit PAD (model.py:903-905): nothing to pin
+            m = float(top[b] - got[b])
+            if m == 0.0:
+                exact += 1
+            elif m <= tol * float(spread[b]):
+                near += 1
+            else:
+                bad.append((b, t, m, float(spread[b])))
+        if eos is not None:
+            alive &= ids[:, t] != eos
+    return exact, near, bad
+
+
 @pytest.mark.parametrize("cd", [F32, BF16])
 @pytest.mark.parametrize("graph", ["1", "0"])
 def test_greedy_decode_matches_reference_token_ids(M, golden, specs_hash, monkeypatch, graph, cd):
@@ -352,10 +387,21 @@ def test_greedy_decode_matches_reference_token_ids(M, golden, specs_hash, monkey
     if cd == F32:
         assert out.shape == ref.shape and torch.equal(out, ref), (out, ref)
     else:
+        # bf16: identical to the reference's ids up to the first near-tie; every pick (before and after a flip) is the f32
+        # reference computation's argmax on the generated prefix, or within bf16 resolution of it
+        from oracle import mvlt_oracle as O
         n = min(out.shape[1], ref.shape[1])
-        agree = (out[:, :n] == ref[:, :n])
-        # every sample starts right, and most of the 36 picks are the reference's
-        assert bool(agree[:, 0].all()) and agree.float().mean().item() > 0.6, (out, ref)
+        assert bool((out[:, 0] == ref[:, 0]).all()), (out, ref)
+        tscfg = O.SwinCfg(embed_dim=32, depths=(2, 2, 2, 2), num_heads=(1, 2, 4, 8), drop_path_rate=0.2)
+        tbcfg = O.BertCfg(vocab_size=3000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024)
+        with torch.no_grad():
+            exact, near, bad = _teacher_forced_picks_ok(O, hash_sd(specs_hash["hash_tiny_caption"]), tscfg, tbcfg, image, out,
+                                                        eos=tbcfg.eos_token_id)
+        assert not bad, (bad, out, ref)
+        assert exact >= 4 * near, (exact, near)          # near-ties are the exception
+        first_flip = [(int((out[b, :n] != ref[b, :n]).nonzero()[0]) if bool((out[b, :n] != ref[b, :n]).any()) else n) for b in range(out.shape[0])]
+        for b, f in enumerate(first_flip):                # before its first flip a sample IS the reference's sequence
+            assert torch.equal(out[b, :f], ref[b, :f])
 
 
 @pytest.mark.parametrize("cd", [F32, BF16])
@@ -501,6 +547,7 @@ def test_decode_config4_full_size(M, monkeypatch, cd):
     else:
         # bf16: the graph path picks from f32 accumulators (mvlt_gemm_argmax), the eager loop from bf16-rounded
         # logits; a near-tie may flip and the sequence then diverges -- the first tokens must agree for every sample
+        # (each path's picks are pinned to the f32 oracle below / in test_greedy_decode_matches_reference_token_ids)
         assert bool(same[:, :4].all()) and same.float().mean().item() > 0.5
     with torch.no_grad():
         ref = O.greedy_decode_recompute(sd, O.SwinCfg(), O.BertCfg(eos_token_id=-1), image[:4], max_len=6)
@@ -508,7 +555,14 @@ def test_decode_config4_full_size(M, monkeypatch, cd):
     if cd == F32:
         assert torch.equal(got, ref), (got, ref)
     else:
-        assert bool((got[:, :2] == ref[:, :2]).all()) and (got == ref).float().mean().item() >= 0.75, (got, ref)
+        # bf16: every one of the 24 picks is the f32 oracle's argmax on the generated prefix or a near-tie (teacher-forced)
+        with torch.no_grad():
+            exact, near, bad = _teacher_forced_picks_ok(O, sd, O.SwinCfg(), O.BertCfg(eos_token_id=-1), image[:4], got)
+        assert not bad, (bad, got, ref)
+        assert bool((got[:, 0] == ref[:, 0]).all()) and exact >= 4 * near, (exact, near, got, ref)
+        with torch.no_grad():          # the eager per-token loop (bf16-rounded logits) is pinned the same way
+            exact, near, bad = _teacher_forced_picks_ok(O, sd, O.SwinCfg(), O.BertCfg(eos_token_id=-1), image[:4], outs["0"][:4, :6])
+        assert not bad and exact >= 4 * near, (bad, exact, near)
 
 
 def test_sample_mode_decoding(M, specs_hash):
