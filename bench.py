@@ -290,9 +290,9 @@ def one_rank_rccl(steps=40, warmup=10):
 
 def profiled_traffic(key):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (cannot be collected inside this
-    process): profiles/r4_dominant_kernel_traffic.json {"family": {...}, "wgrad_group": {...}}, filled in from the
+    process): profiles/r5_dominant_kernel_traffic.json {"family": {...}, "wgrad_group": {...}}, filled in from the
     scripts/pmc.py passes over scripts/profile_step.py (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)."""
-    name = "profiles/r4_dominant_kernel_traffic.json"
+    name = "profiles/r5_dominant_kernel_traffic.json"
     try:
         with open(os.path.join(ROOT, name)) as fh:
             d = json.load(fh)
