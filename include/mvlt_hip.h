@@ -36,12 +36,12 @@ enum { MVLT_OK = 0, MVLT_ERR_ARG = -1, MVLT_ERR_LAUNCH = -2, MVLT_ERR_UNSUPPORTE
  * signature; a binding compiles / hard-codes the value it was written against and compares it with what the
  * loaded library returns.  mvlt_sizeof(MVLT_STRUCT_*) lets a binding that mirrors the structs by hand (ctypes,
  * cgo, JNI) prove that its mirror has the size the library was compiled with (0 for an unknown id). */
-#define MVLT_ABI_VERSION 6
+#define MVLT_ABI_VERSION 7
 int mvlt_version(void);            /* MVLT_ABI_VERSION of the loaded library */
 const char* mvlt_arch(void);       /* "gfx950" */
 enum { MVLT_STRUCT_GEMM = 0, MVLT_STRUCT_LAYERNORM = 1, MVLT_STRUCT_LAYERNORM_BWD = 2, MVLT_STRUCT_LN_REDUCE_ITEM = 3,
        MVLT_STRUCT_ATTN = 4, MVLT_STRUCT_SWIN_WMSA = 5, MVLT_STRUCT_EMBED = 6, MVLT_STRUCT_ATTN_CACHED = 7,
-       MVLT_STRUCT_ZERO_ITEM = 8, MVLT_STRUCT_RANGE = 9, MVLT_STRUCT_MLM_MASK = 10, MVLT_STRUCT_COUNT = 11 };
+       MVLT_STRUCT_ZERO_ITEM = 8, MVLT_STRUCT_RANGE = 9, MVLT_STRUCT_MLM_MASK = 10, MVLT_STRUCT_GREEDY_STATE = 11, MVLT_STRUCT_COUNT = 12 };
 size_t mvlt_sizeof(int struct_id);
 
 /* ------------------------------------------------------------------ GEMM
@@ -118,6 +118,20 @@ size_t mvlt_gemm_group_workspace_bytes(const MvltGemm* items, int n);
  * part_val / part_idx: scratch, M * ceil(N / 16) elements each. */
 int mvlt_gemm_argmax(const MvltGemm* p, float* part_val, int32_t* part_idx, int64_t* out_idx, float* out_val,
                      void* stream);
+/* The same product with the per-token bookkeeping of greedy_search (model.py:896-913) in the finishing launch, all on the
+ * device: next = argmax; samples that have finished emit pad_id; unfinished[m] &= (next != eos_id); ids[m, *col] = next;
+ * scores[m, *col] = the maximum logit; new_ids[m, 0] = next (the first of the two ids the next cached step feeds);
+ * alive[*col] is raised to 1 by every sample that is still unfinished (the caller zeroes `alive` when a decode starts);
+ * *past += 1 (optional); *col += 1.  One launch (a workgroup per row; the last one to arrive -- `ticket`, an int32 the caller
+ * zeroes once -- advances col / past) instead of the argmax finish + ten one-line kernels per replayed decode step.
+ * has_eos = 0: no EOS handling (unfinished / alive unused). */
+typedef struct MvltGreedyState {
+    int64_t* unfinished; int64_t eos_id, pad_id; int has_eos;
+    int64_t* col; int32_t* past;
+    int64_t* ids; int64_t ld_ids; float* scores; int64_t ld_scores; int64_t* alive; int64_t* new_ids; int64_t ld_new;
+    int32_t* ticket;
+} MvltGreedyState;
+int mvlt_gemm_argmax_greedy(const MvltGemm* p, float* part_val, int32_t* part_idx, const MvltGreedyState* g, void* stream);
 
 /* Decode step (model.py:82-108: 2 new tokens per sample): skinny product with the reduction split over workgroups,
  * acc[M,N] (f32, row stride N) += A[M,K] B[N,K]^T, M <= 64, both operands k-contiguous, no epilogue; k_splits

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmvlt_hip.so")
 
 F32, BF16 = 0, 1
 OK = 0
-ABI_VERSION = 6          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
+ABI_VERSION = 7          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
 ERRORS = {-1: "MVLT_ERR_ARG", -2: "MVLT_ERR_LAUNCH", -3: "MVLT_ERR_UNSUPPORTED"}
 
 EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_DROPOUT = 1, 2, 4, 8
@@ -109,6 +109,12 @@ class MvltMlmMask(C.Structure):
                 ("ids_in", vp), ("full_len", vp), ("itm_label", vp), ("ids_out", vp), ("labels", vp), ("seed", u64)]
 
 
+class MvltGreedyState(C.Structure):
+    _fields_ = [("unfinished", vp), ("eos_id", i64), ("pad_id", i64), ("has_eos", i32),
+                ("col", vp), ("past", vp), ("ids", vp), ("ld_ids", i64), ("scores", vp), ("ld_scores", i64),
+                ("alive", vp), ("new_ids", vp), ("ld_new", i64), ("ticket", vp)]
+
+
 # every symbol include/mvlt_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mvlt_version": (i32, []),
@@ -120,6 +126,7 @@ SYMBOLS = {
     "mvlt_gemm_group": (i32, [C.POINTER(MvltGemm), i32, vp]),
     "mvlt_gemm_group_workspace_bytes": (sz, [C.POINTER(MvltGemm), i32]),
     "mvlt_gemm_argmax": (i32, [C.POINTER(MvltGemm), vp, vp, vp, vp, vp]),
+    "mvlt_gemm_argmax_greedy": (i32, [C.POINTER(MvltGemm), vp, vp, C.POINTER(MvltGreedyState), vp]),
     "mvlt_gemm_skinny_accum": (i32, [C.POINTER(MvltGemm), vp, i32, vp]),
     "mvlt_layernorm_acc_fwd": (i32, [i32, vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
     "mvlt_colsum": (i32, [i32, vp, i64, i32, i32, vp, i32, vp, vp]),
@@ -172,7 +179,7 @@ SYMBOLS = {
 
 # ctypes mirror of every struct, in the order of the MVLT_STRUCT_* ids of the header
 STRUCTS = [MvltGemm, MvltLayerNorm, MvltLayerNormBwd, MvltLnReduceItem, MvltAttn, MvltSwinWmsa, MvltEmbed,
-           MvltAttnCached, MvltZeroItem, MvltRange, MvltMlmMask]
+           MvltAttnCached, MvltZeroItem, MvltRange, MvltMlmMask, MvltGreedyState]
 
 _lib = None
 

@@ -664,6 +664,131 @@ __global__ __launch_bounds__(64) void argmax_parts_kernel(const float* part_val,
     if (threadIdx.x == 0) { out_idx[blockIdx.x] = bi; if (out_val) out_val[blockIdx.x] = best; }
 }
 
+// Decoder GEMM of the last-row MLM head fused with the greedy pick, wide form (round 5): a workgroup = 128 vocabulary columns,
+// wave w = columns 16 w .. +16 over the WHOLE reduction -- no k-split across waves, so no LDS reduction and no barrier; the
+// 47 MB weight matrix is streamed once by 239 workgroups (one per CU) with UNR k-blocks in flight per wave, the 32-64
+// activation rows come from L1 / L2.  The 16-column form above launches 1,908 workgroups that each re-read the whole
+// activation matrix and meet in LDS: 29 us for a product whose bytes take 9 us.  Same partial layout (one (max, index) per row
+// and 16 columns), so the finishing kernel is shared.
+template <typename T, int NRT>
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_argmax128_kernel(const GemmDev p, const ArgmaxOut am, int nparts) {
+    using M_ = Mma<T>;
+    using Frag = typename M_::Frag;
+    constexpr int KB = M_::KB, E = TypeInfo<T>::E, UNR = NRT <= 2 ? 12 : 8;          // k-blocks in flight per wave (12 KB of weights; K = 768 in two rounds)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), r15 = lane & 15, g = lane >> 4;
+    const int n0 = (blockIdx.x * SKINNY_WAVES + wave) * 16;
+    if (n0 >= p.N) return;
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* brow = reinterpret_cast<const T*>(p.B) + (long)min(n0 + r15, p.N - 1) * p.ldb + g * E;
+    const T* arow[NRT];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) arow[i] = A + (long)min(16 * i + r15, p.M - 1) * p.lda + g * E;
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkb = p.K / KB;
+    for (int kb0 = 0; kb0 < nkb; kb0 += UNR) {
+        Frag fb[UNR], fa[UNR][NRT];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int k = min(kb0 + u, nkb - 1) * KB;          // past the end: reload the last block, never multiplied
+            fb[u] = *reinterpret_cast<const Frag*>(brow + k);
+#pragma unroll
+            for (int i = 0; i < NRT; ++i) fa[u][i] = *reinterpret_cast<const Frag*>(arow[i] + k);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (kb0 + u < nkb) {
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) M_::mma(acc[i], fb[u], fa[u][i]);
+            }
+        }
+    }
+    // acc[i][r] <-> n = n0 + 4 g + r, m = 16 i + r15
+    f32x4 bias4{0.f, 0.f, 0.f, 0.f};
+    if (p.epi & MVLT_EPI_BIAS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[r] = p.bias[min(n0 + 4 * g + r, p.N - 1)];
+    }
+    const int part = blockIdx.x * SKINNY_WAVES + wave;
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+        float best = -3.0e38f; int bi = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 4 * g + r;
+            const float x = acc[i][r] + bias4[r];
+            if (n < p.N && x > best) { best = x; bi = n; }          // ascending n: ties keep the first index
+        }
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        const int m = 16 * i + r15;
+        if (g == 0 && m < p.M) { am.part_val[(long)m * nparts + part] = best; am.part_idx[(long)m * nparts + part] = bi; }
+    }
+}
+
+// Finish of the greedy pick for ALL rows in one workgroup, with the per-token bookkeeping of greedy_search (model.py:896-913)
+// folded in: next = argmax; finished samples emit PAD; unfinished &= (next != EOS); ids[:, col] = next; scores[:, col] = max
+// logit; new_ids[:, 0] = next (the first of the two tokens the next cached step feeds); alive[col] = any sample unfinished;
+// past += 1 (the cache position the NEXT forward reads: the previous step's [MASK] slot is overwritten); col += 1.
+// Replaces argmax_parts_kernel + ten one-line torch kernels per replayed decode step.  M <= 64; 16 waves, wave w = rows w, w + 16, ...
+struct GreedyState {
+    int64_t* unfinished; int64_t eos, pad; int has_eos;
+    int64_t* col; int32_t* past;
+    int64_t* ids; long ld_ids; float* scores; long ld_scores; int64_t* alive; int64_t* new_ids; long ld_new;
+    int32_t* ticket;
+};
+// One workgroup per row (256 threads: ~8 partials per thread, one memory round trip; a single workgroup walking all rows took
+// 26 us).  alive[col] is raised with an atomic max by the rows that are still unfinished (the caller zeroes `alive` when a
+// decode starts); the LAST workgroup to arrive (ticket) advances col and past and re-arms the ticket.  Every workgroup reads
+// col before it draws its ticket, and col is written only after all tickets are drawn.
+__global__ __launch_bounds__(256) void greedy_pick_kernel(const float* part_val, const int* part_idx, int nparts, int M, const GreedyState st) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = blockIdx.x;
+    const long col = st.col[0];
+    const long base = (long)m * nparts;
+    float best = -3.0e38f; int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        const float v = part_val[base + i]; const int idx = part_idx[base + i];
+        if (v > best || (v == best && idx < bi)) { best = v; bi = idx; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ov = s_val[w]; const int oi = s_idx[w];
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        int64_t nxt = bi;
+        if (st.has_eos) {
+            const int64_t unf = st.unfinished[m];
+            nxt = nxt * unf + st.pad * (1 - unf);
+            const int64_t unf2 = unf * (nxt != st.eos ? 1 : 0);
+            st.unfinished[m] = unf2;
+            if (unf2) atomicMax(reinterpret_cast<unsigned long long*>(st.alive + col), 1ULL);
+        }
+        st.ids[(long)m * st.ld_ids + col] = nxt;
+        st.scores[(long)m * st.ld_scores + col] = best;
+        st.new_ids[(long)m * st.ld_new] = nxt;
+        __threadfence();
+        if (atomicAdd(st.ticket, 1) == M - 1) {
+            *st.ticket = 0;
+            st.col[0] = col + 1;
+            if (st.past) st.past[0] += 1;
+        }
+    }
+}
+
 // Several independent products in one launch (the weight gradients of one layer): the tile lists of the
 // items are concatenated, a workgroup finds its item by a scan of the (<= 8) prefix counts.
 constexpr int GROUP_MAX = 8;
@@ -1107,6 +1232,22 @@ extern "C" int mvlt_gemm_group(const MvltGemm* items, int n, void* stream) {
     return MVLT_ERR_UNSUPPORTED;
 }
 
+// the (max, index) partials per row and 16 columns: wide streaming form for big vocabularies, else the 16-column skinny kernel
+template <typename T>
+static void argmax_products(const MvltGemm* p, const GemmDev& d, float* part_val, int32_t* part_idx, int nblk, hipStream_t s) {
+    const bool vec = (p->lda % TypeInfo<T>::E == 0) && (p->ldb % TypeInfo<T>::E == 0) && aligned16(p->A) && aligned16(p->B);
+    if (vec && p->N >= 4096 && p->K % Mma<T>::KB == 0) {
+        const dim3 grid(ceil_div(nblk, SKINNY_WAVES)), block(64 * SKINNY_WAVES);
+        const ArgmaxOut am{part_val, part_idx};
+        if (p->M <= 16) hipLaunchKernelGGL((gemm_argmax128_kernel<T, 1>), grid, block, 0, s, d, am, nblk);
+        else if (p->M <= 32) hipLaunchKernelGGL((gemm_argmax128_kernel<T, 2>), grid, block, 0, s, d, am, nblk);
+        else if (p->M <= 48) hipLaunchKernelGGL((gemm_argmax128_kernel<T, 3>), grid, block, 0, s, d, am, nblk);
+        else hipLaunchKernelGGL((gemm_argmax128_kernel<T, 4>), grid, block, 0, s, d, am, nblk);
+        return;
+    }
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, true>), dim3(nblk), dim3(64 * SKINNY_WAVES), 0, s, d, ArgmaxOut{part_val, part_idx});
+}
+
 template <typename T>
 static int gemm_argmax_dispatch(const MvltGemm* p, float* part_val, int32_t* part_idx, int64_t* out_idx, float* out_val,
                                 hipStream_t s) {
@@ -1117,7 +1258,7 @@ static int gemm_argmax_dispatch(const MvltGemm* p, float* part_val, int32_t* par
     Plan pl{64, 16, 1};
     { const int rc = fill_dev<T>(p, pl, d); if (rc != MVLT_OK) return rc; }
     const int nblk = ceil_div(p->N, 16);
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, true>), dim3(nblk), dim3(64 * SKINNY_WAVES), 0, s, d, ArgmaxOut{part_val, part_idx});
+    argmax_products<T>(p, d, part_val, part_idx, nblk, s);
     hipLaunchKernelGGL(argmax_parts_kernel, dim3(p->M), dim3(64), 0, s, part_val, part_idx, nblk, out_idx, out_val);
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
@@ -1132,6 +1273,27 @@ extern "C" int mvlt_gemm_argmax(const MvltGemm* p, float* part_val, int32_t* par
     if (p->dtype == MVLT_F32) return gemm_argmax_dispatch<float>(p, part_val, part_idx, out_idx, out_val, s);
     if (p->dtype == MVLT_BF16) return gemm_argmax_dispatch<bf16_t>(p, part_val, part_idx, out_idx, out_val, s);
     return MVLT_ERR_UNSUPPORTED;
+}
+
+extern "C" int mvlt_gemm_argmax_greedy(const MvltGemm* p, float* part_val, int32_t* part_idx, const MvltGreedyState* g, void* stream) {
+    MVLT_CHECK(p && p->A && p->B && part_val && part_idx && g, MVLT_ERR_ARG);
+    MVLT_CHECK(p->M > 0 && p->M <= 64 && p->N > 0 && p->K > 0 && p->lda > 0 && p->ldb > 0, MVLT_ERR_ARG);
+    MVLT_CHECK(!p->a_kmajor && !p->b_kmajor && (p->epilogue & ~(MVLT_EPI_BIAS)) == 0, MVLT_ERR_UNSUPPORTED);
+    if (p->epilogue & MVLT_EPI_BIAS) MVLT_CHECK(p->bias, MVLT_ERR_ARG);
+    MVLT_CHECK(g->col && g->ticket && g->ids && g->scores && g->new_ids && g->ld_ids > 0 && g->ld_scores > 0 && g->ld_new > 0, MVLT_ERR_ARG);
+    if (g->has_eos) MVLT_CHECK(g->unfinished && g->alive, MVLT_ERR_ARG);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    GemmDev d;
+    Plan pl{64, 16, 1};
+    const int nblk = ceil_div(p->N, 16);
+    if (p->dtype == MVLT_BF16) { const int rc = fill_dev<bf16_t>(p, pl, d); if (rc != MVLT_OK) return rc; argmax_products<bf16_t>(p, d, part_val, part_idx, nblk, s); }
+    else if (p->dtype == MVLT_F32) { const int rc = fill_dev<float>(p, pl, d); if (rc != MVLT_OK) return rc; argmax_products<float>(p, d, part_val, part_idx, nblk, s); }
+    else return MVLT_ERR_UNSUPPORTED;
+    GreedyState st{g->unfinished, g->eos_id, g->pad_id, g->has_eos, g->col, g->past, g->ids, g->ld_ids, g->scores, g->ld_scores, g->alive,
+                   g->new_ids, g->ld_new, g->ticket};
+    hipLaunchKernelGGL(greedy_pick_kernel, dim3(p->M), dim3(256), 0, s, part_val, part_idx, nblk, p->M, st);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
 }
 
 extern "C" int mvlt_gemm_skinny_accum(const MvltGemm* p, float* acc, int k_splits, void* stream) {

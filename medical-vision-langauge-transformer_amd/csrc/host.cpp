@@ -545,6 +545,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         return std::vector<int64_t>{(int64_t)sizeof(MvltGemm), (int64_t)sizeof(MvltLayerNorm), (int64_t)sizeof(MvltLayerNormBwd),
                                     (int64_t)sizeof(MvltLnReduceItem), (int64_t)sizeof(MvltAttn), (int64_t)sizeof(MvltSwinWmsa),
                                     (int64_t)sizeof(MvltEmbed), (int64_t)sizeof(MvltAttnCached), (int64_t)sizeof(MvltZeroItem),
-                                    (int64_t)sizeof(MvltRange), (int64_t)sizeof(MvltMlmMask)};
+                                    (int64_t)sizeof(MvltRange), (int64_t)sizeof(MvltMlmMask), (int64_t)sizeof(MvltGreedyState)};
     });
 }

@@ -716,6 +716,7 @@ extern "C" size_t mvlt_sizeof(int struct_id) {
         case MVLT_STRUCT_ZERO_ITEM: return sizeof(MvltZeroItem);
         case MVLT_STRUCT_RANGE: return sizeof(MvltRange);
         case MVLT_STRUCT_MLM_MASK: return sizeof(MvltMlmMask);
+        case MVLT_STRUCT_GREEDY_STATE: return sizeof(MvltGreedyState);
         default: return 0;
     }
 }

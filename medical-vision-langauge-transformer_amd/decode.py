@@ -20,6 +20,7 @@ import os
 
 import torch
 
+from . import _lib as L
 from . import ops
 from .arena import Arena
 from .bert import EncoderOutput
@@ -32,8 +33,8 @@ _SKINNY_SPLIT = os.environ.get("MVLT_DETERMINISTIC", "0") != "1"
 _SPLITS = (2, 4)      # reduction splits of (attention output, FFN-out) projections: the fastest of the round-2 sweep
 
 
-def _layers_cached(mv, ar, x, kc, vc, past, n_new):
-    """x: [B*n_new, H] embeddings of the new tokens -> last hidden [B*n_new, H]."""
+def _layers_cached(mv, ar, x, kc, vc, past, n_new, out_last=None):
+    """x: [B*n_new, H] embeddings of the new tokens -> last hidden [B*n_new, H] (written into ``out_last`` when given)."""
     cfg = mv.config
     H = cfg.hidden_size
     nH = cfg.num_attention_heads
@@ -50,7 +51,9 @@ def _layers_cached(mv, ar, x, kc, vc, past, n_new):
             acc = ar._views[key] = torch.zeros((rows, H), dtype=torch.float32, device=x.device)
         elif not torch.cuda.is_current_stream_capturing():
             acc.zero_()          # a step that aborted between an accumulate and its LayerNorm left partial sums behind
+    nl = len(mv.encoder.layer)
     for i, layer in enumerate(mv.encoder.layer):
+        last_out = out_last if i == nl - 1 else None
         sa, so = layer.attention.self, layer.attention.output
         qkv = ops.gemm(x, ar.compute(sa.query.weight, 3 * H), bias=ar.master_span(sa.query.bias, 3 * H))
         ctx = ops.attn_cached(qkv, kc[i], vc[i], past, (H // nH) ** -0.5)
@@ -67,11 +70,11 @@ def _layers_cached(mv, ar, x, kc, vc, past, n_new):
         if split:
             ops.gemm_skinny_accum(a, ar.compute(lo.dense.weight), acc, _SPLITS[1])
             x = ops.layernorm_acc_fwd(acc, lo.dense.bias.data, x1, lo.LayerNorm.weight.data, lo.LayerNorm.bias.data,
-                                      lo.LayerNorm.eps, x1.dtype)
+                                      lo.LayerNorm.eps, x1.dtype, out=last_out)
         else:
             y2 = ops.gemm(a, ar.compute(lo.dense.weight), bias=lo.dense.bias.data, residual=x1)
             x, _, _, _ = ops.layernorm_fwd(y2, lo.LayerNorm.weight.data, lo.LayerNorm.bias.data, lo.LayerNorm.eps,
-                                           save_stats=False)
+                                           save_stats=False, out=last_out)
     return x
 
 
@@ -152,39 +155,41 @@ class _GreedyGraph:
         self.past = torch.zeros(1, dtype=torch.int32, device=dev)
         self.col = torch.zeros(1, dtype=torch.int64, device=dev)
         self.new_ids = torch.full((B, 2), mask_id, dtype=torch.int64, device=dev)       # [last token, MASK]
-        self.hlast = torch.zeros((B, H), dtype=cd, device=dev)
+        # last hidden states of the two new tokens of every sample; the MLM head reads the [MASK] rows in place (row stride 2 H)
+        self.hfull = torch.zeros((B * 2, H), dtype=cd, device=dev)
+        self.hlast = self.hfull.view(B, 2, H)[:, 1]
         self.unfinished = torch.ones(B, dtype=torch.int64, device=dev)
         self.ids = torch.zeros((B, max_length), dtype=torch.int64, device=dev)
         self.scores = torch.zeros((B, max_length), dtype=torch.float32, device=dev)
         self.alive = torch.ones(max_length, dtype=torch.int64, device=dev)
         self.cd, self.graph = cd, None
+        # device-side state of the greedy loop, handed to mvlt_gemm_argmax_greedy: the pick, PAD for finished samples, the
+        # EOS flags, the ids / scores columns, the next input id, `past` and `col` are all advanced by its finishing launch
+        st = self.state = L.MvltGreedyState()
+        st.unfinished, st.eos_id, st.pad_id, st.has_eos = self.unfinished.data_ptr(), (eos if eos is not None else -1), pad, int(eos is not None)
+        st.col, st.past = self.col.data_ptr(), self.past.data_ptr()
+        st.ids, st.ld_ids, st.scores, st.ld_scores = self.ids.data_ptr(), max_length, self.scores.data_ptr(), max_length
+        st.alive, st.new_ids, st.ld_new = self.alive.data_ptr(), self.new_ids.data_ptr(), 2
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        st.ticket = self.ticket.data_ptr()
 
     def head(self):
-        """token <- argmax(MLM head(hlast)); record it in column `col`."""
+        """token <- argmax(MLM head(hlast)); record it in column `col`; past += 1; col += 1 (all on the device)."""
         model = self.model
         ar = Arena.of(model, self.cd)
         hd = model.MLM_head_seq2seq
         _, _, t2, _, _ = hd._transform(ar, self.hlast, False)
-        # decoder GEMM fused with the greedy pick: the [B, 30522] logits are never written
-        nxt, score = ops.gemm_argmax(t2, ar.compute(hd.predictions.decoder.weight), hd.predictions.decoder.bias.data)
-        if self.eos is not None:
-            nxt = nxt * self.unfinished + self.pad * (1 - self.unfinished)
-            self.unfinished.mul_((nxt != self.eos).long())
-            self.alive.index_copy_(0, self.col, self.unfinished.max()[None])
-        self.ids.index_copy_(1, self.col, nxt[:, None])
-        self.scores.index_copy_(1, self.col, score[:, None])
-        self.new_ids[:, 0].copy_(nxt)
-        self.col.add_(1)
+        # decoder GEMM fused with the greedy pick and its bookkeeping: the [B, 30522] logits are never written
+        ops.gemm_argmax_greedy(t2, ar.compute(hd.predictions.decoder.weight), hd.predictions.decoder.bias.data, self.state)
 
     def forward2(self):
-        """2-token cached forward of [last token, MASK] at positions past, past+1 (model.py:82-108)."""
+        """2-token cached forward of [last token, MASK] at positions past, past+1 (model.py:82-108).  `past` was advanced by
+        the pick that produced the token: the previous step's [MASK] slot is overwritten (model.py:890-894)."""
         mv = self.model.MVLBert
         ar = Arena.of(self.model, self.cd)
         B, H = self.B, mv.config.hidden_size
         x = _embed_new(mv, self.new_ids, self.past, self.cd).view(B * 2, H)
-        h = _layers_cached(mv, ar, x, self.kc, self.vc, self.past, 2).view(B, 2, H)
-        self.hlast.copy_(h[:, -1])
-        self.past.add_(1)                        # the [MASK] slot is overwritten by the next step (model.py:890-894)
+        _layers_cached(mv, ar, x, self.kc, self.vc, self.past, 2, out_last=self.hfull)
 
     def capture(self):
         # scratch buffers (split-K workspace) used inside the graph get their own tag: the captured pointers must
@@ -220,7 +225,7 @@ def _greedy_graph_loop(model, feat, max_length, pad, eos, mask_id, cd):
     for i in range(nl):
         _fill_cache_from_qkv(saved["layers"][i][1], B, L0, nH, H // nH, gg.kc[i], gg.vc[i], L0 - 1)
     del saved
-    gg.past.fill_(L0 - 1); gg.col.zero_(); gg.unfinished.fill_(1); gg.alive.fill_(1)
+    gg.past.fill_(L0 - 2); gg.col.zero_(); gg.unfinished.fill_(1); gg.alive.zero_(); gg.ticket.zero_()      # (the first pick advances `past` to L0 - 1; the picks raise `alive`)
     gg.hlast.copy_(hidden[:, -1])
     done = 0
     for t in range(max_length - 1):

@@ -327,6 +327,28 @@ def gemm_argmax(A, W, bias=None):
     return idx, val
 
 
+def gemm_argmax_greedy(A, W, bias, state):
+    """Decoder GEMM + greedy pick + the per-token bookkeeping of greedy_search in two launches (mvlt_gemm_argmax_greedy).
+    A: [M <= 64, K] (rows may be strided), W: [N, K]; ``state``: a prepared ``L.MvltGreedyState`` (decode._GreedyGraph)."""
+    M, K = A.shape
+    N = W.shape[0]
+    p = L.MvltGemm()
+    p.dtype, p.M, p.N, p.K = _dt(A), M, N, K
+    p.A, p.lda, p.B, p.ldb = _p(A), A.stride(0), _p(W), _ld(W)
+    if bias is not None:
+        p.epilogue, p.bias = L.EPI_BIAS, _p(bias)
+    nblk = (N + 15) // 16
+    key = ("argmax_parts", M, nblk, A.device.index)
+    buf = _argmax_parts.get(key)
+    if buf is None:
+        buf = _argmax_parts[key] = (torch.empty((M, nblk), dtype=torch.float32, device=A.device),
+                                    torch.empty((M, nblk), dtype=torch.int32, device=A.device))
+    L.check(L.lib().mvlt_gemm_argmax_greedy(C.byref(p), _p(buf[0]), _p(buf[1]), C.byref(state), _stream()), "mvlt_gemm_argmax_greedy")
+
+
+_argmax_parts = {}
+
+
 def gemm_skinny_accum(A, W, acc, k_splits):
     """acc [M,N] f32 += A [M<=64, K] @ W[N,K]^T with the reduction split over k_splits workgroups per column tile."""
     _need_cuda(A, W)
