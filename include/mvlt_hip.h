@@ -133,11 +133,11 @@ typedef struct MvltGreedyState {
 } MvltGreedyState;
 int mvlt_gemm_argmax_greedy(const MvltGemm* p, float* part_val, int32_t* part_idx, const MvltGreedyState* g, void* stream);
 
-/* Decode step (model.py:82-108: 2 new tokens per sample): skinny product with the reduction split over workgroups,
- * acc[M,N] (f32, row stride N) += A[M,K] B[N,K]^T, M <= 64, both operands k-contiguous, no epilogue; k_splits
- * workgroups share every 16-column tile and meet in acc through atomicAdd.  Pair it with mvlt_layernorm_acc_fwd, which
- * applies bias + residual + LayerNorm (the BertSelfOutput / BertOutput tail, modeling_bert.py:282-293,340-351) and zeroes
- * acc again. */
+/* Decode step (model.py:82-108: 2 new tokens per sample): skinny product with the reduction split over workgroups:
+ * acc[s][M][N] (f32, k_splits slabs) = A[:, k-slice s] B[:, k-slice s]^T, M <= 64, both operands k-contiguous, no epilogue;
+ * k_splits workgroups share every 16-column tile, each WRITES the slab of its slice (plain stores: no float atomics, nothing
+ * to zero, bit-reproducible).  Pair it with mvlt_layernorm_acc_fwd(nsplit = k_splits), which adds the slabs in slice order
+ * and applies bias + residual + LayerNorm (the BertSelfOutput / BertOutput tail, modeling_bert.py:282-293,340-351). */
 int mvlt_gemm_skinny_accum(const MvltGemm* p, float* acc, int k_splits, void* stream);
 
 /* column sums: out[n] = sum_m x[m*ld + n]  (bias gradients), f32 out.
@@ -191,9 +191,9 @@ typedef struct MvltLayerNormBwd {
 } MvltLayerNormBwd;
 int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream);
 int mvlt_layernorm_bwd_workspace_rows(void);
-/* y[r,:] = LayerNorm(acc[r,:] + bias + residual[r,:]) * gamma + beta, rows <= a few hundred, C <= 2048; acc (f32) is
- * zeroed after it is read (see mvlt_gemm_skinny_accum).  residual may be NULL. */
-int mvlt_layernorm_acc_fwd(int dtype, float* acc, const float* bias, const void* residual, const float* gamma,
+/* y[r,:] = LayerNorm(sum_s acc[s][r,:] + bias + residual[r,:]) * gamma + beta, rows <= a few hundred, C <= 2048; acc = the
+ * nsplit slabs [nsplit][rows][C] (f32) of mvlt_gemm_skinny_accum (read only).  residual may be NULL. */
+int mvlt_layernorm_acc_fwd(int dtype, const float* acc, int nsplit, const float* bias, const void* residual, const float* gamma,
                            const float* beta, float eps, int rows, int C, void* y, void* stream);
 /* deferred parameter-gradient reduction: one launch per 24 LayerNorms instead of one per LayerNorm.
  * items is a HOST array; workspace = the buffer given to mvlt_layernorm_bwd, nparts = mvlt_layernorm_bwd_nparts(rows, C). */

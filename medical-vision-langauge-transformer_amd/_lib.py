@@ -128,7 +128,7 @@ SYMBOLS = {
     "mvlt_gemm_argmax": (i32, [C.POINTER(MvltGemm), vp, vp, vp, vp, vp]),
     "mvlt_gemm_argmax_greedy": (i32, [C.POINTER(MvltGemm), vp, vp, C.POINTER(MvltGreedyState), vp]),
     "mvlt_gemm_skinny_accum": (i32, [C.POINTER(MvltGemm), vp, i32, vp]),
-    "mvlt_layernorm_acc_fwd": (i32, [i32, vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
+    "mvlt_layernorm_acc_fwd": (i32, [i32, vp, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
     "mvlt_colsum": (i32, [i32, vp, i64, i32, i32, vp, i32, vp, vp]),
     "mvlt_colsum_workspace_rows": (i32, [i32]),
     "mvlt_layernorm_fwd": (i32, [C.POINTER(MvltLayerNorm), vp]),

@@ -592,9 +592,8 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Ge
 // Skinny product with K split over workgroups (decode: M = 2B rows, N = 768, K = 768 / 3072).  The plain skinny kernel
 // gives every 16-column workgroup the WHOLE activation matrix to read (N/16 x M x K bytes through L2: 48 x 393 KB for
 // the FFN-out product, 10 us per workgroup at the ~50 GB/s a CU takes in); here workgroup (j, s) reads only k-slice s
-// of it and adds its partial 64x16 tile into an f32 accumulator with atomicAdd.  No epilogue: the consumer
-// (mvlt_layernorm_acc_fwd: + bias + residual, LayerNorm, and it zeroes the accumulator again) is the launch that
-// follows anyway.
+// of it and writes its partial 64x16 tile into the slab of its slice.  No epilogue: the consumer
+// (mvlt_layernorm_acc_fwd: sum of the slices + bias + residual, LayerNorm) is the launch that follows anyway.
 template <typename T>
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_accum_kernel(const GemmDev p, float* accout) {
     using M_ = Mma<T>;
@@ -641,9 +640,13 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_accum_kernel(co
         f32x4 v = red[0][i][lane];
 #pragma unroll
         for (int w = 1; w < SKINNY_WAVES; ++w) v += red[w][i][lane];
-        float* c = accout + (long)(16 * i + r15) * p.N + n0 + 4 * g;
+        // slab of this k-slice: [gridDim.y][M][N] f32, written once with plain stores; the consumer (ln_acc_fwd_kernel) adds the
+        // slices in slice order -- no float atomics, no zeroing pass, bit-reproducible (round 5; the atomic form cost ~1 us more)
+        float* c = accout + ((long)blockIdx.y * p.M + 16 * i + r15) * p.N + n0 + 4 * g;
+        if (n0 + 4 * g + 4 <= p.N) store4f(c, v);
+        else
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (n0 + 4 * g + r < p.N) atomicAdd(c + r, v[r]);
+            for (int r = 0; r < 4; ++r) if (n0 + 4 * g + r < p.N) c[r] = v[r];
     }
 }
 

@@ -283,14 +283,15 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnRed
     }
 }
 
-// y = LayerNorm(acc + bias + residual) for a few rows (decode: 2B <= 64 rows), one wave per row; acc is the f32 output
-// of mvlt_gemm_skinny_accum and is ZEROED after it is read, ready for the next accumulation.
+// y = LayerNorm(sum_s acc[s] + bias + residual) for a few rows (decode: 2B <= 64 rows), one wave per row; acc holds the nsplit
+// k-slice slabs [nsplit][rows][C] (f32) of mvlt_gemm_skinny_accum, summed here in slice order (deterministic; nothing to zero).
 template <typename T>
-__global__ __launch_bounds__(256) void ln_acc_fwd_kernel(float* acc, const float* bias, const T* residual, const float* gamma,
+__global__ __launch_bounds__(256) void ln_acc_fwd_kernel(const float* acc, int nsplit, const float* bias, const T* residual, const float* gamma,
                                                         const float* beta, float eps, int rows, int C, T* y) {
     const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
-    float* a = acc + (long)r * C;
+    const float* a = acc + (long)r * C;
+    const long slab = (long)rows * C;
     constexpr int MAXV = 8;                           // C <= 2048
     f32x4 v[MAXV];
     float s = 0.f;
@@ -299,9 +300,10 @@ __global__ __launch_bounds__(256) void ln_acc_fwd_kernel(float* acc, const float
         const int c = 4 * (lane + 64 * j);
         v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < C) {
-            v[j] = load4f(a + c) + load4f(bias + c);
+            v[j] = load4f(a + c);
+            for (int sl = 1; sl < nsplit; ++sl) v[j] += load4f(a + sl * slab + c);
+            v[j] += load4f(bias + c);
             if (residual) v[j] += load4f(residual + (long)r * C + c);
-            store4f(a + c, f32x4{0.f, 0.f, 0.f, 0.f});
             s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
         }
     }
@@ -399,13 +401,13 @@ int dispatch(const LnDev& d, bool merge, hipStream_t s) {
 
 extern "C" int mvlt_layernorm_bwd_workspace_rows(void) { return LN_BWD_PARTS; }
 
-extern "C" int mvlt_layernorm_acc_fwd(int dtype, float* acc, const float* bias, const void* residual, const float* gamma,
+extern "C" int mvlt_layernorm_acc_fwd(int dtype, const float* acc, int nsplit, const float* bias, const void* residual, const float* gamma,
                                       const float* beta, float eps, int rows, int C, void* y, void* stream) {
-    MVLT_CHECK(acc && bias && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, MVLT_ERR_ARG);
+    MVLT_CHECK(acc && nsplit >= 1 && nsplit <= 64 && bias && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, MVLT_ERR_ARG);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(ceil_div(rows, 4));
-    if (dtype == MVLT_BF16) hipLaunchKernelGGL(ln_acc_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, acc, bias, (const bf16_t*)residual, gamma, beta, eps, rows, C, (bf16_t*)y);
-    else if (dtype == MVLT_F32) hipLaunchKernelGGL(ln_acc_fwd_kernel<float>, grid, dim3(256), 0, s, acc, bias, (const float*)residual, gamma, beta, eps, rows, C, (float*)y);
+    if (dtype == MVLT_BF16) hipLaunchKernelGGL(ln_acc_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, acc, nsplit, bias, (const bf16_t*)residual, gamma, beta, eps, rows, C, (bf16_t*)y);
+    else if (dtype == MVLT_F32) hipLaunchKernelGGL(ln_acc_fwd_kernel<float>, grid, dim3(256), 0, s, acc, nsplit, bias, (const float*)residual, gamma, beta, eps, rows, C, (float*)y);
     else return MVLT_ERR_UNSUPPORTED;
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;

@@ -27,9 +27,9 @@ from .bert import EncoderOutput
 from .runtime import compute_dtype_of
 
 
-# the split reductions meet in an f32 accumulator through atomicAdd (order not fixed: bf16 greedy decoding can flip a
-# near-tie between two runs); MVLT_DECODE_SPLITK=0 or MVLT_DETERMINISTIC=1 keep every reduction in one workgroup
-_SKINNY_SPLIT = os.environ.get("MVLT_DETERMINISTIC", "0") != "1"
+# the two N = H products of a decode layer split their reduction over workgroups; the k-slices meet in f32 slabs that the
+# LayerNorm launch behind them adds in slice order (round 5: no float atomics -- bf16 greedy decoding is reproducible run to run)
+_SKINNY_SPLIT = True
 _SPLITS = (2, 4)      # reduction splits of (attention output, FFN-out) projections: the fastest of the round-2 sweep
 
 
@@ -48,9 +48,7 @@ def _layers_cached(mv, ar, x, kc, vc, past, n_new, out_last=None):
         key = ("decode_acc", rows, H, x.device.index)
         acc = ar._views.get(key)
         if acc is None:
-            acc = ar._views[key] = torch.zeros((rows, H), dtype=torch.float32, device=x.device)
-        elif not torch.cuda.is_current_stream_capturing():
-            acc.zero_()          # a step that aborted between an accumulate and its LayerNorm left partial sums behind
+            acc = ar._views[key] = torch.empty((max(_SPLITS), rows, H), dtype=torch.float32, device=x.device)
     nl = len(mv.encoder.layer)
     for i, layer in enumerate(mv.encoder.layer):
         last_out = out_last if i == nl - 1 else None
@@ -58,8 +56,8 @@ def _layers_cached(mv, ar, x, kc, vc, past, n_new, out_last=None):
         qkv = ops.gemm(x, ar.compute(sa.query.weight, 3 * H), bias=ar.master_span(sa.query.bias, 3 * H))
         ctx = ops.attn_cached(qkv, kc[i], vc[i], past, (H // nH) ** -0.5)
         if split:
-            ops.gemm_skinny_accum(ctx, ar.compute(so.dense.weight), acc, _SPLITS[0])
-            x1 = ops.layernorm_acc_fwd(acc, so.dense.bias.data, x, so.LayerNorm.weight.data, so.LayerNorm.bias.data,
+            ops.gemm_skinny_accum(ctx, ar.compute(so.dense.weight), acc[:_SPLITS[0]], _SPLITS[0])
+            x1 = ops.layernorm_acc_fwd(acc[:_SPLITS[0]], so.dense.bias.data, x, so.LayerNorm.weight.data, so.LayerNorm.bias.data,
                                        so.LayerNorm.eps, x.dtype)
         else:
             y1 = ops.gemm(ctx, ar.compute(so.dense.weight), bias=so.dense.bias.data, residual=x)
@@ -68,8 +66,8 @@ def _layers_cached(mv, ar, x, kc, vc, past, n_new, out_last=None):
         a = ops.gemm(x1, ar.compute(layer.intermediate.dense.weight), bias=layer.intermediate.dense.bias.data, gelu=True)
         lo = layer.output
         if split:
-            ops.gemm_skinny_accum(a, ar.compute(lo.dense.weight), acc, _SPLITS[1])
-            x = ops.layernorm_acc_fwd(acc, lo.dense.bias.data, x1, lo.LayerNorm.weight.data, lo.LayerNorm.bias.data,
+            ops.gemm_skinny_accum(a, ar.compute(lo.dense.weight), acc[:_SPLITS[1]], _SPLITS[1])
+            x = ops.layernorm_acc_fwd(acc[:_SPLITS[1]], lo.dense.bias.data, x1, lo.LayerNorm.weight.data, lo.LayerNorm.bias.data,
                                       lo.LayerNorm.eps, x1.dtype, out=last_out)
         else:
             y2 = ops.gemm(a, ar.compute(lo.dense.weight), bias=lo.dense.bias.data, residual=x1)

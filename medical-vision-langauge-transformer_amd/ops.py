@@ -350,11 +350,12 @@ _argmax_parts = {}
 
 
 def gemm_skinny_accum(A, W, acc, k_splits):
-    """acc [M,N] f32 += A [M<=64, K] @ W[N,K]^T with the reduction split over k_splits workgroups per column tile."""
+    """acc[s] (f32 [k_splits, M, N]) = A[:, k-slice s] @ W[:, k-slice s]^T: the reduction split over k_splits workgroups per
+    column tile, every slice in a slab of its own (no atomics; layernorm_acc_fwd adds them in slice order)."""
     _need_cuda(A, W)
     M, K = A.shape
     N = W.shape[0]
-    assert acc.dtype == torch.float32 and acc.shape == (M, N) and acc.is_contiguous() and A.stride(1) == 1 and W.stride(1) == 1
+    assert acc.dtype == torch.float32 and acc.shape == (k_splits, M, N) and acc.is_contiguous() and A.stride(1) == 1 and W.stride(1) == 1
     p = L.MvltGemm()
     p.dtype, p.M, p.N, p.K = _dt(A), M, N, K
     p.A, p.lda, p.B, p.ldb = A.data_ptr(), _ld(A), W.data_ptr(), _ld(W)
@@ -363,20 +364,21 @@ def gemm_skinny_accum(A, W, acc, k_splits):
 
 
 def layernorm_acc_fwd(acc, bias, residual, gamma, beta, eps, dtype, out=None):
-    """LayerNorm(acc + bias + residual); acc (f32 [rows, C]) is zeroed by the kernel after it is read."""
-    rows, Cn = acc.shape
+    """LayerNorm(sum_s acc[s] + bias + residual); acc: the f32 slabs [nsplit, rows, C] of gemm_skinny_accum."""
+    nsplit, rows, Cn = acc.shape
     y = out if out is not None else torch.empty((rows, Cn), dtype=dtype, device=acc.device)
-    L.check(L.lib().mvlt_layernorm_acc_fwd(_DT[dtype], _p(acc), _p(bias), _p(residual), _p(gamma), _p(beta), float(eps),
+    L.check(L.lib().mvlt_layernorm_acc_fwd(_DT[dtype], _p(acc), int(nsplit), _p(bias), _p(residual), _p(gamma), _p(beta), float(eps),
                                            rows, Cn, _p(y), _stream()), "mvlt_layernorm_acc_fwd")
     return y
 
 
 _GROUP_LONG_K = 8192
 # MVLT_DETERMINISTIC=1: no float-atomic k-slices in the GEMM path (the 4-wave fallback of the Swin stage-0/1 weight
-# gradients takes split-K slabs + the deterministic reduce; greedy decoding does not split its reductions).  Still
+# gradients takes split-K slabs + the deterministic reduce).  Greedy decoding needs no flag since round 5: its split
+# reductions meet in slabs summed in slice order.  Still
 # accumulated with float atomics under the flag: the relative-position-bias-table gradient (swin_attn_bwd2_kernel) and the
 # word-embedding gradient (embed_bwd); tests/test_model_gpu.py::test_config2_step_is_bit_reproducible_* lists them.  The
-# flag is read once at import (decode.py too): set it before importing the package.
+# flag is read once at import: set it before importing the package.
 DETERMINISTIC = os.environ.get("MVLT_DETERMINISTIC", "0") == "1"
 
 
