@@ -1019,7 +1019,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
     const bool ak = p->a_kmajor != 0, bk = p->b_kmajor != 0;
     if constexpr (sizeof(T) == 2) {
         // weight-stationary row streaming for the HBM-bound Swin stage-0 / 1 products (100 k / 25 k rows, K, N <= 384)
-        if (!ak && d.split_k <= 1 && p->M >= 24576 && p->N <= 768 && p->K <= 384) {
+        if (!ak && d.split_k <= 1 && p->M >= 16384 && p->N <= 768 && p->K <= 384) {
             const int rcs = mvlt_rowstream_try(&d, bk ? 1 : 0, s);
             if (rcs < 0) return MVLT_ERR_LAUNCH;
             if (rcs > 0) {

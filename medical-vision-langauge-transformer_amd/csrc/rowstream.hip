@@ -265,14 +265,14 @@ int rs_launch(const RsArgs& a, hipStream_t s) {
 }  // namespace
 
 // Launcher used by gemm.hip's dispatch: 1 = taken, 0 = not eligible (the tile kernels run), -1 = launch error.
-// Eligible: bf16, A [M, K] contiguous rows (lda == K), one of the Swin stage-0 / 1 shapes below, at least `min_rows` rows
-// (fewer leave the 256 persistent workgroups without work: the tile kernels win), 16-byte aligned operands, an epilogue made of
+// Eligible: bf16, A [M, K] contiguous rows (lda == K), one of the Swin stage-0 / 1 shapes below, enough rows (fewer leave the
+// 256 persistent workgroups without work: the tile kernels win), 16-byte aligned operands, an epilogue made of
 // bias / GELU (+ saved pre-activation) / DropPath row scale / gelu' operand / residual only.
 extern "C" __attribute__((visibility("hidden"))) int mvlt_rowstream_try(const void* dev_block, int b_kmajor, void* stream) {
     const GemmDev& d = *reinterpret_cast<const GemmDev*>(dev_block);
     constexpr int ALLOWED = MVLT_EPI_BIAS | MVLT_EPI_GELU | MVLT_EPI_SAVE_PRE | MVLT_EPI_ROWSCALE | MVLT_EPI_MUL_GELU_GRAD | MVLT_EPI_RESIDUAL;
     if ((d.epi & ~ALLOWED) || d.m_dev || d.split_k > 1 || d.a_colsum || d.a_kmajor) return 0;
-    if (d.lda != d.K || d.ldc != d.N || !d.a_vec || !d.b_vec || !d.epi_vec || d.M < 24576) return 0;
+    if (d.lda != d.K || d.ldc != d.N || !d.a_vec || !d.b_vec || !d.epi_vec || d.M < 16384) return 0;
     if ((d.epi & MVLT_EPI_BIAS) && !aligned16(d.bias)) return 0;
     if ((d.epi & MVLT_EPI_MUL_GELU_GRAD) && (d.epi & MVLT_EPI_RESIDUAL)) return 0;
     if ((d.epi & MVLT_EPI_ROWSCALE) && (d.rps < 16 || d.rps % 16)) return 0;
@@ -287,6 +287,9 @@ extern "C" __attribute__((visibility("hidden"))) int mvlt_rowstream_try(const vo
     // by the dozen products per step whose shape got this far (the tests switch shapes on and off inside one process).
     const char* env = getenv("MVLT_ROWSTREAM");
     const unsigned mask = env ? (unsigned)strtoul(env, nullptr, 0) : RS_DEFAULT_MASK;
+    // default routing only from 49,152 rows (stage 0 at B >= 16: at least four 32-row stages per workgroup behind the
+    // weight-to-register prologue; measured at 100,352 rows); an explicit mask (tests, experiments) routes from 16,384 rows
+    if (!env && d.M < 49152) return 0;
     auto on = [&](int bit) { return (mask >> bit) & 1u; };
     if (!b_kmajor) {
         if (K == 96 && N == 384 && !x2 && on(0)) return rs_launch<96, 384, 4, false, false>(a, s);

@@ -19,7 +19,7 @@ cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/r5_bench_kernel_stats
 cd /tmp
 PACK=0 MLM_CAP=0 STEPS=10 WARM=5 rocprofv3 --kernel-trace -d $O/step -o s --output-format csv -- python3 $R/scripts/profile_step.py > $O/step.log 2>&1
 cd $R
-python scripts/step_kernels.py $O/step 10 70 > $O/r5_step_kernels.txt
+python scripts/step_kernels.py $O/step 25 70 > $O/r5_step_kernels.txt
 PACK=0 MLM_CAP=0 STAMPS=1 STEPS=3 WARM=10 python scripts/profile_step.py 2>&1 | grep -v "^[WE]2026\|amdgpu.ids" > $O/r5_step_phases.txt
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/dec -o d --output-format csv -- python3 $R/scripts/bench_decode.py > $O/decode.log 2>&1 || true
