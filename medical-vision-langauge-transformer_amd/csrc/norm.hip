@@ -285,7 +285,9 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnRed
 
 // y = LayerNorm(sum_s acc[s] + bias + residual) for a few rows (decode: 2B <= 64 rows), one wave per row; acc holds the nsplit
 // k-slice slabs [nsplit][rows][C] (f32) of mvlt_gemm_skinny_accum, summed here in slice order (deterministic; nothing to zero).
-template <typename T>
+// NS > 0: the slice count at compile time (all slab loads of a row are independent and go out together: one memory round trip);
+// NS = 0: any count, slice by slice.
+template <typename T, int NS>
 __global__ __launch_bounds__(256) void ln_acc_fwd_kernel(const float* acc, int nsplit, const float* bias, const T* residual, const float* gamma,
                                                         const float* beta, float eps, int rows, int C, T* y) {
     const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -300,8 +302,17 @@ __global__ __launch_bounds__(256) void ln_acc_fwd_kernel(const float* acc, int n
         const int c = 4 * (lane + 64 * j);
         v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < C) {
-            v[j] = load4f(a + c);
-            for (int sl = 1; sl < nsplit; ++sl) v[j] += load4f(a + sl * slab + c);
+            if constexpr (NS > 0) {
+                f32x4 part[NS];
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) part[sl] = load4f(a + sl * slab + c);
+                v[j] = part[0];
+#pragma unroll
+                for (int sl = 1; sl < NS; ++sl) v[j] += part[sl];          // slice order: the same sum whatever NS path runs
+            } else {
+                v[j] = load4f(a + c);
+                for (int sl = 1; sl < nsplit; ++sl) v[j] += load4f(a + sl * slab + c);
+            }
             v[j] += load4f(bias + c);
             if (residual) v[j] += load4f(residual + (long)r * C + c);
             s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
@@ -406,8 +417,12 @@ extern "C" int mvlt_layernorm_acc_fwd(int dtype, const float* acc, int nsplit, c
     MVLT_CHECK(acc && nsplit >= 1 && nsplit <= 64 && bias && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, MVLT_ERR_ARG);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(ceil_div(rows, 4));
-    if (dtype == MVLT_BF16) hipLaunchKernelGGL(ln_acc_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, acc, nsplit, bias, (const bf16_t*)residual, gamma, beta, eps, rows, C, (bf16_t*)y);
-    else if (dtype == MVLT_F32) hipLaunchKernelGGL(ln_acc_fwd_kernel<float>, grid, dim3(256), 0, s, acc, nsplit, bias, (const float*)residual, gamma, beta, eps, rows, C, (float*)y);
+#define LN_ACC_GO(T_, NS_) hipLaunchKernelGGL((ln_acc_fwd_kernel<T_, NS_>), grid, dim3(256), 0, s, acc, nsplit, bias, (const T_*)residual, gamma, beta, eps, rows, C, (T_*)y)
+#define LN_ACC_BY_NS(T_) do { if (nsplit == 1) LN_ACC_GO(T_, 1); else if (nsplit == 2) LN_ACC_GO(T_, 2); else if (nsplit == 4) LN_ACC_GO(T_, 4); else LN_ACC_GO(T_, 0); } while (0)
+    if (dtype == MVLT_BF16) LN_ACC_BY_NS(bf16_t);
+    else if (dtype == MVLT_F32) LN_ACC_BY_NS(float);
+#undef LN_ACC_BY_NS
+#undef LN_ACC_GO
     else return MVLT_ERR_UNSUPPORTED;
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
