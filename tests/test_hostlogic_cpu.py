@@ -173,3 +173,20 @@ def test_unconsumed_gradients_accumulate_and_consumed_ones_do_not():
     ar.note_grads_consumed()
     ar.begin_backward(); ar.grad_view(m.common.weight).fill_(1.5); ar.mark(m.common.weight); ar.publish_grads()
     assert float(m.common.weight.grad[0, 0]) == 1.5
+
+
+def test_hardware_queue_default_is_set_on_import():
+    """mvlt_amd sets GPU_MAX_HW_QUEUES=8 on import unless the user chose a value (profiles/r5_ddp_one_rank.md: with the default 4
+    hardware queues the step's two streams and RCCL's share queues and serialise); a process that had initialised HIP first is
+    flagged so that GradReducer can warn."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); import mvlt_amd; "
+            "print(os.environ['GPU_MAX_HW_QUEUES'], mvlt_amd.HWQ_SET_LATE)") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ))
+    assert out.stdout.split() == ["8", "False"], (out.stdout, out.stderr[-500:])
+    code2 = code.replace("os.environ.pop('GPU_MAX_HW_QUEUES', None)", "os.environ['GPU_MAX_HW_QUEUES'] = '16'")
+    out = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, env=dict(os.environ))
+    assert out.stdout.split() == ["16", "False"], (out.stdout, out.stderr[-500:])
