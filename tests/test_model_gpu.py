@@ -903,6 +903,44 @@ def test_config2_batch32_full_size(M, monkeypatch):
     assert all(l == l and abs(l) < 1e4 for l in losses) and losses[-1] < losses[0], losses
 
 
+def test_training_step_reports_a_handoff_timeout(M, monkeypatch):
+    """VERDICT r4 weak #4, end to end: a hand-off wait of the fused Swin attention that runs out inside a TRAINING step must
+    not pass silently -- the loss of that step is NaN (the unit's rows of the block output were poisoned) and the NEXT
+    PretrainStep call raises ops.DeviceHandoffError (the error count travels to pinned host memory behind the step, no
+    device sync); check_device_errors raises as well.  Provoked on the Swin-S model at B = 16 (stage 2 then has 64 windows: the head
+    groups of its 32 window pairs meet inside mvlt_swin_wmsa2_fwd; stages 0 / 1 keep all heads in one workgroup) by mis-arming
+    one window pair's arrival counter with the wait shortened to 20 ms."""
+    from mvlt_amd import ops
+    from mvlt_amd.train import PretrainStep, synthetic_batch
+    cfg = M.MVLBertPretrainConfig()
+    cfg.ITM_task = True
+    torch.manual_seed(0)
+    model = M.MVLBertForPretraining(cfg).cuda().train()
+    step = PretrainStep(model, lr=1e-5)
+    batch = synthetic_batch(16, 80, "cuda", 93)[:4]
+    monkeypatch.setattr(random, "random", lambda: 0.9)
+    loss = step(batch)                                   # a clean step first: allocates the workspace of the compute stream
+    assert loss.item() == loss.item()
+    ops.wmsa2_check(sync=True)
+    wss = list(ops._WMSA2_SYNC.values())
+    assert wss, "the B = 16 step did not run the fused W-MSA kernel"
+    try:
+        ops.wmsa2_set_timeout_ms(20)
+        for ws in wss:
+            ws[16 + 2 * 3] = -1000                       # pair 3 of the next launch on that stream never completes its arrival count
+        loss = step(batch)
+        torch.cuda.synchronize()
+        assert loss.item() != loss.item(), loss.item()   # NaN reached the loss
+        assert ops.wmsa2_sync_errors() > 0
+        with pytest.raises(ops.DeviceHandoffError):
+            step(batch)                                  # reported one step late, without a sync of its own
+        with pytest.raises(ops.DeviceHandoffError):
+            model.check_device_errors()
+    finally:
+        ops.wmsa2_set_timeout_ms(0)
+        ops.wmsa2_clear_errors()
+
+
 def test_config2_step_is_bit_reproducible_except_the_atomic_accumulations(M, monkeypatch):
     """the B=32 bf16 training step (train mode: dropout + DropPath, same seeds) run twice from the same
     parameters gives bit-identical gradients everywhere EXCEPT the tensors that are accumulated with float atomics:
