@@ -37,6 +37,15 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 
 constexpr int HT_BYTES = 128 * 64 * 2;          // one half-tile: 128 operand rows x 64 bf16
 
+// -DG8_TRACE (diagnostic build only): thread 0 of every workgroup stamps the 100 MHz real-time counter at the phase boundaries
+// of its FIRST tile into a buffer set by mvlt_gemm8_trace_buffer (scripts/g8_trace.py reads it)
+#ifdef G8_TRACE
+__device__ long long* g_g8_trace = nullptr;
+#define G8_STAMP(k) do { if (threadIdx.x == 0 && g_g8_trace) g_g8_trace[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define G8_STAMP(k) do { } while (0)
+#endif
+
 #define G8_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define G8_BARRIER() do { G8_FENCE(); __builtin_amdgcn_s_barrier(); G8_FENCE(); } while (0)
 #define G8_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
@@ -325,6 +334,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
     using Cfg = G8Cfg<MH, NH>;
     constexpr int BM = 128 * MH, BN = 128 * NH, HPK = Cfg::HPK, RING_KT = Cfg::RING_KT;
     extern __shared__ __attribute__((aligned(1024))) char smem[];          // ring of RING_KT * HPK half-tile slots
+    G8_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = wave >> 2, wc = wave & 3;
@@ -458,6 +468,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
     auto advance = [&]() { if (++is.kt >= is.kt_end) set_tile(is.ord + 1); };
 
     // ---- prologue
+    G8_STAMP(1);
     set_tile(0);
     if constexpr (HPK == 4) {                  // the whole K-tile 0 and A0 of K-tile 1; 3 half-tiles stay in flight
         issue(0, is.kt, 0); issue(1, is.kt, 0); issue(2, is.kt, 0); issue(3, is.kt, 0);
@@ -475,7 +486,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
         issue(0, is.kt, 1); issue(1, is.kt, 1);
         G8_VMCNT(4);
     }
+    G8_STAMP(2);
     G8_BARRIER();
+    G8_STAMP(3);
     if (wr == 1) G8_BARRIER();                                            // group 1 runs one barrier behind
 
     int g = 0;                                                            // flat K-tile index over the tile list
@@ -581,6 +594,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
         }
         // ---- epilogue of this unit; the next unit's first half-tiles are already on their way
         // acc[r] <-> n = nb + 4 * (lane >> 4) + r, m = mb + (lane & 15)   (MFMA issued as (B fragment, A fragment))
+        if (ord == 0) G8_STAMP(4);
         bool finish = true;
         if (S > 1) {
             // k-slices of one tile meet through f32 slabs; the LAST arriver sums them in slice order and stores the tile
@@ -667,10 +681,13 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
                 }
             }
         }
+        if (ord == 0) G8_STAMP(5);
         if (S > 1 && wr == 1) G8_BARRIER();
     }
     if (wr == 0) G8_BARRIER();                                            // balance group 1's extra barrier
+    G8_STAMP(6);
     G8_VMCNT(0);                                                          // the overrun issues land before the LDS is released
+    G8_STAMP(7);
 }
 
 // 512 zero bytes for the reduction rows beyond a ragged K (k-major A operand)
@@ -785,6 +802,12 @@ G8Plan g8_plan_kk(const GemmDev* d, int n) {
 }
 
 }  // namespace
+
+#ifdef G8_TRACE
+extern "C" int mvlt_gemm8_trace_buffer(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_g8_trace), &buf, sizeof(buf)) == hipSuccess ? MVLT_OK : MVLT_ERR_LAUNCH;
+}
+#endif
 
 // Launchers used by gemm.hip's dispatch: return 1 when the product(s) were taken, 0 when not eligible (the caller then
 // uses the 4-wave kernels), -1 on a launch error.  Eligible: bf16, 16-byte aligned operand rows, no split-K requested,
