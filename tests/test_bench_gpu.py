@@ -29,3 +29,23 @@ def test_bench_two_ranks_self_launch_relays_one_json_line():
     assert out["value"] > 0 and out["ms_per_step"] > 0
     loss = out["config"]["loss"]
     assert loss == loss and 5.0 < loss < 15.0          # ~ln(30522) + ln 2 on random-init weights
+
+
+def test_bench_one_rank_over_rccl_with_and_without_the_collective():
+    """`other_configs.one_rank_rccl` of the default bench line: the step with the gradient reducer over RCCL
+    on ONE rank (MVLT_FORCE_DDP=1), and the same without the collective itself (MVLT_DDP_NULL_COLLECTIVE=1) -- exactly one JSON
+    line each (RCCL prints a banner on stdout: bench.py re-points file descriptor 1 for the run), a finite loss, and the
+    hardware-queue default in place."""
+    for extra in ({}, {"MVLT_DDP_NULL_COLLECTIVE": "1"}):
+        env = dict(os.environ, MVLT_FORCE_DDP="1", **extra)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GPU_MAX_HW_QUEUES"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extra",
+                            "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 1 and out["value"] > 0
+        loss = out["config"]["loss"]
+        assert loss == loss and 5.0 < loss < 15.0
