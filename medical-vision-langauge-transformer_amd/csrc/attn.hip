@@ -1003,13 +1003,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnDev p)
 //   * dS also goes to LDS as a bf16 image [32 queries][keys]; after a barrier the waves split dQ^T = K^T dS^T by
 //     (feature tile, query tile): complete results, no reduction over the waves that own the keys.
 // LDS: K image (for the transposing read), double-buffered Q / dO / dS block images, lse, delta, key mask: 60 KB.
-constexpr int AB2_NW = 5, AB2_NT = 64 * AB2_NW;
-constexpr int AB2_LD = 72, AB2_LDS = 168;                     // row strides (elements): [.][64] images, [32][160] dS image
-constexpr int AB2_ROWS = 160;
-constexpr size_t AB2_SMEM = (size_t)AB2_ROWS * AB2_LD * 2 + 2 * 2 * 32 * AB2_LD * 2 + 2 * 32 * AB2_LDS * 2 + 3 * AB2_ROWS * 4;
+// NW waves own 2 NW key tiles: NW = 5 -> up to 160 rows (config #2: L = 131), NW = 6 -> up to 192 rows (config #5: L = 179; round 5).
+constexpr int AB2_LD = 72;                                    // row stride (elements) of the [.][64] images
+template <int NW> struct Ab2Geom {
+    static constexpr int NT = 64 * NW, ROWS = 32 * NW, LDS = ROWS + 8;          // LDS = row stride of the [32][ROWS] dS image
+    static constexpr size_t SMEM = (size_t)ROWS * AB2_LD * 2 + 2 * 2 * 32 * AB2_LD * 2 + 2 * 32 * LDS * 2 + 3 * ROWS * 4;
+};
 
-template <bool S2S, bool DROP>
-__global__ __launch_bounds__(AB2_NT) void bert_attn_bwd2_kernel(const AttnDev p) {
+template <bool S2S, bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW) void bert_attn_bwd2_kernel(const AttnDev p) {
+    constexpr int AB2_NW = NW, AB2_NT = Ab2Geom<NW>::NT, AB2_ROWS = Ab2Geom<NW>::ROWS, AB2_LDS = Ab2Geom<NW>::LDS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using T = bf16_t;
     using M = Mma<T>;
@@ -1195,11 +1198,23 @@ thread_local hipEvent_t t_stop_event = nullptr;
         else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                       \
     } while (0)
 
-static int bert_bwd_form() { return 1; }          // 1 = one-launch backward where it applies (bf16, <= 160 rows); else two launches
+static int bert_bwd_form() { return 1; }          // 1 = one-launch backward where it applies (bf16, <= 192 rows); else two launches
+template <int NW>
 static int launch_bert_bwd2(const AttnDev& d, hipStream_t s) {
     dim3 grid(d.nseq, d.nH);
     const bool s2s = d.mode == MVLT_ATTN_SEQ2SEQ, drop = d.drop_thresh != 0;
-#define AB2_LAUNCH(S, D) ATTN_LAUNCH_LAST((bert_attn_bwd2_kernel<S, D>), grid, dim3(AB2_NT), AB2_SMEM, s, d)
+    using GM = Ab2Geom<NW>;
+    if constexpr (GM::SMEM > 64 * 1024) {
+        static const bool attr = [] {
+            bool ok = true;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(bert_attn_bwd2_kernel<true, true, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::SMEM) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(bert_attn_bwd2_kernel<true, false, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::SMEM) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(bert_attn_bwd2_kernel<false, true, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::SMEM) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(bert_attn_bwd2_kernel<false, false, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::SMEM) == hipSuccess;
+            return ok; }();
+        if (!attr) return MVLT_ERR_LAUNCH;
+    }
+#define AB2_LAUNCH(S, D) ATTN_LAUNCH_LAST((bert_attn_bwd2_kernel<S, D, NW>), grid, dim3(GM::NT), GM::SMEM, s, d)
     if (s2s) { if (drop) AB2_LAUNCH(true, true); else AB2_LAUNCH(true, false); }
     else { if (drop) AB2_LAUNCH(false, true); else AB2_LAUNCH(false, false); }
 #undef AB2_LAUNCH
@@ -1289,7 +1304,8 @@ int dispatch(AttnDev d, bool bwd, int dtype, hipStream_t s) {
         return launch<T, 32, 4, true>(d, bwd, dtype, s);
     }
     if (d.hd != 64) return MVLT_ERR_UNSUPPORTED;
-    if (bwd && sizeof(T) == 2 && d.NT <= 10 && bert_bwd_form()) return launch_bert_bwd2(d, s);
+    if (bwd && sizeof(T) == 2 && d.NT <= 10 && bert_bwd_form()) return launch_bert_bwd2<5>(d, s);
+    if (bwd && sizeof(T) == 2 && d.NT <= 12 && bert_bwd_form()) return launch_bert_bwd2<6>(d, s);          // up to 192 rows (config #5)
     if (bwd && d.delta_ws) {           // two-launch backward (dQ+delta, then dK/dV): 2 workgroups per CU
         if (d.NT <= 5) return launch_split<T, 64, 5>(d, dtype, s);
         if (d.NT <= 9) return launch_split<T, 64, 9>(d, dtype, s);

@@ -755,7 +755,8 @@ def bert_ref(qkv, B, Lq, nH, mask_add, scale, keep=None, p=0.0):
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("T,seq2seq,p", [(80, False, 0.0), (80, True, 0.0), (23, False, 0.0), (24, True, 0.1),
                                          (80, False, 0.1), (128, False, 0.1), (128, True, 0.0),   # 128: config #5 (L=179)
-                                         (109, True, 0.1), (109, False, 0.0), (110, False, 0.1)])   # L=160: the longest sequence of the one-launch bf16 backward (10 key tiles); 161: back to two launches
+                                         (109, True, 0.1), (109, False, 0.0), (110, False, 0.1),   # L=160: the longest sequence of the 5-wave one-launch bf16 backward (10 key tiles); 161: the 6-wave form (round 5: up to 192 rows, config #5's 179)
+                                         (141, True, 0.1), (141, False, 0.0)])   # L=192: its longest
 def test_bert_attention(ops, dt, T, seq2seq, p):
     from mvlt_amd._lib import ATTN_BIDIR, ATTN_SEQ2SEQ
     from oracle import mvlt_oracle as O
