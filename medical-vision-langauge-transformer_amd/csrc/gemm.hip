@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     const int orig = blockIdx.y * gx + blockIdx.x;
     if (orig >= gx * gy) return;
     const int t = xcd_remap(orig, gx * gy);
-    const int by = t / gx, bx = t - by * gx, bz = blockIdx.z;
+    int by, bx;
+    tile_coords(t, gx, gy, p.xcs, by, bx);
+    const int bz = blockIdx.z;
     const int m0 = by * BM, n0 = bx * BN;
     const int ks = bz * p.k_per_split;
     const int ke = min(p.K, ks + p.k_per_split);
@@ -483,8 +485,9 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const GemmDev p) {
     const int orig = blockIdx.y * gx + blockIdx.x;
     if (orig < gx * gy) {
         const int t = xcd_remap(orig, gx * gy);
-        const int by = t / gx;
-        gemm_body<T, BM, BN, AK, BK_, PF2, 0, WIDE>(q, t - by * gx, by, blockIdx.z, sA, sB);
+        int by, bx;
+        tile_coords(t, gx, gy, q.xcs, by, bx);
+        gemm_body<T, BM, BN, AK, BK_, PF2, 0, WIDE>(q, bx, by, blockIdx.z, sA, sB);
     }
     asm volatile("" :: "v"(pfv));
 }
@@ -998,6 +1001,22 @@ static int fill_dev(const MvltGemm* p, const Plan& pl, GemmDev& d) {
     // tiles of 64 / 128 columns only (fragment PAIRS)
     d.wide = sizeof(T) == 2 && ev && !(epi & (MVLT_EPI_OUT_F32 | MVLT_EPI_ACCUM)) && p->N % 8 == 0 && p->ldc % 8 == 0 && pl.split <= 1 &&
              pl.bn != 96 && (!(epi & MVLT_EPI_RESIDUAL) || p->ldr % 8 == 0) && (!(epi & MVLT_EPI_BIAS) || aligned16(p->bias));
+    // tile order (tile_coords): the number of column groups that minimises what the eight L2s pull over the fabric,
+    // M * xcs (rows of A, every group re-reads its row band) + 8 N / xcs (columns of B); MVLT_XCD_CS = 1 turns it off, 2 / 4 / 8 force it
+    static const int xcs_env = [] { const char* e = getenv("MVLT_XCD_CS"); return e ? atoi(e) : 0; }();
+    d.xcs = 1;
+    {
+        const int gx = ceil_div(p->N, pl.bn), gy = ceil_div(p->M, pl.bm);
+        if (xcs_env > 1) { if (gx % xcs_env == 0) d.xcs = xcs_env; }
+        else if (xcs_env == 0 && gx * gy >= 128) {
+            long best = (long)p->M + 8L * p->N;
+            for (int cs = 2; cs <= 8; cs *= 2)
+                if (gx % cs == 0 && gy >= 2 * (8 / cs)) {
+                    const long c = (long)p->M * cs + 8L * p->N / cs;
+                    if (c < best) { best = c; d.xcs = cs; }
+                }
+        }
+    }
     return MVLT_OK;
 }
 

@@ -21,6 +21,7 @@ struct GemmDev {
     int atomic_out;                      // grouped weight gradients with in-launch split-K: f32 atomicAdd onto zeroed C
     int a_kmajor;                        // A is k-major (weight gradients): m_dev then limits the reduction, not the rows
     int wide;                            // bf16 rows out with 16-byte aligned 8-column chunks (and operands): kernels built with WIDE
+    int xcs;                             // column groups of the tile order (tile_coords below); 0 / 1 = plain row-major list
 };
 
 // Ragged batches planned on the GPU: the launch is sized for the upper bound, the kernel reads the real count.
@@ -374,6 +375,17 @@ MVLT_DEV void glds16_asm(const void* gsrc, unsigned lds_dst) {
 MVLT_DEV int xcd_remap(int orig, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// Position t of the tile list -> (row tile, column tile).  With xcs > 1 (a divisor of gx) the list runs through the column
+// groups one after the other (all row tiles of the first gx / xcs column tiles, then the next group ...), so the contiguous
+// eighth of the list that xcd_remap hands an XCD is a BLOCK of (8 / xcs)-th of the rows x one column group instead of a row band
+// x ALL columns: an XCD's L2 then pulls 1 / xcs of B and xcs / 8 of A over the fabric instead of all of B and 1 / 8 of A.
+MVLT_DEV void tile_coords(int t, int gx, int gy, int xcs, int& by, int& bx) {
+    if (xcs <= 1) { by = t / gx; bx = t - by * gx; return; }
+    const int hx = gx / xcs, per = gy * hx;
+    const int g = t / per, r = t - g * per;
+    by = r / hx; bx = g * hx + (r - by * hx);
 }
 
 // MvltGemm.prefetch: every thread of the launch reads one dword of a few 128-byte lines of a byte range that a LATER kernel

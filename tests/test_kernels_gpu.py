@@ -49,6 +49,27 @@ def test_gemm_layouts(ops, dt, ak, bk, M, N, K):
     assert rel(out, ref) < tol(dt)
 
 
+@pytest.mark.parametrize("bk", [False, True])
+@pytest.mark.parametrize("M,N,K", [(3150, 3072, 128), (1000, 4096, 64), (2100, 2048, 192), (6272, 1536, 64), (4192, 768, 256)])
+def test_gemm_column_grouped_tile_order(ops, bk, M, N, K):
+    """Products with >= 128 tiles whose tile list runs through 2 / 4 / 8 column groups (gemm_dev.h:tile_coords -- which L2 sees which
+    tile): every output tile written exactly once and in its place, with ragged edges and with a device-side row count."""
+    A = rnd((M, K), torch.bfloat16, 3)
+    B = rnd((N, K), torch.bfloat16, 4)
+    ref = A.float() @ B.float().t()
+    Bin = B.t().contiguous() if bk else B
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(A, Bin, b_kmajor=bk, out=out)
+    assert torch.isfinite(out.float()).all()
+    assert rel(out, ref) < tol(torch.bfloat16)
+    used = M - 333
+    out2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(A, Bin, b_kmajor=bk, out=out2, m_dev=torch.tensor([used], dtype=torch.int32, device="cuda"))
+    assert torch.equal(out2[:used], out[:used])
+    bm = 128                                        # rows beyond the last tile that holds a valid row stay untouched
+    assert torch.isnan(out2[-(-used // bm) * bm:].float()).all()
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_asymmetric_integer_exact(ops, dt):
     """A = I-like / asymmetric B catches row<->col swaps of the MFMA C layout."""
