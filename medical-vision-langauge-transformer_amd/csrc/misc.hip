@@ -930,7 +930,12 @@ extern "C" int mvlt_adamw(float* param, const float* grad, float* exp_avg, float
     MVLT_CHECK(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, MVLT_ERR_ARG);
     MVLT_CHECK(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq), MVLT_ERR_ARG);
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, STREAM(stream), param, grad, exp_avg,
+    // TWO 256-thread workgroups per CU, not thousands: the sweep is seven interleaved streams (four read, three and a half written)
+    // and HBM serves them best when few waves walk them -- stand-alone 6.0-6.1 TB/s with 256-768 workgroups against 5.3 with 8192
+    // (scripts/adamw_probe.hip, 182.4 M parameters: 0.90 vs 1.03 ms); in the step 512 is the best of 256 / 384 / 512 / 1024 / 8192
+    // (optimizer phase 0.845 vs 0.88 ms on a box with fast HBM, step -0.08 ms on a slower one; profiles/r5_adamw_grid.txt)
+    static const int cap = [] { const char* e = getenv("MVLT_ADAMW_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 256, cap)), dim3(256), 0, STREAM(stream), param, grad, exp_avg,
                        exp_avg_sq, (bf16_t*)shadow_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
                        (float)sqrt(bc2), grad_scale);
     MVLT_LAUNCH_CHECK();
