@@ -837,10 +837,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDev p_in) 
         const int m = ok ? (int)(idx / nq) : 0, n = ok ? (int)(idx % nq) * 4 : 0;
         f32x4 v{0.f, 0.f, 0.f, 0.f};
         if (ok) {
-            for (int s = w; s < p.split_k; s += 4) {
-                const float* ws = p.ws + ((long)s * p.M + m) * p.N + n;
-                if ((p.N & 3) == 0) { f32x4 t = load4f(ws); v += t; }
-                else for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += ws[r];
+            if ((p.N & 3) == 0) {
+                // eight slabs per round trip (a plain loop waits out one load latency per slab: 30 us for the 96 slices of
+                // the patch-embedding weight gradient, at the very end of the backward pass), summed in slice order
+                const long sstride = (long)p.M * p.N;
+                const float* ws0 = p.ws + (long)m * p.N + n;
+                for (int s = w; s < p.split_k; s += 32) {
+                    f32x4 t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int sj = s + 4 * j;
+                        t[j] = sj < p.split_k ? load4f(ws0 + sj * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v += t[j];
+                }
+            } else {
+                for (int s = w; s < p.split_k; s += 4) {
+                    const float* ws = p.ws + ((long)s * p.M + m) * p.N + n;
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += ws[r];
+                }
             }
         }
         red[w][lane] = v;
@@ -851,7 +867,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDev p_in) 
     if (p.a_colsum) {
         for (int m = blockIdx.x * 256 + threadIdx.x; m < p.M; m += gridDim.x * 256) {
             float s0 = 0.f;
-            for (int z = 0; z < p.split_k; ++z) s0 += p.ws_colsum[(long)z * p.M + m];
+            for (int z = 0; z < p.split_k; z += 8) {
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = z + j < p.split_k ? p.ws_colsum[(long)(z + j) * p.M + m] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s0 += t[j];
+            }
             p.a_colsum[m] = (p.epi & MVLT_EPI_ACCUM) ? p.a_colsum[m] + s0 : s0;
         }
     }

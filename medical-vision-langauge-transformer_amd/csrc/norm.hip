@@ -249,7 +249,9 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* part
     }
 }
 
-struct LnReduceBatch { MvltLnReduceItem it[24]; int n; };
+constexpr int LN_REDUCE_BATCH = 96;          // 96 x 32 B of kernel arguments: the ~52 LayerNorms of a Swin backward pass in ONE launch
+struct LnReduceBatch { MvltLnReduceItem it[LN_REDUCE_BATCH]; int n; };
+static_assert(sizeof(LnReduceBatch) <= 3584, "kernel argument block");
 // one launch reduces the partial rows of up to 24 LayerNorms: blockIdx.y = item, blockIdx.x = 64-column group
 __global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnReduceBatch b) {
     __shared__ float red[2][16][64];
@@ -482,9 +484,9 @@ extern "C" int mvlt_layernorm_bwd_nparts(int rows, int C) {
 extern "C" int mvlt_layernorm_param_reduce_batch(const MvltLnReduceItem* items, int n, void* stream) {
     MVLT_CHECK(items && n > 0, MVLT_ERR_ARG);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    for (int i0 = 0; i0 < n; i0 += 24) {
+    for (int i0 = 0; i0 < n; i0 += LN_REDUCE_BATCH) {
         LnReduceBatch b;
-        b.n = n - i0 < 24 ? n - i0 : 24;
+        b.n = n - i0 < LN_REDUCE_BATCH ? n - i0 : LN_REDUCE_BATCH;
         int maxC = 0;
         for (int i = 0; i < b.n; ++i) {
             b.it[i] = items[i0 + i];

@@ -553,7 +553,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_
 
 class LnReduceQueue:
     """Partial dgamma/dbeta rows of every LayerNorm of one backward pass live in one pool and are
-    reduced by ceil(n/24) launches at the end (instead of one launch per LayerNorm)."""
+    reduced by ceil(n/96) launches at the end (instead of one launch per LayerNorm)."""
     _pool = {}
     _active = []          # queues with pending items (flushed early by the DDP bucket launcher)
 

@@ -11,7 +11,9 @@ LAYERS = {"bert layer (R=3150)": (3150, [(768, 3072), (3072, 768), (768, 2304), 
           "swin s3 block (R=1568)": (1568, [(768, 3072), (3072, 768), (768, 2304), (768, 768)]),
           "swin s1 block (R=25088)": (25088, [(192, 768), (768, 192), (192, 576), (192, 192)]),
           "swin s0 block (R=100352)": (100352, [(96, 384), (384, 96), (96, 288), (96, 96)])}
+ONLY = os.environ.get("ONLY")          # e.g. ONLY="s0 block,s1 block"
 for name, (R, shp) in LAYERS.items():
+    if ONLY and not any(o in name for o in ONLY.split(",")): continue
     items, fl = [], 0.0
     for ni, no in shp:
         dy = torch.randn(R, no, device=dev).bfloat16(); x = torch.randn(R, ni, device=dev).bfloat16()
