@@ -815,8 +815,12 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GemmGroupDev g
         const int gx = (p.N + BN - 1) / BN, gy = (p.M + BM - 1) / BM;
         const int local = t - gp.start[i];
         const int bz = local / (gx * gy), tile = local - bz * gx * gy;          // k-slice bz of output tile `tile`
-        const int by = tile / gx;
-        gemm_body<T, BM, BN, AK, BK_, false, DEEP>(p, tile - by * gx, by, bz, sA, sB);
+        // the list runs along the SHORTER side of the tile grid first: the contiguous chunk of it that lands on one XCD (xcd_remap)
+        // is then a block, not a sliver of a few rows x all columns -- a [768, 3072] gradient: 6 + 9 operand bands per L2 instead of 3 + 24
+        int by, bx;
+        if (gx > gy) { bx = tile / gy; by = tile - bx * gy; }
+        else { by = tile / gx; bx = tile - by * gx; }
+        gemm_body<T, BM, BN, AK, BK_, false, DEEP>(p, bx, by, bz, sA, sB);
     }
 }
 
