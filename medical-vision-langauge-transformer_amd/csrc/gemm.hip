@@ -370,7 +370,11 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     using T = bf16_t;
     constexpr int BKE = 64, FM = BM / 32, FN = BN / 32;
     static_assert(!BKM || BN == 64 || BN == 128, "k-major B tiles: 64 or 128 columns");
-    __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * BKE];
+    // two stages; beyond the 64 KB a static array may have (160 x 128 tiles: 72 KB) the launcher passes dynamic LDS
+    constexpr bool DYN = 2 * (BM + BN) * BKE * sizeof(T) > 65536;
+    extern __shared__ __attribute__((aligned(16))) char glds_dyn[];
+    __shared__ __attribute__((aligned(16))) T glds_static[DYN ? 8 : 2 * (BM + BN) * BKE];
+    T* const smem = DYN ? reinterpret_cast<T*>(glds_dyn) : glds_static;
     const GemmDev p = effective<false>(p_in);
     const unsigned pfv = prefetch_lines(p_in);
     const int gx = gridDim.x;
@@ -909,6 +913,21 @@ int launch_layout(const GemmDev& d, bool ak, bool bk, dim3 grid, hipStream_t s) 
 
 struct Plan { int bm, bn, split; };
 
+// 160 x 128 tiles exist only as the LDS-DMA kernel with the 16-byte epilogue (gemm_glds_kernel<160, 128, *, true>): every
+// condition of that path is checked here, at PLAN time (the grid is sized for the planned tile)
+bool tile160_ok(const MvltGemm* p) {
+    const int epi = p->epilogue;
+    if (p->dtype != MVLT_BF16 || p->a_kmajor || p->split_k > 1 || p->a_colsum) return false;
+    if (p->K % 64 || p->N % 8 || p->lda % 8 || p->ldb % 8 || p->ldc % 8) return false;
+    if (!aligned16(p->A) || !aligned16(p->B) || !aligned16(p->C)) return false;
+    if (epi & (MVLT_EPI_OUT_F32 | MVLT_EPI_ACCUM)) return false;
+    if ((epi & MVLT_EPI_RESIDUAL) && (p->ldr % 8 || !aligned16(p->residual))) return false;
+    if ((epi & MVLT_EPI_SAVE_PRE) && !aligned16(p->pre)) return false;
+    if ((epi & MVLT_EPI_MUL_GELU_GRAD) && !aligned16(p->aux)) return false;
+    if ((epi & MVLT_EPI_BIAS) && !aligned16(p->bias)) return false;
+    return true;
+}
+
 Plan choose_plan(const MvltGemm* p) {
     // tile: BN = 128 when N is a multiple of 128 (or large), else 96 (all model
     // widths are multiples of 96), 64 for tiny N.  BM = 128 unless that leaves
@@ -931,10 +950,21 @@ Plan choose_plan(const MvltGemm* p) {
     // stand-alone (6272 x 1536 x 384: 19.8 vs 20.3 us, 3090 x 2304 x 768: 22.9 vs 23.1) and finish more evenly inside the forward
     // pass, a serial chain of ~250 launches where every tail is exposed: +0.55 % pairs/s (6 interleaved runs each)
     if (!p->a_kmajor && !p->b_kmajor && p->N % 64 == 0 && p->M <= 8192 && p->K <= 768 && p->N <= 2304) { pl.bm = 64; pl.bn = 64; }
+    // ONE round of 160 x 128 tiles (two workgroups per CU: 512 slots) where that fills 2/3 .. all of the chip: 71 FLOP per byte of
+    // L2 -> LDS traffic against 32-43 for the 64-row tiles (stand-alone 3150 x 3072 x 768 + GELU 27.1 vs 29.9 us, 3150 x 2304 x 768
+    // 21.5 vs 23.7, 6272 x 1536 x 384 22.1 vs 24.5, 4192 x 2304 x 768 22.0 vs 28.3; scripts/tile160_sweep.sh)
+    // Forward products only: for the dgrads of the same shapes the 72-KB workgroups share a CU badly with the weight-gradient stream
+    // (step 11.66 -> 11.90 ms with them, 11.71 -> 11.64 ms with the forward products alone; profiles/r5_tile160_ab.txt).
+    static const bool t160 = [] { const char* e = getenv("MVLT_TILE160"); return !e || atoi(e) != 0; }();
+    if (t160 && p->N % 128 == 0 && p->N >= 1536 && p->K <= 1024 && !p->b_kmajor && tile160_ok(p)) {
+        const long t = (long)ceil_div(p->M, 160) * (p->N / 128);
+        if (t > 340 && t <= 512) { pl.bm = 160; pl.bn = 128; }
+    }
     if (const char* ov = getenv("MVLT_TILE")) {          // experiments: MVLT_TILE=bm,bn
         int a = 0, b = 0;
         if (sscanf(ov, "%d,%d", &a, &b) == 2 && (a == 128 || a == 64) && (b == 128 || b == 96 || b == 64) &&
             !(a == 128 && b == 64)) { pl.bm = a; pl.bn = b; }
+        if (a == 160 && b == 128 && tile160_ok(p)) { pl.bm = 160; pl.bn = 128; }
     }
     long tiles = (long)ceil_div(p->M, pl.bm) * ceil_div(p->N, pl.bn);
     int split = p->split_k;
@@ -942,7 +972,7 @@ Plan choose_plan(const MvltGemm* p) {
         split = 1;
         const int bke = (p->dtype == MVLT_BF16) ? 64 : 32;
         const int nkt = ceil_div(p->K, bke);
-        if (tiles < 200 && nkt >= 16) {          // small outputs with a long reduction only (wgrads)
+        if (tiles < 200 && nkt >= 16 && pl.bm != 160) {          // small outputs with a long reduction only (wgrads)
             split = (int)((768 + tiles - 1) / tiles);
             if (split > nkt / 8) split = nkt / 8;
             if (split > 96) split = 96;
@@ -1086,14 +1116,23 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
         // faster on 128x128 tiles and 18-24 % on 64x64; inside the training step the 128x128 form (64 KB of LDS, two
         // workgroups per CU) is SLOWER than the register-staged one (three per CU, shares the CU better with the
         // weight-gradient stream): 16.5 vs 16.1 ms per step.
-        const bool glds_on = pl.bm == 64;          // LDS-DMA loop for the 64-row tiles (comment above)
+        const bool glds_on = pl.bm == 64 || pl.bm == 160;          // LDS-DMA loop for the 64-row tiles (comment above) and the 160-row ones
         const int kspan = d.split_k > 1 ? d.k_per_split : p->K;
         const bool bkm_ok = !bk || ((pl.bn == 64 || pl.bn == 128) && p->N % 8 == 0 && p->N >= 8);
         if (glds_on && !ak && bkm_ok && p->K % 64 == 0 && kspan % 64 == 0 && d.a_vec && d.b_vec) {
             bool done = true;
 #define GLDS_GO(BM_, BN_, BKM_) do { if (d.wide) hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, BKM_, true>), grid, dim3(256), 0, s, d); \
                                      else hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, BKM_, false>), grid, dim3(256), 0, s, d); } while (0)
-            if (bk) {
+            // 160-row tiles (72 KB of dynamic LDS, two workgroups per CU): wide epilogue only
+#define GLDS_GO_DYN(BM_, BN_, BKM_) do { constexpr int sh_ = 2 * (BM_ + BN_) * 64 * 2; \
+                static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM_, BN_, BKM_, true>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, sh_) == hipSuccess; \
+                if (!ok_) return MVLT_ERR_LAUNCH; \
+                hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, BKM_, true>), grid, dim3(256), sh_, s, d); } while (0)
+            if (pl.bm == 160) {
+                if (bk) GLDS_GO_DYN(160, 128, true); else GLDS_GO_DYN(160, 128, false);
+            }
+            else if (bk) {
                 if (pl.bm == 128 && pl.bn == 128) GLDS_GO(128, 128, true);
                 else if (pl.bm == 64 && pl.bn == 128) GLDS_GO(64, 128, true);
                 else if (pl.bm == 64 && pl.bn == 64) GLDS_GO(64, 64, true);
@@ -1106,6 +1145,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
             else if (pl.bm == 64 && pl.bn == 64) GLDS_GO(64, 64, false);
             else done = false;
 #undef GLDS_GO
+#undef GLDS_GO_DYN
             if (done) {
                 MVLT_LAUNCH_CHECK();
                 if (p->event_after_main) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p->event_after_main), s);
@@ -1120,6 +1160,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
             }
         }
     }
+    if (pl.bm == 160) return MVLT_ERR_UNSUPPORTED;          // (tile160_ok and the conditions above disagree: never launch a mis-sized grid)
     if (pl.bm == 128 && pl.bn == 128) launch_layout<T, 128, 128>(d, ak, bk, grid, s);
     else if (pl.bm == 128 && pl.bn == 96) launch_layout<T, 128, 96>(d, ak, bk, grid, s);
     else if (pl.bm == 64 && pl.bn == 128) launch_layout<T, 64, 128>(d, ak, bk, grid, s);
