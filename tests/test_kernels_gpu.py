@@ -239,6 +239,44 @@ def test_gemm_epilogues(ops, dt, M, N, K):
     assert rel(out, hf.grad) < tol(dt)
 
 
+@pytest.mark.parametrize("M,N,K", [(3150, 3072, 768),        # BertLayer FFN-in of a packed B = 32 step: 20 x 24 tiles of 160 x 128
+                                   (3111, 2304, 768),        # qkv; the last row tile holds 71 of its 160 rows
+                                   (6272, 1536, 384)])       # Swin stage-2 Mlp.fc1: 40 x 12 tiles
+def test_gemm_tile160_forward_products(ops, M, N, K):
+    """Forward products that fill the chip with ONE round of 160 x 128 tiles take gemm_glds_kernel<160, 128> (72 KB of dynamic
+    LDS, five 16-row fragments per wave): the plan says so, and every epilogue the model issues on these shapes equals the
+    fp32 torch statement -- bias, bias + GELU + saved pre-activation, bias + dropout + residual, and a device-side row count."""
+    import ctypes as C
+    from mvlt_amd import _lib as L
+    dt = torch.bfloat16
+    A, W = rnd((M, K), dt, 41), rnd((N, K), dt, 42, K ** -0.5)
+    bias = rnd((N,), torch.float32, 43)
+    q = L.MvltGemm()
+    q.dtype, q.M, q.N, q.K, q.lda, q.ldb, q.ldc = L.BF16, M, N, K, K, K, N
+    q.A, q.B, q.C = A.data_ptr(), W.data_ptr(), A.data_ptr()
+    bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
+    assert L.lib().mvlt_gemm_plan(C.byref(q), C.byref(bm), C.byref(bn), C.byref(sp)) == 0
+    assert (bm.value, bn.value, sp.value) == (160, 128, 1)
+    q.b_kmajor = 1                                   # the dgrad of the same shape stays on the smaller tiles
+    assert L.lib().mvlt_gemm_plan(C.byref(q), C.byref(bm), C.byref(bn), C.byref(sp)) == 0 and bm.value != 160
+    base = A.float() @ W.float().t() + bias
+    out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+    ops.gemm(A, W, bias=bias, out=out)
+    assert torch.isfinite(out.float()).all() and rel(out, base) < tol(dt)
+    pre = torch.empty((M, N), dtype=dt, device="cuda")
+    out = ops.gemm(A, W, bias=bias, gelu=True, save_pre=pre)
+    assert rel(pre, base) < tol(dt) and rel(out, F.gelu(base)) < tol(dt)
+    res = rnd((M, N), dt, 44)
+    out = ops.gemm(A, W, bias=bias, dropout=(0.1, 99, 5), residual=res)
+    keep = ops.dropout_mask(M * N, 0.1, 99, 5, A.device).view(M, N).float()
+    assert rel(out, res.float() + base * keep / 0.9) < tol(dt)
+    used = M - 200
+    out2 = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+    ops.gemm(A, W, bias=bias, out=out2, m_dev=torch.tensor([used], dtype=torch.int32, device="cuda"))
+    assert rel(out2[:used], base[:used]) < tol(dt)
+    assert torch.isnan(out2[-(-used // 160) * 160:].float()).all()
+
+
 # (K, N, b_kmajor, epilogue): the nine products mvlt_gemm routes to the row-streaming kernel (csrc/rowstream.hip)
 _ROWSTREAM = [(96, 384, False, "gelu_pre"), (96, 384, False, "gelu"), (384, 96, False, "scale_res"), (384, 96, False, "res"),
               (192, 768, False, "gelu_pre"), (96, 384, True, "aux"), (384, 96, True, ""), (96, 96, True, ""), (288, 96, True, ""),
