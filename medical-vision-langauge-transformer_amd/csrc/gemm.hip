@@ -1063,11 +1063,11 @@ static int fill_dev(const MvltGemm* p, const Plan& pl, GemmDev& d) {
     d.xcs = 1;
     {
         const int gx = ceil_div(p->N, pl.bn), gy = ceil_div(p->M, pl.bm);
-        if (xcs_env > 1) { if (gx % xcs_env == 0) d.xcs = xcs_env; }
+        if (xcs_env > 1) { if (gx >= xcs_env) d.xcs = xcs_env; }
         else if (xcs_env == 0 && gx * gy >= 128) {
             long best = (long)p->M + 8L * p->N;
             for (int cs = 2; cs <= 8; cs *= 2)
-                if (gx % cs == 0 && gy >= 2 * (8 / cs)) {
+                if (gx >= 2 * cs && gy >= 2 * (8 / cs)) {
                     const long c = (long)p->M * cs + 8L * p->N / cs;
                     if (c < best) { best = c; d.xcs = cs; }
                 }

@@ -377,15 +377,18 @@ MVLT_DEV int xcd_remap(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-// Position t of the tile list -> (row tile, column tile).  With xcs > 1 (a divisor of gx) the list runs through the column
-// groups one after the other (all row tiles of the first gx / xcs column tiles, then the next group ...), so the contiguous
-// eighth of the list that xcd_remap hands an XCD is a BLOCK of (8 / xcs)-th of the rows x one column group instead of a row band
-// x ALL columns: an XCD's L2 then pulls 1 / xcs of B and xcs / 8 of A over the fabric instead of all of B and 1 / 8 of A.
+// Position t of the tile list -> (row tile, column tile).  With xcs > 1 the list runs through xcs column groups one after the
+// other (all row tiles of the first ceil(gx / xcs) column tiles, then the next group ...; the last group takes what is left), so the
+// contiguous eighth of the list that xcd_remap hands an XCD is a BLOCK of (8 / xcs)-th of the rows x one column group instead of a
+// row band x ALL columns: an XCD's L2 then pulls 1 / xcs of B and xcs / 8 of A over the fabric instead of all of B and 1 / 8 of A.
+// (host side: xcs <= gx, so the last group is never empty)
 MVLT_DEV void tile_coords(int t, int gx, int gy, int xcs, int& by, int& bx) {
     if (xcs <= 1) { by = t / gx; bx = t - by * gx; return; }
-    const int hx = gx / xcs, per = gy * hx;
-    const int g = t / per, r = t - g * per;
-    by = r / hx; bx = g * hx + (r - by * hx);
+    const int hx = (gx + xcs - 1) / xcs, per = gy * hx;
+    const int ng = (gx + hx - 1) / hx;                       // groups that actually exist (<= xcs)
+    const int g = min(t / per, ng - 1), r = t - g * per;
+    const int w = g == ng - 1 ? gx - g * hx : hx;
+    by = r / w; bx = g * hx + (r - by * w);
 }
 
 // MvltGemm.prefetch: every thread of the launch reads one dword of a few 128-byte lines of a byte range that a LATER kernel

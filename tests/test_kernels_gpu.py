@@ -50,7 +50,9 @@ def test_gemm_layouts(ops, dt, ak, bk, M, N, K):
 
 
 @pytest.mark.parametrize("bk", [False, True])
-@pytest.mark.parametrize("M,N,K", [(3150, 3072, 128), (1000, 4096, 64), (2100, 2048, 192), (6272, 1536, 64), (4192, 768, 256)])
+@pytest.mark.parametrize("M,N,K", [(3150, 3072, 128), (1000, 4096, 64), (2100, 2048, 192), (6272, 1536, 64), (4192, 768, 256),
+                                   (400, 30528, 64),         # the MLM decoder on the labelled rows: 239 column tiles, eight uneven groups
+                                   (2100, 2176, 128)])       # 17 column tiles
 def test_gemm_column_grouped_tile_order(ops, bk, M, N, K):
     """Products with >= 128 tiles whose tile list runs through 2 / 4 / 8 column groups (gemm_dev.h:tile_coords -- which L2 sees which
     tile): every output tile written exactly once and in its place, with ragged edges and with a device-side row count."""
