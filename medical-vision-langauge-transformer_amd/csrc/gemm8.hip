@@ -693,13 +693,24 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const G8Group gp) {
 // 512 zero bytes for the reduction rows beyond a ragged K (k-major A operand)
 __device__ __attribute__((aligned(256))) unsigned char g8_zero_page[512];
 
+// Persistent workgroups of a weight-gradient launch: HALF the CUs.  These launches run on the side stream beside the dgrad chain,
+// and one 8-wave workgroup takes a CU's whole LDS and register file: with 256 of them the chain's kernels found no CU at all while
+// a group ran (stage-0 / 1 of the B = 32 step: the chain kernel beside each of the four groups took 80-150 us instead of 25-50).
+// 128 workgroups with the k-slices planned for 128 units: a group takes 122-128 us instead of 83-99 stand-alone (the reduction is
+// HBM-bound, fewer CUs pull harder each), the chain keeps the other half of the chip, the step gains 0.1 ms
+// (11.84 -> 11.74 ms, 3 interleaved rounds; 96 / 112 / 144 / 160 workgroups: -0.05 .. -0.08; profiles/r5_g8_wgrad_grid.txt).
+int g8_wgrad_cap() {
+    static const int wcap = [] { const char* e = getenv("MVLT_G8_WGRAD_GRID"); return e && atoi(e) > 0 ? atoi(e) : 128; }();
+    return wcap;
+}
 template <int MH, int NH, bool AKM, bool BKM, int EPI, bool WIDE = false>
 int g8_launch1(const G8Group& gp, long units, hipStream_t s) {
     constexpr int sh = G8Cfg<MH, NH>::LDS + 64;                           // ring + the products' effective sizes + ticket
     static const bool attr = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel<MH, NH, AKM, BKM, EPI, WIDE>),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, sh) == hipSuccess; }();
     if (!attr) return -1;
-    const int grid = units < 256 ? (int)units : 256;
+    const int cap = (AKM && BKM) ? g8_wgrad_cap() : 256;
+    const int grid = units < cap ? (int)units : cap;
     hipLaunchKernelGGL((gemm8_kernel<MH, NH, AKM, BKM, EPI, WIDE>), dim3(grid), dim3(512), sh, s, gp);
     return hipGetLastError() == hipSuccess ? 1 : -1;
 }
@@ -773,7 +784,7 @@ int g8_choose(const GemmDev* d, int n, bool big_only, long* tiles_out) {
 // Weight-gradient groups (both operands k-major, reduction over the activation rows): tile shape AND number of k-slices.
 // Few output tiles, thousands of reduction rows: without k-slices a BertLayer group has 108 tiles of 256 x 256 for 256
 // CUs.  Model per unit: K-tiles x time per K-tile of the shape (1.5 / 0.7 / 0.45 us for 256x256 / 128x256 / 128x128,
-// measured in gpurun_out g8_check) x rounds of 256 units, plus the last arriver's slab sum.
+// measured in gpurun_out g8_check) x rounds of g8_wgrad_cap() units, plus the last arriver's slab sum.
 struct G8Plan { int mode, split; long tiles, units; double est_us; size_t ws_bytes; };
 G8Plan g8_plan_kk(const GemmDev* d, int n) {
     G8Plan best{0, 1, 0, 0, 1e30, 0};
@@ -791,7 +802,7 @@ G8Plan g8_plan_kk(const GemmDev* d, int n) {
             if (forced_s && forced_s != S) continue;
             if (S > 1 && nk / S < 6) break;
             const long units = tiles * S;
-            const double est = (double)ceil_div(units, 256) * ceil_div(nk, S) * sh.tk + (S > 1 ? 5.0 + sh.red * S : 0.0) + 7.0;
+            const double est = (double)ceil_div(units, g8_wgrad_cap()) * ceil_div(nk, S) * sh.tk + (S > 1 ? 5.0 + sh.red * S : 0.0) + 7.0;
             if (est < best.est_us) {
                 best = G8Plan{sh.mode, S, tiles, units, est, 0};
                 if (S > 1) best.ws_bytes = (size_t)units * sh.bm * sh.bn * 4 + (size_t)units * sh.bm * 4 + (size_t)tiles * 4 + 1024;
