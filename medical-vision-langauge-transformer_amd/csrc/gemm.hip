@@ -365,15 +365,18 @@ MVLT_DEV void glds_fill(const bf16_t* const (&src)[R / 32], bf16_t* lds_tile, in
 // [64 k][BN] with the 32-byte units XOR-swizzled by kswz<BN>(k) (the layout tile_frag<T, BN, true> transposes out of with
 // ds_read_b64_tr_b16); one LDS-DMA instruction covers 1 KB = 8 (BN = 64) / 4 (BN = 128) k-rows, the swizzle again on the
 // source side.  With transposing reads in the loop the DMA is issued through inline asm (glds16_asm, gemm_dev.h).
-template <int BM, int BN, bool BKM, bool WIDE>
+template <int N> MVLT_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int BM, int BN, bool BKM, bool WIDE, int NST = 2>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     using T = bf16_t;
     constexpr int BKE = 64, FM = BM / 32, FN = BN / 32;
     static_assert(!BKM || BN == 64 || BN == 128, "k-major B tiles: 64 or 128 columns");
-    // two stages; beyond the 64 KB a static array may have (160 x 128 tiles: 72 KB) the launcher passes dynamic LDS
-    constexpr bool DYN = 2 * (BM + BN) * BKE * sizeof(T) > 65536;
+    static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+    // NST stages; beyond the 64 KB a static array may have (160 x 128 tiles: 72 KB) the launcher passes dynamic LDS
+    constexpr bool DYN = NST * (BM + BN) * BKE * sizeof(T) > 65536;
     extern __shared__ __attribute__((aligned(16))) char glds_dyn[];
-    __shared__ __attribute__((aligned(16))) T glds_static[DYN ? 8 : 2 * (BM + BN) * BKE];
+    __shared__ __attribute__((aligned(16))) T glds_static[DYN ? 8 : NST * (BM + BN) * BKE];
     T* const smem = DYN ? reinterpret_cast<T*>(glds_dyn) : glds_static;
     const GemmDev p = effective<false>(p_in);
     const unsigned pfv = prefetch_lines(p_in);
@@ -432,11 +435,15 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (nkt > 0) fill(0, 0);
+    if (NST == 3 && nkt > 1) fill(1, 1);
     for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt has landed
+        // this wave's share of tile kt has landed (three stages: the BM / 32 + BN / 32 requests of tile kt + 1 may still be in
+        // flight -- vmcnt completes in order, so a COUNTED wait leaves exactly those outstanding; a fourth stage measured nothing)
+        if (NST == 3 && kt + 1 < nkt) wait_vmcnt<BM / 32 + BN / 32>();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // everybody's has; everybody is done reading tile kt-1
-        if (kt + 1 < nkt) fill((kt + 1) & 1, kt + 1);
-        const T* a = smem + (kt & 1) * STAGE;
+        if (kt + NST - 1 < nkt) fill((kt + NST - 1) % NST, kt + NST - 1);
+        const T* a = smem + (kt % NST) * STAGE;
         const T* b = a + BM * BKE;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -1129,8 +1136,18 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, sh_) == hipSuccess; \
                 if (!ok_) return MVLT_ERR_LAUNCH; \
                 hipLaunchKernelGGL((gemm_glds_kernel<BM_, BN_, BKM_, true>), grid, dim3(256), sh_, s, d); } while (0)
+            // Three LDS stages (two K-tiles in flight per workgroup, counted vmcnt) where a launch has so few 64 x 64 tiles that a CU
+            // holds one or two workgroups and every K-tile waits out a full L2 -> LDS latency: 1568 x 768 x 3072 26.8 -> 21.6 us.
+            // With three workgroups per CU the loop is bound by the CU's L2 -> LDS bandwidth and the third stage only costs
+            // (3150 x 768 x 3072: 32.3 vs 29.8 us; profiles/r5_glds_stages.txt).  MVLT_GLDS_STAGES=0 off, 2 = every 64 x 64 product.
+            static const int st3 = [] { const char* e = getenv("MVLT_GLDS_STAGES"); return e ? atoi(e) : 1; }();
+            const long tiles64 = (long)grid.x * grid.y;
             if (pl.bm == 160) {
                 if (bk) GLDS_GO_DYN(160, 128, true); else GLDS_GO_DYN(160, 128, false);
+            }
+            else if (st3 && pl.bm == 64 && pl.bn == 64 && d.wide && kspan >= 768 && (st3 == 2 || (!bk && tiles64 <= 400))) {
+                if (bk) hipLaunchKernelGGL((gemm_glds_kernel<64, 64, true, true, 3>), grid, dim3(256), 0, s, d);
+                else hipLaunchKernelGGL((gemm_glds_kernel<64, 64, false, true, 3>), grid, dim3(256), 0, s, d);
             }
             else if (bk) {
                 if (pl.bm == 128 && pl.bn == 128) GLDS_GO(128, 128, true);
