@@ -903,6 +903,63 @@ def test_config2_batch32_full_size(M, monkeypatch):
     assert all(l == l and abs(l) < 1e4 for l in losses) and losses[-1] < losses[0], losses
 
 
+@pytest.mark.parametrize("name,flip", [("bidir", 0.9), ("seq2seq", 0.1)])
+def test_config2_batch32_loss_and_gradients_vs_oracle(M, golden, specs_hash, name, flip):
+    """the BENCHMARKED routing pinned to something independent.  At B = 32 the default bf16 path sends
+    Swin stages 0-2 through wmsa2 with its cross-workgroup hand-off, the stage-0 products through the row-streaming kernel,
+    the BertLayer / stage-2 forward products through the 160 x 128 tiles, the tile lists through the column-grouped order
+    and the stage-0 / 1 weight gradients through the half-chip engine launches -- none of which a B = 2 golden exercises.
+    The CPU oracle (pinned bit-for-bit to the reference by tests/golden/make_golden.py) runs the same B = 32 batch with
+    the same full-rank hash weights, forward + backward (~20-40 s on the box's host cores); held: loss at the north-star
+    1e-3, and for the golden list's 16 gradient tensors + the active decoder the norm and 4,096 strided elements at
+    HASH_GRAD[bf16] -- the bounds the B = 2 reference goldens are held to."""
+    from conftest import hash_sd
+    from oracle import mvlt_oracle as O
+    g = golden("hash_models")
+    names = [k[len("gradnorm_bidir_"):] for k in g if k.startswith("gradnorm_bidir_") and not k.endswith("_decoder")]
+    assert len(names) >= 16
+    seq2seq = name == "seq2seq"
+    names.append(f"MLM_head_{name}.predictions.decoder.weight")
+    cfg = M.MVLBertPretrainConfig()
+    cfg.ITM_task = True
+    model = M.MVLBertForPretraining(cfg)
+    sd = hash_sd(specs_hash["hash_pretrain"])
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected
+    model = M.set_compute_dtype(model.cuda().eval(), BF16)
+    image, ids, labels, itm = synth_batch(32, 80, seed=191)
+    random.random = (lambda v=flip: v)
+    try:
+        loss = model(image.cuda(), ids.cuda(), labels.cuda(), itm.cuda())
+    finally:
+        random.random = _ORIG_RANDOM_RANDOM
+    assert model.last_seq2seq == seq2seq
+    loss.backward()
+    torch.cuda.synchronize()
+    M.ops.wmsa2_check(sync=True)                     # the hand-off ran (stages 0-2 at B = 32) and did not time out
+    params = dict(model.named_parameters())
+    got = {pn: params[pn].grad.detach().float().cpu() for pn in names}
+    got_loss = loss.item()
+    del model, params, loss
+    torch.cuda.empty_cache()
+    torch.set_num_threads(max(1, min(64, len(os.sched_getaffinity(0)))))
+    osd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    ref = O.pretrain_loss(osd, O.SwinCfg(), O.BertCfg(), image, ids, labels, itm, seq2seq, itm_task=True)
+    ref.backward()
+    assert abs(got_loss - ref.item()) < HASH_LOSS[BF16] * abs(ref.item()), (got_loss, ref.item())
+    bad = []
+    for pn in names:
+        gr, rr = got[pn], osd[pn].grad
+        e_norm = abs(gr.double().norm().item() - rr.double().norm().item()) / rr.double().norm().item()
+        st = max(1, gr.numel() // 4096)
+        e_str = rel_err(gr.reshape(-1)[::st][:4096], rr.reshape(-1)[::st][:4096])
+        if os.environ.get("MVLT_TEST_VERBOSE"):
+            print(f"B=32 {name} {pn}: norm err {e_norm:.2e}, 4096 strided {e_str:.2e}")
+        if e_norm > HASH_GRAD[BF16] or e_str > HASH_GRAD[BF16]:
+            bad.append((pn, e_norm, e_str))
+    assert not bad, bad
+
+
 def test_training_step_reports_a_handoff_timeout(M, monkeypatch):
     """VERDICT r4 weak #4, end to end: a hand-off wait of the fused Swin attention that runs out inside a TRAINING step must
     not pass silently -- the loss of that step is NaN (the unit's rows of the block output were poisoned) and the NEXT
