@@ -1233,6 +1233,10 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
         long t128 = 0;
         for (int i = 0; i < n; ++i) t128 += (long)ceil_div(items[i].M, 128) * ceil_div(items[i].N, 128);
         if (t128 >= 256) bm = 128;
+        // MVLT_WGRAD_BM=64: 64 x 128 tiles for every group (162 instead of 243 VGPRs per wave: two such workgroups leave a third
+        // of a SIMD's registers to the dgrad chain's kernels; A/B switch, profiles/r6_ln_bwd.md)
+        static const int env_bm = [] { const char* e = getenv("MVLT_WGRAD_BM"); return e ? atoi(e) : 0; }();
+        if (env_bm == 64) bm = 64;
     }
     long tiles = 0;
     int kmin = items[0].K;
@@ -1300,7 +1304,8 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
     // at most 2 workgroups per CU (of the 3 that fit): the group runs on the side stream beside the dgrad
     // chain, which should keep a share of every CU (16.8 vs 17.1 ms/step uncapped; 1 / 3 per CU measured equal or worse)
     int total = g.start[n];
-    constexpr int per_cu = 2;
+    // (MVLT_WGRAD_PER_CU=1|2|3: A/B switch; round 6 re-ran 1 against 2 with the low-footprint LayerNorm backward beside it)
+    static const int per_cu = [] { const char* e = getenv("MVLT_WGRAD_PER_CU"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 3 ? v : 2; }();
     if (total > per_cu * 256) total = per_cu * 256;
     // bf16: two LDS stages + two register sets, one barrier per k-tile (the single-stage form measured 1.3 % slower in the step)
 #define GROUP_LAUNCH(BM_, BN_, D_) hipLaunchKernelGGL((gemm_group_kernel<T, BM_, BN_, true, true, D_>), dim3(total), dim3(256), 0, s, g)

@@ -220,6 +220,167 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnDev p) {
     }
 }
 
+// ---- LayerNorm backward, low-footprint form (round 6; profiles/r6_ln_bwd.md) --------------------------------------------------
+// Inside the training step this kernel runs on the dgrad chain BESIDE a layer's weight-gradient workgroups (side stream), which hold
+// 336-496 of a SIMD's 512 VGPRs and 96-128 KB of a CU's LDS.  The kernel above is compiled for 128 VGPRs per wave and launched as
+// 8-wave blocks with 25-49 KB of LDS: beside two weight-gradient workgroups NOT ONE such block fits on a CU, so the launch runs on
+// the CUs the weight gradients left half empty -- 38 us in the step against 9 us alone for the BertLayer shape
+// (scripts/in_situ_overlap.py on a kernel trace; counters cannot show it, `rocprofv3 --pmc` serialises dispatches).
+// This form is built to fit INTO what is left: 4-wave blocks, <= 80 VGPRs (rows stay packed as loaded and are converted where
+// they are used, twice; the next row group's loads are issued before the current one is reduced, so a wave keeps two row
+// groups in flight), 2 x C floats of LDS (the waves of a block fold their parameter-gradient rows one after the other: fixed
+// order, no atomics).  Same arithmetic, same partial-row contract (one partial row pair per block) as the kernel above.
+MVLT_DEV f32x4 ln_unpack4(const u32x2& w) {
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, w[0] << 16); r[1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+    r[2] = __builtin_bit_cast(float, w[1] << 16); r[3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+    return r;
+}
+MVLT_DEV u32x2 ln_pack4(const f32x4& v) {
+    bf16x4 r; r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
+    return __builtin_bit_cast(u32x2, r);
+}
+
+// bf16, C == 4 LPR NV exactly (every width of configs #2 / #5), no GELU, no patch-merging gather.  All row operands go through
+// buffer descriptors: one 32-bit offset register per row instead of a 64-bit pointer per operand, rows past the end read
+// zeros and their stores are dropped by the range check -- no clamps, no predicated loads.  PF: two row groups in flight.
+struct LnRowSet { uint32_t voff, zoff; float mean, rstd, zs; };
+template <int LPR, int NV, bool PF>
+__global__ __launch_bounds__(256, PF ? (NV <= 2 ? 5 : 4) : (NV <= 3 ? 6 : 5)) void ln_bwd2_kernel(const LnDev p) {
+    constexpr int RPW = 64 / LPR;
+    constexpr int JB = LPR * 8;                                       // bytes between a lane's 4-element chunks
+    constexpr uint32_t OOB = 0x7fffffffu;
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = lane % LPR;
+    const int C = p.C, rowb = C * 2;
+    const int nrows = ln_rows(p);
+    const int stride = gridDim.x * 4 * RPW;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, nrows * rowb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, p.rows * rowb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dres ? p.dres : p.x), 0, p.dres ? nrows * rowb : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(p.dx, 0, nrows * rowb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(p.dz ? p.dz : p.dx, 0, p.dz ? p.rows * rowb : 0, 0x00020000);
+    f32x4 ag[NV], ab[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { ag[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[j] = ag[j]; }
+    // gamma lives in LDS behind the reduction rows (12 registers less per wave at C = 768: the difference between one and two
+    // resident blocks per CU beside the weight-gradient workgroups); re-read per row group through an address hipcc cannot hoist
+    float* lgam = red + 2 * C;
+    for (int c = threadIdx.x; c < C; c += 256) lgam[c] = p.gamma[c];
+    __syncthreads();
+    uint32_t gaddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lgam + sl * 16;
+    auto gam = [&](int j) -> f32x4 {
+        asm volatile("" : "+v"(gaddr));
+        return *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(gaddr + j * LPR * 16);
+    };
+
+    auto request = [&](int r0, LnRowSet& st, u32x2 (&xr)[NV], u32x2 (&dr)[NV], u32x2 (&rr)[NV]) {
+        const int r = r0 + lane / LPR, rc = min(r, nrows - 1);
+        const bool rv = r < nrows;
+        st.mean = p.mean[rc]; st.rstd = p.rstd[rc];
+        const int rd = p.rowmap ? p.rowmap[rc] : rc;
+        st.zs = p.zscale ? p.zscale[rc / p.zrps] : 1.0f;
+        const int zr = p.zmap ? p.zmap[rc] : rc;
+        st.voff = (uint32_t)(r * rowb + sl * 8);
+        st.zoff = rv ? (uint32_t)(zr * rowb + sl * 8) : OOB;
+        const uint32_t doff = rv ? (uint32_t)(rd * rowb + sl * 8) : OOB;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            xr[j] = __builtin_amdgcn_raw_buffer_load_b64(rx, st.voff + j * JB, 0, 0);
+            dr[j] = __builtin_amdgcn_raw_buffer_load_b64(rdy, doff + j * JB, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) rr[j] = __builtin_amdgcn_raw_buffer_load_b64(rdr, st.voff + j * JB, 0, 0);
+    };
+    // (the packed registers pass through an opaque asm in front of each use: hipcc otherwise keeps the f32 forms of pass 1 alive
+    // for pass 2 -- 36 more registers per row group than the packed operands it was given)
+    auto opaque = [](u32x2& v) { asm volatile("" : "+v"(v)); };
+    auto finish = [&](const LnRowSet& st, u32x2 (&xr)[NV], u32x2 (&dr)[NV], u32x2 (&rr)[NV]) {
+        float s1 = 0.f, s2 = 0.f;
+        const float nm = -st.mean * st.rstd;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            opaque(xr[j]); opaque(dr[j]);
+            const f32x4 xv = ln_unpack4(xr[j]), d = ln_unpack4(dr[j]), gm = gam(j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = fmaf(xv[e], st.rstd, nm), g = d[e] * gm[e];
+                s1 += g; s2 = fmaf(g, xh, s2);
+                ag[j][e] = fmaf(d[e], xh, ag[j][e]); ab[j][e] += d[e];
+            }
+        }
+        // (the parameter-gradient sums are complete HERE: left alone, hipcc moves them behind the stores below and carries the
+        // 8 NV products across the whole second pass)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(ag[j]), "+v"(ab[j]));
+        s1 = group_sum<LPR>(s1) * (1.0f / (4 * LPR * NV));
+        s2 = group_sum<LPR>(s2) * (1.0f / (4 * LPR * NV));
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            opaque(xr[j]); opaque(dr[j]); opaque(rr[j]);
+            const f32x4 xv = ln_unpack4(xr[j]), d = ln_unpack4(dr[j]), rs = ln_unpack4(rr[j]), gm = gam(j);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = fmaf(xv[e], st.rstd, nm);
+                o[e] = fmaf(st.rstd, fmaf(d[e], gm[e], -s1) - xh * s2, rs[e]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(ln_pack4(o), rdx, st.voff + j * JB, 0, 0);
+            if (p.dz) {                                         // gradient entering the residual branch that produced this tensor
+                if (p.zthresh) {
+                    const uint32_t base = (st.voff >> 1) + 4 * LPR * j;          // element index r C + c
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rng_keep(p.seed, p.tag, base + e, p.zthresh) ? o[e] * p.zdscale : 0.f;
+                }
+                o *= st.zs;
+                __builtin_amdgcn_raw_buffer_store_b64(ln_pack4(o), rdz, st.zoff + j * JB, 0, 0);
+            }
+        }
+    };
+    LnRowSet sa, sb;
+    u32x2 xa[NV], da[NV], ra[NV], xb[NV], db[NV], rb[NV];
+    int r0 = (blockIdx.x * 4 + wave) * RPW;
+    if constexpr (PF) {
+        if (r0 < nrows) request(r0, sa, xa, da, ra);
+        while (r0 < nrows) {
+            const int r1 = r0 + stride;
+            if (r1 < nrows) request(r1, sb, xb, db, rb);
+            finish(sa, xa, da, ra);
+            if (r1 >= nrows) break;
+            const int r2 = r1 + stride;
+            if (r2 < nrows) request(r2, sa, xa, da, ra);
+            finish(sb, xb, db, rb);
+            r0 = r2;
+        }
+    } else {
+        for (; r0 < nrows; r0 += stride) { request(r0, sa, xa, da, ra); finish(sa, xa, da, ra); }
+    }
+    // the row groups of a wave (LPR < 64) fold by xor-shuffle; the waves of the block add their rows into LDS one after the other
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ag[j][e] += __shfl_xor(ag[j][e], o, 64); ab[j][e] += __shfl_xor(ab[j][e], o, 64); }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w && lane < LPR) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                f32x4* g = reinterpret_cast<f32x4*>(&red[4 * (sl + LPR * j)]);
+                f32x4* b = reinterpret_cast<f32x4*>(&red[C + 4 * (sl + LPR * j)]);
+                if (w == 0) { *g = ag[j]; *b = ab[j]; } else { *g += ag[j]; *b += ab[j]; }
+            }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < 2 * C; c += 256)
+        (c >= C ? p.part_b : p.part_g)[(long)blockIdx.x * C + (c >= C ? c - C : c)] = red[c];
+}
+
 // partial rows -> dgamma/dbeta: block = 64 columns x 16 row groups (one wave each), coalesced 256-B row reads
 __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* part_g, const float* part_b, int nparts, int C,
                                                                float* dgamma, float* dbeta, int accumulate) {
@@ -345,7 +506,12 @@ __global__ __launch_bounds__(256) void ln_acc_fwd_kernel(const float* acc, int n
 }
 
 constexpr int LN_BWD_PARTS = 512;
+// MVLT_LN_BWD2=0: the round-1..5 kernel in 8-wave blocks everywhere (A/B switch; read once)
+static bool ln_bwd2_on() { static const bool on = [] { const char* e = getenv("MVLT_LN_BWD2"); return !(e && e[0] == '0'); }(); return on; }
 static int ln_bwd_waves(int C) {
+    // 4-wave blocks for EVERY variant while the low-footprint kernel is on: the number of partial rows a launch writes
+    // (mvlt_layernorm_bwd_nparts) is a function of (rows, C) alone, whichever kernel the dtype / gelu / merge flags pick
+    if (ln_bwd2_on()) return 4;
     int nw = 8;                                    // per-wave partial rows: nw * 2 * C floats of LDS, keep <= 64 KB
     while (nw > 1 && (size_t)nw * 2 * C * sizeof(float) > 64 * 1024) nw >>= 1;
     return nw;
@@ -381,6 +547,17 @@ void launch_bwd(LnDev d, bool merge, hipStream_t s) {
     const int nw = ln_bwd_waves(d.C);
     const int blocks = ln_bwd_blocks(d.rows, d.C);       // (LPR == ln_lpr(C): dispatch() below)
     d.nparts = blocks;
+    if constexpr (sizeof(T) == 2 && NV <= 4) {
+        // the 150 launches of a step; LayerNorm + GELU, the patch-merging gather, f32 and widths that do not fill the lanes
+        // exactly keep the general kernel (in 4-wave blocks too)
+        if (ln_bwd2_on() && !merge && !d.gelu && d.C == 4 * LPR * NV && (long)d.rows * d.C < (1L << 30) - 65536) {
+            static const bool pf = [] { const char* e = getenv("MVLT_LN_BWD2_PF"); return e && e[0] == '1'; }();          // two row groups in flight per wave (A/B switch)
+            const size_t sh2 = 3 * (size_t)d.C * sizeof(float);          // reduction rows [2][C] + gamma [C]
+            if (pf && NV <= 3) hipLaunchKernelGGL((ln_bwd2_kernel<LPR, NV, true>), dim3(blocks), dim3(256), sh2, s, d);
+            else hipLaunchKernelGGL((ln_bwd2_kernel<LPR, NV, false>), dim3(blocks), dim3(256), sh2, s, d);
+            return;
+        }
+    }
     const size_t sh = 2 * (size_t)nw * d.C * sizeof(float);
     if (merge) hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, true>), dim3(blocks), dim3(64 * nw), sh, s, d);
     else hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, false>), dim3(blocks), dim3(64 * nw), sh, s, d);

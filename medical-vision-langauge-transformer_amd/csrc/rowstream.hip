@@ -72,6 +72,26 @@ template <int NIW, int MAXR> MVLT_DEV void rs_wait_rem(int rem) {
     else { if (rem >= MAXR) rs_vmcnt<(MAXR * NIW)>(); else rs_wait_rem<NIW, MAXR - 1>(rem); }
 }
 
+// ---- bank-conflict-free row images (round 6).  A stage's rows land in LDS by LDS-DMA, which writes base + 16 lane: the image is
+// linear, [32 rows][CPR 16-byte chunks].  A consumer's ds_read_b128 of an MFMA fragment takes chunk 4 kb + g of rows mr = 0..15;
+// with a row stride of K * 2 bytes = 768 (K = 384) all 16 rows start on the same bank: SQ_LDS_BANK_CONFLICT was 87 % of
+// SQ_LDS_IDX_ACTIVE on the K = 384 shapes and exactly 50 % on K = 96 / 288 (profiles/r5_step_rowstream_pmc.txt).  As in
+// gemm8.hip the fix sits on the DMA's SOURCE side: position `pos` of row r receives logical chunk pos ^ s(r) (inside aligned
+// groups of GRP = 16 / 8 / 4 chunks, whatever divides the row), and the reader asks for position c ^ s(r).  s() per row
+// width and per reader (the A fragment reads chunks in lane-group order g, the epilogue operand in the chunk-layout order
+// 2 (g & 1) + (g >> 1)) was chosen with scripts/lds_bank_model.py: every read below costs the ideal 4 LDS cycles.
+template <int CPR> struct RsSwz {
+    static constexpr int GRP = CPR % 16 == 0 ? 16 : (CPR % 8 == 0 ? 8 : 4);
+    static constexpr int NQ = GRP / 4;
+    template <bool EPI> static MVLT_DEV int s(int r) {
+        if constexpr (GRP == 16) return r & 15;
+        else if constexpr (GRP == 8) return EPI ? (2 * ((r >> 1) & 3) + ((r >> 3) & 1)) : ((r >> 1) & 7);
+        else return ((EPI ? 0xB4 : 0x78) >> (2 * ((r >> 2) & 3))) & 3;          // EPI: [0, 1, 3, 2], A: [0, 2, 3, 1] by (r >> 2) & 3
+    }
+    // logical chunk that position `pos` of row r holds (= position of logical chunk `pos`: the map is an involution)
+    template <bool EPI> static MVLT_DEV int chunk(int r, int pos) { return (pos & ~(GRP - 1)) | ((pos ^ s<EPI>(r)) & (GRP - 1)); }
+};
+
 struct RsArgs { GemmDev g; int n_chunks; };
 
 template <int K, int N, int WN, bool BKM, bool X2>
@@ -115,12 +135,13 @@ __global__ __launch_bounds__((2 * WN + 2) * 64) void rowstream_kernel(const RsAr
 #pragma unroll
             for (int j = 0; j < NIW; ++j) {
                 const int idx = 2 * j + lw;                           // this wave's instruction of the stage
-                if (idx < NIX) {                                      // activation rows: one contiguous block
-                    const long off = (long)r0 * K + (long)(idx * 64 + lane) * 8;
+                if (idx < NIX) {                                      // activation rows: one contiguous block, chunks swizzled inside each row
+                    const int q = idx * 64 + lane, r = q / (K / 8), pos = q - r * (K / 8);
+                    const long off = (long)(r0 + r) * K + RsSwz<K / 8>::template chunk<false>(r, pos) * 8;
                     glds16_asm(X + (off < xlast ? off : xlast), slot + idx * 1024);
                 } else if constexpr (X2) {                            // row operand of the epilogue: [32, N] of an ld-strided matrix
-                    const int q = (idx - NIX) * 64 + lane, r = q / (N / 8), ch = q - r * (N / 8);
-                    glds16_asm(E + (long)min(r0 + r, rows - 1) * lde + col0 + ch * 8, slot + idx * 1024);
+                    const int q = (idx - NIX) * 64 + lane, r = q / (N / 8), pos = q - r * (N / 8);
+                    glds16_asm(E + (long)min(r0 + r, rows - 1) * lde + col0 + RsSwz<N / 8>::template chunk<true>(r, pos) * 8, slot + idx * 1024);
                 }
             }
         };
@@ -172,6 +193,16 @@ __global__ __launch_bounds__((2 * WN + 2) * 64) void rowstream_kernel(const RsAr
             for (int kb = 0; kb < KS; ++kb)
                 fw[j][kb] = *reinterpret_cast<const bf16x8*>(W + (long)(col0 + ncol + 16 * j + mr) * p.ldb + 32 * kb + 8 * g);
     }
+    // byte offset of chunk 4 kb + g of this lane's row inside its aligned chunk group, for the NQ values of kb mod NQ
+    using SA = RsSwz<K / 8>;
+    using SE = RsSwz<N / 8>;
+    int xq[SA::NQ];
+    {
+        const int sa = SA::template s<false>(mr);
+#pragma unroll
+        for (int i = 0; i < SA::NQ; ++i) xq[i] = ((i ^ (sa >> 2)) & (SA::NQ - 1)) * 64 + ((g ^ sa) & 3) * 16;
+    }
+    const int se = SE::template s<true>(mr);
     const int epi = p.epi;
     f32x4 bias_lo[NP], bias_hi[NP];
 #pragma unroll
@@ -194,10 +225,10 @@ __global__ __launch_bounds__((2 * WN + 2) * 64) void rowstream_kernel(const RsAr
         f32x4 acc[FN];
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* xa = slot + ((16 * wm + mr) * K + 8 * g) * 2;
+        const char* xa = slot + (16 * wm + mr) * K * 2;
 #pragma unroll
         for (int kb = 0; kb < KS; ++kb) {
-            const bf16x8 fx = *reinterpret_cast<const bf16x8*>(xa + kb * 64);
+            const bf16x8 fx = *reinterpret_cast<const bf16x8*>(xa + (kb & ~(SA::NQ - 1)) * 64 + xq[kb & (SA::NQ - 1)]);
 #ifndef RS_ABL_NOMMA
 #pragma unroll
             for (int j = 0; j < FN; ++j) Mma<bf16_t>::mma(acc[j], fw[j][kb], fx);
@@ -231,7 +262,10 @@ __global__ __launch_bounds__((2 * WN + 2) * 64) void rowstream_kernel(const RsAr
             }
             if (do_scale) { lo *= sc; hi *= sc; }
             if constexpr (X2) {
-                const u32x4 ev = *reinterpret_cast<const u32x4*>(slot + XB + ((16 * wm + mr) * N + ncol + 32 * q + cofs) * 2);
+                // logical chunk 4 Q + cc of the row (Q = this fragment pair's 32-column quad, cc = cofs / 8) sits at position chunk ^ se
+                const int Q = (ncol >> 5) + q, cc = cofs >> 3;
+                const int epos = ((Q & ~(SE::NQ - 1)) | ((Q ^ (se >> 2)) & (SE::NQ - 1))) * 4 + ((cc ^ se) & 3);
+                const u32x4 ev = *reinterpret_cast<const u32x4*>(slot + XB + (16 * wm + mr) * N * 2 + epos * 16);
                 f32x4 elo, ehi;
                 unpack8(ev, elo, ehi);
                 if (do_aux) {

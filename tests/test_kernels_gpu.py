@@ -481,6 +481,47 @@ def test_layernorm_fwd_bwd(ops, dt, C):
     assert rel(dgam, gr.grad) < 1e-4 and rel(dbet, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("C,rows", [(96, 40013), (192, 20011), (384, 6272), (768, 4192), (128, 9001), (1024, 3001)])
+def test_layernorm_bwd_low_footprint_kernel(ops, C, rows):
+    """The round-6 LayerNorm backward (`ln_bwd2_kernel`: bf16, buffer-descriptor row operands, 4-wave blocks) at row counts
+    that make every wave walk several row groups (up to 512 blocks x 4 waves x 64 / LPR rows per pass), with the gathered
+    dy (Swin window order), the residual-path gradient, the scattered + DropPath-scaled branch output and a DEVICE row
+    count below the storage rows -- against the fp32 torch statement; rows beyond the device count must stay untouched."""
+    dt = torch.bfloat16
+    x = rnd((rows, C), dt, 220, 2.0)
+    g = (1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(221))).cuda()
+    b = (0.1 * torch.randn(C, generator=torch.Generator().manual_seed(222))).cuda()
+    _, mean, rstd, _ = ops.layernorm_fwd(x, g, b, 1e-5)
+    dy = rnd((rows, C), dt, 223)
+    dres = rnd((rows, C), dt, 224)
+    perm = torch.randperm(rows, generator=torch.Generator().manual_seed(225)).int().cuda()
+    rps = (rows + 4) // 5
+    rs = torch.tensor([0.5, 1.0, 0.0, 2.0, 1.25], device="cuda")
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.layer_norm(xr, (C,), gr, br, 1e-5).backward(dy.float()[perm.long()])           # row r receives dy[perm[r]]
+    want = xr.grad + dres.float()
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dx, dz = ops.layernorm_bwd(dy, x, mean, rstd, g, dgam, dbet, dy_rowmap=perm, dres=dres,
+                               branch=dict(rowmap=perm, rowscale=(rs, rps)))
+    assert rel(dx, want) < tol(dt)
+    assert rel(dgam, gr.grad) < 2e-4 and rel(dbet, br.grad) < 2e-4
+    exp = torch.empty_like(want)
+    exp[perm.long()] = dx.float() * rs[torch.arange(rows, device="cuda") // rps][:, None]
+    assert rel(dz, exp) < tol(dt)
+    # valid rows on the device: the tail keeps its sentinel, the parameter gradients see the valid rows only
+    nv = rows - 777
+    rows_dev = torch.tensor([nv], dtype=torch.int32, device="cuda")
+    dx2 = torch.full_like(x, 7.0)
+    ops.layernorm_bwd(dy, x, mean, rstd, g, dgam, dbet, dres=dres, dx=dx2, rows_dev=rows_dev)
+    xr2 = x.float()[:nv].requires_grad_(True)
+    gr2 = g.clone().requires_grad_(True)
+    F.layer_norm(xr2, (C,), gr2, b, 1e-5).backward(dy.float()[:nv])
+    assert rel(dx2[:nv], xr2.grad + dres.float()[:nv]) < tol(dt)
+    assert bool((dx2[nv:] == 7.0).all())
+    assert rel(dgam, gr2.grad) < 2e-4
+
+
 def test_integration_md_binding_example_runs():
     """the ctypes stub printed in INTEGRATION.md is extracted, executed as is and its function is
     checked against torch (LayerNorm + window-order row scatter, visual_feature_extractor.py:356-367)."""
