@@ -195,7 +195,7 @@ int mvlt_layernorm_bwd_workspace_rows(void);
  * nsplit slabs [nsplit][rows][C] (f32) of mvlt_gemm_skinny_accum (read only).  residual may be NULL. */
 int mvlt_layernorm_acc_fwd(int dtype, const float* acc, int nsplit, const float* bias, const void* residual, const float* gamma,
                            const float* beta, float eps, int rows, int C, void* y, void* stream);
-/* deferred parameter-gradient reduction: one launch per 24 LayerNorms instead of one per LayerNorm.
+/* deferred parameter-gradient reduction: one launch per 96 LayerNorms instead of one per LayerNorm.
  * items is a HOST array; workspace = the buffer given to mvlt_layernorm_bwd, nparts = mvlt_layernorm_bwd_nparts(rows, C). */
 typedef struct MvltLnReduceItem { const float* workspace; int nparts, C; float* dgamma; float* dbeta; } MvltLnReduceItem;
 int mvlt_layernorm_bwd_nparts(int rows, int C);

@@ -1397,9 +1397,16 @@ extern "C" int mvlt_gemm_argmax_greedy(const MvltGemm* p, float* part_val, int32
     GemmDev d;
     Plan pl{64, 16, 1};
     const int nblk = ceil_div(p->N, 16);
-    if (p->dtype == MVLT_BF16) { const int rc = fill_dev<bf16_t>(p, pl, d); if (rc != MVLT_OK) return rc; argmax_products<bf16_t>(p, d, part_val, part_idx, nblk, s); }
-    else if (p->dtype == MVLT_F32) { const int rc = fill_dev<float>(p, pl, d); if (rc != MVLT_OK) return rc; argmax_products<float>(p, d, part_val, part_idx, nblk, s); }
-    else return MVLT_ERR_UNSUPPORTED;
+    // the same preconditions as mvlt_gemm_argmax (the skinny kernels walk whole k-blocks with 16-byte fragment loads: a K that is
+    // not a multiple of the k-block would silently lose its tail, unaligned strides would fault) -- ADVICE r5
+    MVLT_CHECK(g->ld_ids > 0 && g->ld_scores > 0 && g->ld_new > 0 && g->col != nullptr, MVLT_ERR_ARG);
+    if (p->dtype == MVLT_BF16) {
+        MVLT_CHECK(is_skinny<bf16_t>(p) && p->lda % TypeInfo<bf16_t>::E == 0 && p->ldb % TypeInfo<bf16_t>::E == 0 && aligned16(p->A) && aligned16(p->B), MVLT_ERR_UNSUPPORTED);
+        const int rc = fill_dev<bf16_t>(p, pl, d); if (rc != MVLT_OK) return rc; argmax_products<bf16_t>(p, d, part_val, part_idx, nblk, s);
+    } else if (p->dtype == MVLT_F32) {
+        MVLT_CHECK(is_skinny<float>(p) && p->lda % TypeInfo<float>::E == 0 && p->ldb % TypeInfo<float>::E == 0 && aligned16(p->A) && aligned16(p->B), MVLT_ERR_UNSUPPORTED);
+        const int rc = fill_dev<float>(p, pl, d); if (rc != MVLT_OK) return rc; argmax_products<float>(p, d, part_val, part_idx, nblk, s);
+    } else return MVLT_ERR_UNSUPPORTED;
     GreedyState st{g->unfinished, g->eos_id, g->pad_id, g->has_eos, g->col, g->past, g->ids, g->ld_ids, g->scores, g->ld_scores, g->alive,
                    g->new_ids, g->ld_new, g->ticket};
     hipLaunchKernelGGL(greedy_pick_kernel, dim3(p->M), dim3(256), 0, s, part_val, part_idx, nblk, p->M, st);

@@ -514,7 +514,12 @@ void side_release() { g_side_keepalive.clear(); g_ws_side.retired.clear(); g_ws_
 // a HIP graph has recorded the addresses of the current scratch buffers: keep them alive for the life of the process
 std::vector<Tensor> g_pinned_scratch;
 void scratch_pin() {
-    for (Scratch* s : {&g_ws_main, &g_ws_side}) if (s->buf.defined()) g_pinned_scratch.push_back(s->buf);
+    for (Scratch* s : {&g_ws_main, &g_ws_side}) {
+        if (!s->buf.defined()) continue;
+        bool have = false;
+        for (const Tensor& t : g_pinned_scratch) have = have || t.data_ptr() == s->buf.data_ptr();
+        if (!have) g_pinned_scratch.push_back(s->buf);          // once per buffer, however many graphs are captured
+    }
 }
 
 // which: 0 = grouped weight-gradient launches, 1 = forward / dgrad products issued by the layer calls

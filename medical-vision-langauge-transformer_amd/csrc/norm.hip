@@ -413,7 +413,7 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* part
 constexpr int LN_REDUCE_BATCH = 96;          // 96 x 32 B of kernel arguments: the ~52 LayerNorms of a Swin backward pass in ONE launch
 struct LnReduceBatch { MvltLnReduceItem it[LN_REDUCE_BATCH]; int n; };
 static_assert(sizeof(LnReduceBatch) <= 3584, "kernel argument block");
-// one launch reduces the partial rows of up to 24 LayerNorms: blockIdx.y = item, blockIdx.x = 64-column group
+// one launch reduces the partial rows of up to 96 LayerNorms (LN_REDUCE_BATCH): blockIdx.y = item, blockIdx.x = 64-column group
 __global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnReduceBatch b) {
     __shared__ float red[2][16][64];
     const MvltLnReduceItem it = b.it[blockIdx.y];
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnRed
         const float* pg = it.workspace;
         const float* pb = it.workspace + (long)LN_PARTS_STRIDE * it.C;
         // four rows of each matrix in flight per step (a plain loop waits out one load latency per partial row: 39 us for
-        // the 24 LayerNorms of a Swin / BERT pass)
+        // the 24 LayerNorms of a Swin / BERT pass of that round)
         float g1 = 0.f, g2 = 0.f, g3 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
         int i = w;
         for (; i + 48 < it.nparts; i += 64) {

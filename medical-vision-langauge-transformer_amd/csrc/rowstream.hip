@@ -92,6 +92,29 @@ template <int CPR> struct RsSwz {
     template <bool EPI> static MVLT_DEV int chunk(int r, int pos) { return (pos & ~(GRP - 1)) | ((pos ^ s<EPI>(r)) & (GRP - 1)); }
 };
 
+// k-major weight image [K][N] (dgrads), read once per workgroup by the transposing ds_read_b64_tr_b16: the 16 k-rows of a fragment
+// half sit N * 2 bytes apart (768 B at N = 384: all on one bank group, 8-way conflicts).  Row k's 16-byte chunks are XOR-ed
+// with wswz(k) (even: the two chunks a lane group reads stay neighbours); same model, every read at the ideal 2 cycles.
+template <int N> MVLT_DEV int rs_wswz(int k) {
+    constexpr int CPR = N / 8;
+    if constexpr (CPR % 16 == 0) return 2 * (k & 3) + 8 * ((k >> 3) & 1);
+    else if constexpr (CPR % 8 == 0) return 2 * ((k >> 1) & 1) + 4 * ((k >> 3) & 1);
+    else return 2 * ((k >> 3) & 1);
+}
+template <int N> MVLT_DEV bf16x8 rs_frag_kmajor(const bf16_t* wl, int row0, int k0) {
+    const int l = threadIdx.x & 63;
+    const int g = l >> 4, i = l & 15, q = i >> 2, pp = i & 3;
+    const int ka = k0 + 8 * g + q, kb = ka + 4, n = row0 + 4 * pp, ch = n >> 3, w = n & 7;
+    const bf16_t* p0 = wl + ka * N + ((ch ^ rs_wswz<N>(ka)) << 3) + w;
+    const bf16_t* p1 = wl + kb * N + ((ch ^ rs_wswz<N>(kb)) << 3) + w;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
 struct RsArgs { GemmDev g; int n_chunks; };
 
 template <int K, int N, int WN, bool BKM, bool X2>
@@ -151,8 +174,8 @@ __global__ __launch_bounds__((2 * WN + 2) * 64) void rowstream_kernel(const RsAr
             const unsigned wdst = lds0 + (unsigned)(RING - Cfg::SW) * SL;
 #pragma unroll
             for (int j = 0; j < NIWW; ++j) {
-                const int idx = 2 * j + lw, q = idx * 64 + lane, k = q / (N / 8), ch = q - k * (N / 8);
-                glds16_asm(W + (long)k * p.ldb + col0 + ch * 8, wdst + idx * 1024);
+                const int idx = 2 * j + lw, q = idx * 64 + lane, k = q / (N / 8), pos = q - k * (N / 8);
+                glds16_asm(W + (long)k * p.ldb + col0 + (pos ^ rs_wswz<N>(k)) * 8, wdst + idx * 1024);
             }
             for (int s = 0; s < D0; ++s) if (s < ns) issue(s);
             rs_wait_rem<NIW, D0>(ns < D0 ? ns : D0);                  // the weight image has landed
@@ -183,7 +206,7 @@ __global__ __launch_bounds__((2 * WN + 2) * 64) void rowstream_kernel(const RsAr
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int kb = 0; kb < KS; ++kb) fw[j][kb] = frag_kmajor(wl, N, ncol + 16 * j, 32 * kb);
+            for (int kb = 0; kb < KS; ++kb) fw[j][kb] = rs_frag_kmajor<N>(wl, ncol + 16 * j, 32 * kb);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         rs_barrier();                                                 // P2
     } else {

@@ -106,7 +106,7 @@ class GradReducer:
         fork_stream: issue the buckets from a helper stream that waits for the main AND the weight-gradient stream, so
         the main stream is not stalled at bucket boundaries (one rank over RCCL, B=32: 14.7 ms per step against 15.9 with
         the main stream joining the weight-gradient stream before each bucket; 13.6 without a reducer).  Default (None):
-        the MVLT_DDP_FORK environment switch, ON.  What orders the exchange: the helper stream waits for everything queued
+        the MVLT_DDP_FORK environment switch, which is OFF unless set to 1 (see the end of this paragraph).  What orders the exchange: the helper stream waits for everything queued
         on both streams when the bucket leaves (each gradient element is written once per backward pass, before that point
         -- tests/test_model_gpu.py::test_ddp_buckets_carry_final_gradients checks every element, both settings run in
         tests/test_ddp_gpu.py); _finish waits for every handle before the optimizer or the next backward pass touches
@@ -187,6 +187,15 @@ class GradReducer:
                 if had is not None:
                     self.model.__dict__["_mvlt_label_sync"] = had
         return ctx()
+
+    def no_sync(self):
+        """Deprecated alias of :meth:`no_label_sync` (the name this method had up to round 4; kept so that existing callers and
+        loops ported from torch DDP do not break with AttributeError).  NOTE the semantics: gradients of a backward() inside
+        the context ARE still exchanged -- only the label-count collective of the forward is skipped."""
+        import warnings
+        warnings.warn("GradReducer.no_sync() is a deprecated alias of no_label_sync(): gradients are still exchanged inside it "
+                      "(this engine overwrites gradients per backward pass; it has no accumulation mode)", DeprecationWarning, stacklevel=2)
+        return self.no_label_sync()
 
     def label_sync(self, count: torch.Tensor) -> torch.Tensor:
         """count: f32 [1] on this rank's device = labelled tokens of this rank's shard.  Returns N_global / world (f32 [1]):

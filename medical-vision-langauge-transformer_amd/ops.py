@@ -142,8 +142,15 @@ _pinned_scratch = []
 
 
 def pin_scratch():
-    """A HIP graph is about to record (or has recorded) the addresses of the scratch workspaces: never free them."""
-    _pinned_scratch.extend(_ws.values())
+    """A HIP graph is about to record (or has recorded) the addresses of the scratch workspaces: never free them.
+    Idempotent (a buffer is pinned once, by address) and limited to the buffers a capture can have seen: the "graph"-tagged
+    Python workspaces and the native host path's scratch (the training pass's split-K workspaces used to be pinned
+    again at every capture)."""
+    have = {b.data_ptr() for b in _pinned_scratch}
+    for key, buf in _ws.items():
+        if key[2] == "graph" and buf.data_ptr() not in have:
+            _pinned_scratch.append(buf)
+            have.add(buf.data_ptr())
     if _host is not None:
         _host.scratch_pin()
 
@@ -723,9 +730,21 @@ def wmsa2_sync_ws(device, words):
     launch leaves its counters zeroed; word 0 is the sticky error count (include/mvlt_hip.h).  One workspace per (device,
     stream): launches of one stream are serialised, launches of different streams never share counters."""
     st = _stream_cache[0]          # (pinned by the engines for the duration of a pass: torch.cuda.current_stream costs ~5 us)
-    key = (torch.device(device), (st.value or 0) if st is not None else torch.cuda.current_stream(device).cuda_stream)
+    if _stream_cache[1] == "graph":
+        # ONE workspace for every captured inference graph of the device (replays are serialised on the caller's stream): it is
+        # allocated and zeroed by the eager warm-up run that precedes a capture (runtime.GraphedEval._capture), so no memset is
+        # ever captured -- a replay must not clear the sticky error count -- and it is never reallocated under a graph that has
+        # its address baked in (a larger one is a NEW buffer; the old one is kept alive)
+        key = (torch.device(device), "graph")
+    else:
+        key = (torch.device(device), (st.value or 0) if st is not None else torch.cuda.current_stream(device).cuda_stream)
     ws = _WMSA2_SYNC.get(key)
     if ws is None or ws.numel() < words:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mvlt_amd: the W-MSA hand-off workspace must exist before a HIP-graph capture (run the call once "
+                               "eagerly under ops.on_stream(stream, 'graph') first, as runtime.GraphedEval does)")
+        if ws is not None and key[1] == "graph":
+            _ws_graph_keep.append(ws)
         ws = torch.zeros(max(words, 4096), dtype=torch.int32, device=device)
         _WMSA2_SYNC[key] = ws
     return ws

@@ -63,9 +63,13 @@ class GraphedEval:
     copy is refreshed before every replay).  Arguments may be tensors or None.  Outputs are returned as fresh clones.
     The first ``warmup`` calls of a signature run eagerly (lazy state, allocator); capture happens on a private stream."""
 
+    MAX_GRAPHS = 8       # signatures kept captured per module (least recently used beyond that is dropped; ADVICE r5: variable
+                         # question lengths / batch sizes must not grow graphs and their memory without bound)
+
     def __init__(self, fn, module, warmup=2):
         self.fn, self.module, self.warmup = fn, module, warmup
         self.seen, self.graphs = {}, {}
+        self._pool = None    # one private memory pool shared by every graph of this module
 
     @staticmethod
     def _sig(args):
@@ -84,13 +88,22 @@ class GraphedEval:
             self.seen[key] = n + 1
             if n < self.warmup:
                 return self.fn(*args)
+            if len(self.graphs) >= self.MAX_GRAPHS:
+                del self.graphs[next(iter(self.graphs))]          # dicts keep insertion order: the least recently used entry
+                if len(self.seen) > 64:
+                    self.seen.clear()
             ent = self.graphs[key] = self._capture(args)
+        else:
+            self.graphs[key] = self.graphs.pop(key)              # most recently used last
         static_in, static_out, graph = ent
         for s, a in zip(static_in, args):
             if s is not None:
                 s.copy_(a, non_blocking=True)
         ar.refresh_shadow()                      # parameters written since the last call (load_state_dict, an optimizer step)
         graph.replay()
+        # a hand-off wait of the fused Swin attention that ran out inside the replay poisons the outputs with NaN; the sticky
+        # count is looked at here without a sync (raises one call late, like PretrainStep) -- ADVICE r5
+        ops.wmsa2_check(sync=False)
         outs = tuple(o.clone() if isinstance(o, torch.Tensor) else o for o in static_out)
         return outs if len(outs) != 1 else outs[0]
 
@@ -105,9 +118,11 @@ class GraphedEval:
         torch.cuda.synchronize()
         ops.pin_scratch()                        # workspaces whose addresses the graph records must never be freed
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, pool=self._pool):
             with ops.on_stream(torch.cuda.current_stream(), "graph"):
                 out = self.fn(*static_in)
+        if self._pool is None:
+            self._pool = g.pool()
         ops.pin_scratch()
         out = out if isinstance(out, tuple) else (out,)
         return static_in, out, g
