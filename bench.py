@@ -273,7 +273,14 @@ def one_rank_rccl(steps=40, warmup=10):
     own cost, the rest is RCCL's one-rank pass over the 836 MB gradient arena (a copy a real ring does not make)."""
     import subprocess
     out = {}
-    for key, extra in (("ms_per_step", {}), ("ms_per_step_without_the_collective", {"MVLT_DDP_NULL_COLLECTIVE": "1"})):
+    arms = (("ms_per_step", {}), ("ms_per_step_without_the_collective", {"MVLT_DDP_NULL_COLLECTIVE": "1"}),
+            # round 6: the same run with the end-of-backward wait deferred (what is left is the collective's kernel BESIDE the
+            # backward pass: the exposed tail is the difference to the first figure), and a rehearsal of world size 8 -- every
+            # bucket copied twice by 32 persistent workgroups at a few hundred GB/s on a third stream, the shape of a ring
+            # all-reduce that is xGMI-bound for milliseconds (mvlt_amd/ddp.py: MVLT_DDP_DEFER_WAIT, MVLT_DDP_REHEARSE)
+            ("ms_per_step_wait_deferred", {"MVLT_DDP_DEFER_WAIT": "1"}),
+            ("ms_per_step_ring_rehearsal_32wg", {"MVLT_DDP_REHEARSE": "32,2"}))
+    for key, extra in arms:
         env = dict(os.environ, MVLT_FORCE_DDP="1", **extra)
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup),
@@ -283,8 +290,9 @@ def one_rank_rccl(steps=40, warmup=10):
         except Exception as e:          # the headline must not depend on this extra
             out[key] = None
             out["error"] = repr(e)[:200]
-    out["workload"] = ("config #2 step with GradReducer over RCCL on one rank (MVLT_FORCE_DDP=1): 64 MiB buckets exchanged one bucket "
-                       "late on the main stream; second figure: reducer without the collective")
+    out["workload"] = ("config #2 step with GradReducer over RCCL on one rank (MVLT_FORCE_DDP=1): 64 MiB buckets (8 MiB for the last 32 MB "
+                       "of the arena) exchanged one bucket late on the main stream; second figure: reducer without the collective; third: "
+                       "collective issued, end-of-backward wait deferred; fourth: ring-collective rehearsal (2 x bucket bytes, 32 workgroups)")
     return out
 
 

@@ -308,6 +308,12 @@ int mvlt_swin_wmsa2_set_timeout_ms(int ms);    /* bound of the hand-off wait, pr
 /* Diagnostic: `blocks` workgroups of 256 threads, each holding lds_bytes of LDS, spin for `usec` microseconds (100 MHz
  * real-time clock) and exit.  The tests use it to take CUs away from a launch that needs its workgroups co-resident. */
 int mvlt_debug_hold_cus(int blocks, int lds_bytes, int usec, void* stream);
+/* Diagnostic: copy `bytes` (multiple of 16, 16-byte aligned; dst may equal src) with `blocks` persistent workgroups of 256
+ * threads and `inflight` (1..4) 16-byte loads in flight per thread -- the launch geometry of a ring collective's kernel,
+ * i.e. a few hundred GB/s for milliseconds.  bench.py's one-GPU rehearsal of the data-parallel step issues it where the
+ * all-reduce of a gradient bucket would run (MVLT_DDP_REHEARSE, mvlt_amd.ddp).  No reference counterpart (the reference
+ * has no distributed code). */
+int mvlt_debug_stream_copy(void* dst, const void* src, int64_t bytes, int blocks, int inflight, void* stream);
 
 /* ------------------------------------------------------------------ data movement / embeddings
  * PatchEmbed im2col (visual_feature_extractor.py:562): img f32 NCHW [B,3,S,S]

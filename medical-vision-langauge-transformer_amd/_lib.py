@@ -148,6 +148,7 @@ SYMBOLS = {
     "mvlt_swin_wmsa2_fwd": (i32, [C.POINTER(MvltSwinWmsa), vp, vp]),
     "mvlt_swin_wmsa2_set_timeout_ms": (i32, [i32]),
     "mvlt_debug_hold_cus": (i32, [i32, i32, i32, vp]),
+    "mvlt_debug_stream_copy": (i32, [vp, vp, i64, i32, i32, vp]),
     "mvlt_im2col_patch": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "mvlt_pack_plan": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "mvlt_label_plan": (i32, [vp, vp, i32, vp, vp, vp, vp]),

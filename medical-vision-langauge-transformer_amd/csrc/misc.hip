@@ -1043,6 +1043,33 @@ __global__ __launch_bounds__(256) void hold_cus_kernel(long long ticks, int lds_
 }
 }  // namespace
 
+// Diagnostic (bench.py's one-GPU rehearsal of the multi-GPU step): a copy with the launch geometry of a ring collective -- FEW
+// persistent workgroups, each streaming its slice with a bounded number of loads in flight -- so that it moves `bytes` at a
+// few hundred GB/s for milliseconds beside the backward pass, the way RCCL's kernel does at world size 8 (xGMI-bound), instead
+// of finishing at HBM speed.  dst may equal src (values unchanged).
+namespace {
+__global__ __launch_bounds__(256) void stream_copy_kernel(u32x4* dst, const u32x4* src, long n16, int inflight) {
+    const long per = (n16 + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+    for (long i = lo + threadIdx.x; i < hi; i += 256L * 4) {
+        u32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < inflight && i + 256L * j < hi) v[j] = __builtin_nontemporal_load(src + i + 256L * j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < inflight && i + 256L * j < hi) __builtin_nontemporal_store(v[j], dst + i + 256L * j);
+        if (inflight < 4) for (int j = inflight; j < 4; ++j) if (i + 256L * j < hi) dst[i + 256L * j] = src[i + 256L * j];
+    }
+}
+}  // namespace
+
+extern "C" int mvlt_debug_stream_copy(void* dst, const void* src, int64_t bytes, int blocks, int inflight, void* stream) {
+    MVLT_CHECK(dst && src && bytes > 0 && bytes % 16 == 0 && aligned16(dst) && aligned16(src), MVLT_ERR_ARG);
+    MVLT_CHECK(blocks >= 1 && blocks <= 1024 && inflight >= 1 && inflight <= 4, MVLT_ERR_ARG);
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(blocks), dim3(256), 0, STREAM(stream), (u32x4*)dst, (const u32x4*)src, (long)(bytes / 16), inflight);
+    MVLT_LAUNCH_CHECK();
+    return MVLT_OK;
+}
+
 extern "C" int mvlt_debug_hold_cus(int blocks, int lds_bytes, int usec, void* stream) {
     MVLT_CHECK(blocks >= 1 && blocks <= 4096 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && usec >= 0 && usec <= 5000000, MVLT_ERR_ARG);
     auto k = hold_cus_kernel;

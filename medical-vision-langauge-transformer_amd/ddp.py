@@ -90,6 +90,26 @@ def plan_ranges(arena: Arena, lo: int, hi: int, done: set, gap_elems: int = GAP_
 # MVLT_DDP_NULL_COLLECTIVE=1 (diagnostic, one rank only): the reducer runs -- buckets, events, stream joins, LayerNorm flushes --
 # but issues no collective: what is left over a run without a reducer is the reducer's own cost
 _NULL_COLLECTIVE = os.environ.get("MVLT_DDP_NULL_COLLECTIVE", "0") == "1"
+# MVLT_DDP_DEFER_WAIT=1 (diagnostic, one rank only): the collectives are issued as usual but the end of the backward pass does not
+# wait for them -- the optimizer runs beside the last buckets.  (step with the wait) - (step without) = the EXPOSED tail of the
+# exchange; (step without the wait) - (step without the collective) = what the collective's kernel costs the backward pass it runs
+# beside.  Correct on ONE rank only (an in-place all-reduce over one rank leaves the gradients as they are).
+_DEFER_WAIT = os.environ.get("MVLT_DDP_DEFER_WAIT", "0") == "1"
+# MVLT_DDP_REHEARSE="blocks[,inflight]" (diagnostic, one rank only): instead of the collective every bucket is copied twice (the
+# reduce-scatter and the all-gather pass of a ring both read and write the local buffer once) by a kernel with a ring collective's
+# launch geometry -- `blocks` persistent workgroups, a few hundred GB/s -- on a third stream: what the backward pass loses to a
+# collective that is xGMI-bound for milliseconds, which RCCL's one-rank memcpy does not show.  Gradients are left unchanged.
+_REHEARSE = os.environ.get("MVLT_DDP_REHEARSE", "")
+
+
+class _EventHandle:
+    """Handle of a rehearsal copy: wait() orders the current stream behind it, like a Work handle of the process group."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
 
 
 class GradReducer:
@@ -129,6 +149,15 @@ class GradReducer:
         self.pending_casts = []
         self.model = model
         self.bucket_elems = bucket_bytes // 4
+        # Tapered tail (round 6): what _finish issues at the end of the backward pass is serial behind the
+        # last Swin stage-0 kernel at ANY world size -- with one bucket size that is the lagged bucket plus the remainder, up
+        # to 2 x 64 MiB.  The gradients that become ready last sit at the LOW end of the arena (patch embedding, Swin stages
+        # 0 / 1, the first stage-2 blocks); below `taper_elems` buckets close at `tail_bucket_elems`, so at most two small
+        # buckets are still unsent when the backward pass ends.  MVLT_DDP_TAPER_MB / MVLT_DDP_TAIL_BUCKET_MB (0 = no taper).
+        taper_mb = float(os.environ.get("MVLT_DDP_TAPER_MB", "32"))
+        tail_mb = float(os.environ.get("MVLT_DDP_TAIL_BUCKET_MB", "8"))
+        self.taper_elems = int(taper_mb * (1 << 20)) // 4
+        self.tail_bucket_elems = min(self.bucket_elems, max(1, int(tail_mb * (1 << 20)) // 4)) if taper_mb > 0 and tail_mb > 0 else self.bucket_elems
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         try:
@@ -206,6 +235,8 @@ class GradReducer:
 
     # ---- hooks called by the engines (runtime.backward_begin / arena.watermark / backward_end)
     def _begin(self, arena: Arena) -> None:
+        for h in self.__dict__.pop("_deferred", []):
+            h.wait()
         self.pending_hi = arena.total
         self.handles, self.launched, self.done = [], [], set()
         self.pending_casts = []
@@ -219,7 +250,11 @@ class GradReducer:
         return (not p.requires_grad) or (self.prev_marked is not None and id(p) not in self.prev_marked)
 
     def _on_watermark(self, arena: Arena, lo: int) -> None:
-        if self.pending_hi - lo >= self.bucket_elems:
+        # bucket size by where the watermark stands: full-size buckets while most of the backward pass is still ahead, small
+        # ones for the last `taper_elems` of the arena (scaled down for small arenas so that tests see both regimes)
+        taper = min(self.taper_elems, arena.total // 4)
+        need = self.tail_bucket_elems if lo < taper else self.bucket_elems
+        if self.pending_hi - lo >= need:
             self._close(arena, lo, self.pending_hi)
             self.pending_hi = lo
 
@@ -269,6 +304,28 @@ class GradReducer:
         def reduce_ranges(rs):
             if _NULL_COLLECTIVE:          # diagnostic (scripts/r5_ddp_overhead.sh): everything but the collective itself
                 return []
+            if _REHEARSE and arena.flat.is_cuda and self.world == 1:
+                from . import ops
+                parts = [int(v) for v in _REHEARSE.split(",")]
+                blocks, inflight = parts[0], (parts[1] if len(parts) > 1 else 2)
+                st = self.__dict__.get("_rehearse_stream")
+                if st is None:
+                    st = self._rehearse_stream = torch.cuda.Stream(device=arena.flat.device)
+                    self._rehearse_buf = torch.empty(self.bucket_elems + (64 << 10), dtype=torch.float32, device=arena.flat.device)
+                st.wait_stream(torch.cuda.current_stream())
+                hs = []
+                for a, b in rs:
+                    for c0 in range(a, b, self._rehearse_buf.numel()):
+                        c1 = min(b, c0 + self._rehearse_buf.numel())
+                        n = (c1 - c0) // 4 * 4
+                        if n <= 0:
+                            continue
+                        ops.debug_stream_copy(self._rehearse_buf[:n], arena.grad[c0:c0 + n], blocks, inflight, stream=st)
+                        ops.debug_stream_copy(arena.grad[c0:c0 + n], self._rehearse_buf[:n], blocks, inflight, stream=st)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    hs.append(_EventHandle(ev))
+                return hs
             return [dist.all_reduce(arena.grad[a:b], op=op, group=self.pg, async_op=True) for a, b in rs]
 
         if self.comm_dtype == torch.float32 and fork is not None and self.on_bucket is None:
@@ -324,8 +381,11 @@ class GradReducer:
         self._launch(arena, 0, arena.total)
         self.pending_hi = 0
         self.prev_marked = {id(p) for p in arena._marked}
-        for h in self.handles:
-            h.wait()
+        if _DEFER_WAIT and self.world == 1 and arena.flat.is_cuda:
+            self._deferred = self.handles          # diagnostic: waited for at the start of the next backward pass
+        else:
+            for h in self.handles:
+                h.wait()
         self.handles = []
         if arena.flat.is_cuda:
             from . import ops

@@ -805,6 +805,15 @@ def wmsa2_set_timeout_ms(ms):
     L.check(L.lib().mvlt_swin_wmsa2_set_timeout_ms(int(ms)), "mvlt_swin_wmsa2_set_timeout_ms")
 
 
+def debug_stream_copy(dst, src, blocks=32, inflight=2, stream=None):
+    """Diagnostic: copy src -> dst (same byte count, may alias) with the launch geometry of a ring collective's kernel."""
+    _need_cuda(dst, src)
+    nbytes = src.numel() * src.element_size()
+    assert dst.numel() * dst.element_size() == nbytes and nbytes % 16 == 0
+    st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    L.check(L.lib().mvlt_debug_stream_copy(_p(dst), _p(src), nbytes, int(blocks), int(inflight), st), "mvlt_debug_stream_copy")
+
+
 def debug_hold_cus(blocks, lds_bytes, usec, stream=None):
     """Diagnostic: occupy CUs with spinning workgroups on `stream` (default: the current one)."""
     st = stream.cuda_stream if stream is not None else _stream()

@@ -43,10 +43,13 @@ def _real_model_marks(model):
     return order
 
 
-def _worker_real(rank, world, port, q, average):
+def _worker_real(rank, world, port, q, average, taper=False):
     """The REAL model's arena (582 parameters, fused QKV groups, idle MLM head, never-used parameters) under the
-    reducer: one emulated backward pass per rank over gloo."""
+    reducer: one emulated backward pass per rank over gloo.  taper: small buckets for the low end of the arena (the gradients
+    that become ready LAST), so that little is left for the serial tail behind the backward pass (round 6)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if taper:
+        os.environ.update(MVLT_DDP_TAPER_MB="4", MVLT_DDP_TAIL_BUCKET_MB="0.125")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys
@@ -83,8 +86,20 @@ def _worker_real(rank, world, port, q, average):
                 ar.mark(*grp)
             n_early = len(red.launched)
             assert n_early >= 2, "buckets should leave while the backward pass is still running"
+            sent_before_end = sum(b - a for a, b in red.launched)
             runtime.backward_end(ar)
             covered = sorted(red.launched)
+            if taper:
+                # what the end of the backward pass still had to send (the serial tail) is at most two tail buckets + the
+                # merged gap allowance, and the ranges of the tapered region are small while the early ones are full size
+                total_sent = sum(b - a for a, b in covered)
+                tail = total_sent - sent_before_end
+                assert tail <= 2 * red.tail_bucket_elems + 2 * red.gap_elems + 70000, (tail, red.tail_bucket_elems)
+                lim = min(red.taper_elems, ar.total // 4)
+                low = [b - a for a, b in covered if b <= lim]
+                high = [b - a for a, b in covered if a >= lim]
+                assert len(low) >= 3 and max(low) < red.bucket_elems, (low[:8], red.bucket_elems)      # (a bucket is never smaller than one block's parameters)
+                assert max(high) >= red.bucket_elems // 2, (max(high), red.bucket_elems)
             for (a0, b0), (a1, b1) in zip(covered, covered[1:]):
                 assert b0 <= a1, "overlapping all-reduce ranges"
             # the idle MLM head (the one large block without a gradient) is never communicated; the small never-used
@@ -97,7 +112,7 @@ def _worker_real(rank, world, port, q, average):
                 assert named[k].grad is None
             if pass_no == 0:
                 assert not red.rode_along, "the first pass must not merge gaps"
-            else:
+            elif not taper:
                 # one collective per bucket: at most one more range than bucket launches (the head block behind the idle head)
                 assert red.rode_along and len(covered) <= n_early + 3, (len(covered), n_early)
             scale = 1.0 / world if average else 1.0
@@ -218,15 +233,15 @@ def test_gradient_exchange_two_ranks_gloo(bf16_comm):
     assert all(r[1] == "ok" for r in res), res
 
 
-@pytest.mark.parametrize("average", [True, False])
-def test_real_model_arena_two_ranks_gloo(average):
+@pytest.mark.parametrize("average,taper", [(True, False), (False, False), (True, True)])
+def test_real_model_arena_two_ranks_gloo(average, taper):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, q, average)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, q, average, taper)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
