@@ -54,10 +54,12 @@ struct Wmsa2Dev {
 
 // Hand-off workspace (int32 words).  The layout does not depend on the batch size, so one workspace serves every launch of a
 // stream: word 0 = sticky error count (bounded waits that ran out since the words were last cleared), words 1..15 unused,
-// then per window set {arrivals, readers done}; both counters are back at 0 when a launch has finished.
+// then per window set 8 words: one ARRIVAL FLAG per head group (round 6: was one arrival counter) and the readers-done
+// counter; all of them are back at 0 when a launch has finished.
 #define W2_SYNC_ERROR 0
-#define W2_SYNC_ARRIVE(set) (16 + 2 * (set))
-#define W2_SYNC_DONE(set) (17 + 2 * (set))
+#define W2_SYNC_STRIDE 8     /* words per window set: arrival flag of head group g at +g (g < 7), readers-done counter at +7 */
+#define W2_SYNC_FLAG(set, g) (16 + W2_SYNC_STRIDE * (set) + (g))
+#define W2_SYNC_DONE(set) (16 + W2_SYNC_STRIDE * (set) + 7)
 #define W2_TBL_FLAG 175      // pad entry of the LDS bias table (indices 170..175 are never addressed)
 
 template <int C, int W, int G, int GS> struct W2Geom {
@@ -327,8 +329,12 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                     }
                     asm volatile("" ::: "memory");
                 }
-                if (row < MR) {
-                    const bool rv = tok[ps] >= 0;
+                if (row >= M && row < MR) {
+                    // padded rows of the last 16-row tile: zeros (finite values nobody reads) -- no statistics, no arithmetic
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) *reinterpret_cast<bf16x8*>(xln + xoff<C>(row, sub + LPR * i)) = zero_vec<T>();
+                } else if (row < M) {
+                    const bool rv = true;
                     // sum and sum of squares with the packed dot product (no conversions), reduced over the row's lanes by DPP
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -347,16 +353,22 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                     if (save && sub == 0 && p.mean) { p.mean[tok[ps]] = mean; p.rstd[tok[ps]] = rstd; }
                     T* xs = (p.xn && save) ? p.xn + (grow0 + row) * C : nullptr;
                     const float nm = -mean * rstd;
+                    const f32x2 rs2{rstd, rstd}, nm2{nm, nm};
 #pragma unroll
                     for (int i = 0; i < CPL; ++i) {
                         const int ch = sub + LPR * i;
                         bf16x8 o;
+                        // ((x rstd + nm) gamma + beta) on element PAIRS: two v_pk_fma_f32 per pair instead of a multiply and two
+                        // fmas per element (round 6: the LayerNorm phase is ~500 vector instructions per wave, all of them issue)
+                        const u32x4 xw = __builtin_bit_cast(u32x4, xv[ps][i]);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float gm = ga[i][e >> 2][e & 3], bt = be[i][e >> 2][e & 3];
-                            // (x - mean) rstd gamma + beta = x (rstd gamma) + (beta - mean rstd gamma)
-                            // (padded rows normalise token 0's data: finite values nobody reads -- no per-element select)
-                            o[e] = (T)fmaf((float)xv[ps][i][e], rstd * gm, fmaf(nm, gm, bt));
+                        for (int e = 0; e < 8; e += 2) {
+                            const uint32_t w = xw[e >> 1];
+                            f32x2 x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+                            const f32x2 g2{ga[i][e >> 2][e & 3], ga[i][e >> 2][(e & 3) + 1]}, b2{be[i][e >> 2][e & 3], be[i][e >> 2][(e & 3) + 1]};
+                            f32x2 t = __builtin_elementwise_fma(x2, rs2, nm2);
+                            t = __builtin_elementwise_fma(t, g2, b2);
+                            o[e] = (T)t[0]; o[e + 1] = (T)t[1];
                         }
                         *reinterpret_cast<bf16x8*>(xln + xoff<C>(row, ch)) = o;
                         if (xs) *reinterpret_cast<bf16x8*>(xs + ch * 8) = o;
@@ -714,6 +726,7 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                     __builtin_amdgcn_raw_buffer_store_b128(v, ao_rsrc, (int)(((grow0 + r) * C + hg * OC + ch * 8) * 2), 0, 16);
                 }
             }
+            if (tid == 0) tbl[W2_TBL_FLAG] = 0.0f;         // (a pad entry of the bias table: rewritten with the table per unit)
             vm_drain();
             __syncthreads();
             W2_STAMP(7);                                   // slice published
@@ -733,44 +746,58 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
                     }
                 }
             }
-            if (tid == 0) {
-                __hip_atomic_fetch_add(p.sync + W2_SYNC_ARRIVE(set), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // wait for the other groups of the set.  Bounded (p.spin_ticks of the 100 MHz clock, ~2 s by default): when it
-                // runs out the sticky error word (word 0 of the workspace, whatever the batch size) is set and this unit's rows
-                // of y are written as NaN, so a caller that never reads the word still sees a poisoned loss
-                const long long t0 = __builtin_amdgcn_s_memrealtime();
-                float bad = 0.0f;
-                while (__hip_atomic_load(p.sync + W2_SYNC_ARRIVE(set), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NHG) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > p.spin_ticks) {
-                        __hip_atomic_fetch_add(p.sync + W2_SYNC_ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        bad = 1.0f;
-                        break;
-                    }
-                }
-                tbl[W2_TBL_FLAG] = bad;                    // (a pad entry of the bias table: rewritten with the table per unit)
-            }
-            __syncthreads();
-            poison = tbl[W2_TBL_FLAG] != 0.0f;
-            W2_STAMP(8);                                   // all groups arrived
-            // ---- all heads of the set's rows: sc1 loads (L1 bypassed: another CU wrote them) -> LDS, A-operand layout
+            // ---- the exchange, ordered by ARRIVAL (round 6).  Every group raises its own flag once all its stores have
+            // completed (one lane, after the workgroup's vmcnt(0) + barrier above: cdna_hip_programming.md Guideline 16, flag
+            // form).  The waves of a reader split the NHG slices among themselves -- wave w takes slice slot w / NPART (slot 0 =
+            // the workgroup's own slice: no wait) and part w % NPART of its rows -- and each wave polls ITS group's flag and
+            // then loads that slice with sc1 loads (the wave that polled loads after its poll matched; another CU wrote the
+            // bytes: L1 bypassed) straight into the A-operand tile: the slices of groups that arrived early are in LDS while
+            // the wave of the last group is still waiting, there is no counter round trip (add -> poll) and one workgroup
+            // barrier less than the wait-for-all form (stage 2, B = 32: 6.4 -> ~4 us between "published" and "rows in LDS").
+            // Bounded (p.spin_ticks of the 100 MHz clock, ~2 s by default): when a wait runs out the sticky error word (word 0 of
+            // the workspace, whatever the batch size) is raised and this unit's rows of y are written as NaN, so a caller that
+            // never reads the word still sees a poisoned loss.
+            // (an ADD, polled as "> 0": a flag that was mis-armed negative never reads as raised -- how the tests provoke a time-out)
+            if (tid == 0) __hip_atomic_fetch_add(p.sync + W2_SYNC_FLAG(set, hg), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             {
-                constexpr int CH = C / 8, TOT = M * CH, PER = (TOT + NT - 1) / NT;
+                static_assert(NWV % NHG == 0 && NHG <= 7, "exchange: waves per slice");
+                constexpr int NPART = NWV / NHG;
+                constexpr int CHG = OC / 8;                                  // 16-byte chunks per row of one group's slice
+                constexpr int RP = (M + NPART - 1) / NPART, TOTP = RP * CHG, PER = (TOTP + 63) / 64;
+                const int slot = wave / NPART, part = wave - slot * NPART;
+                const int gid = (hg + slot) % NHG;
+                if (slot != 0) {
+                    int ok = 1;
+                    if (lane == 0) {
+                        const long long t0 = __builtin_amdgcn_s_memrealtime();
+                        while (__hip_atomic_load(p.sync + W2_SYNC_FLAG(set, gid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > p.spin_ticks) { ok = 0; break; }
+                        }
+                        if (!ok) tbl[W2_TBL_FLAG] = 1.0f;          // (several waves may write the same 1.0)
+                    }
+                    ok = __builtin_amdgcn_readfirstlane(ok);          // (also orders the wave's loads below behind lane 0's poll)
+                    asm volatile("" ::: "memory");
+                }
                 u32x4 v[PER];
+                const int r_lo = part * RP, r_hi = min(r_lo + RP, M);
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
-                    const int idx = min(tid + NT * i, TOT - 1);
-                    v[i] = __builtin_amdgcn_raw_buffer_load_b128(ao_rsrc, (int)((grow0 * C + (long)idx * 8) * 2), 0, 16);
+                    const int idx = min(lane + 64 * i, TOTP - 1), r = min(r_lo + idx / CHG, M - 1), ch = idx % CHG;
+                    v[i] = __builtin_amdgcn_raw_buffer_load_b128(ao_rsrc, (int)(((grow0 + r) * C + gid * OC + ch * 8) * 2), 0, 16);
                 }
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
-                    const int idx = tid + NT * i;
-                    if (idx < TOT) { const int r = idx / CH, ch = idx - r * CH; *reinterpret_cast<u32x4*>(xln + xoff<C>(r, ch)) = v[i]; }
+                    const int idx = lane + 64 * i, r = r_lo + idx / CHG, ch = idx % CHG;
+                    if (idx < TOTP && r < r_hi) *reinterpret_cast<u32x4*>(xln + xoff<C>(r, gid * CHG + ch)) = v[i];
                 }
                 // padded rows M..MR-1 of the tile keep the LayerNorm tile's zeros (the attention-output tile ends below them)
             }
             if constexpr (PLDS) vm_drain();                // (the projection weights were requested before these loads: landed)
             __syncthreads();
+            poison = tbl[W2_TBL_FLAG] != 0.0f;
+            if (poison && tid == 0)                        // ONE count per workgroup whose wait ran out
+                __hip_atomic_fetch_add(p.sync + W2_SYNC_ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             W2_STAMP(9);                                   // full rows in LDS
             // every reader counts itself out (the add is issued here, its result is looked at after the projection)
             if (tid == NT - 64) done_ticket = __hip_atomic_fetch_add(p.sync + W2_SYNC_DONE(set), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -844,7 +871,8 @@ __global__ __launch_bounds__(64 * NWV) void wmsa2_fwd_kernel(const Wmsa2Dev p) {
         if constexpr (NHG > 1) {
             // the last reader of the set re-arms its counters for the next launch
             if (tid == NT - 64 && done_ticket == NHG - 1) {
-                __hip_atomic_store(p.sync + W2_SYNC_ARRIVE(set), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int gq = 0; gq < NHG; ++gq) __hip_atomic_store(p.sync + W2_SYNC_FLAG(set, gq), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(p.sync + W2_SYNC_DONE(set), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -887,10 +915,10 @@ extern "C" int mvlt_swin_wmsa2_supported(int dtype, int B, int res, int C, int n
     return C == 384 || C == 192 || C == 96;
 }
 
-// sync_ws: int32 [16 + 2 * (B nW / 2)], zeroed ONCE by the caller when it is allocated (every launch leaves its counters
+// sync_ws: int32 [16 + 8 * (B nW / 2)], zeroed ONCE by the caller when it is allocated (every launch leaves its counters
 // zeroed).  Word 0 is the sticky error count: a bounded hand-off wait ran out (never expected; the unit's rows of y are NaN).
 // One workspace per stream: launches that may run concurrently must not share counters.
-extern "C" int mvlt_swin_wmsa2_sync_words(int B, int res) { return 16 + 2 * (B * (res / 7) * (res / 7) / 2); }
+extern "C" int mvlt_swin_wmsa2_sync_words(int B, int res) { return 16 + W2_SYNC_STRIDE * (B * (res / 7) * (res / 7) / 2); }
 
 // Bound of the hand-off wait (default 2000 ms; the tests shorten it to provoke the failure path).  Process-wide setting.
 static std::atomic<long long> g_w2_spin_ticks{200000000LL};

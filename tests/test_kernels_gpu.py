@@ -812,7 +812,7 @@ def test_swin_wmsa2_timeout_is_loud(ops):
     """A hand-off wait that runs out must not pass silently: the unit's rows of y are NaN, the sticky
     error count (word 0 of the workspace) is raised, ops.wmsa2_check raises both in its synchronous and in its one-call-late
     asynchronous form, and after wmsa2_clear_errors the next launch is clean again.  Provoked by mis-arming the arrival
-    counter of ONE window pair (so its four groups never see each other) with the wait shortened to 20 ms."""
+    flags of ONE window pair (so its four groups never see each other) with the wait shortened to 20 ms."""
     args, w2n = _wmsa2_case(ops, 8)
     x = args[0]
     y0, _ = ops.swin_wmsa2_fwd(*args)
@@ -821,7 +821,7 @@ def test_swin_wmsa2_timeout_is_loud(ops):
     bad_set = 5
     try:
         ops.wmsa2_set_timeout_ms(20)
-        ws[16 + 2 * bad_set] = -1000                      # arrivals of pair `bad_set` can never reach the group count
+        ws[16 + 8 * bad_set:16 + 8 * bad_set + 4] = -1000   # the four arrival flags of pair `bad_set` can never read as raised
         y, _ = ops.swin_wmsa2_fwd(*args)
         torch.cuda.synchronize()
         assert ops.wmsa2_sync_errors() == 4               # the four head groups of the pair

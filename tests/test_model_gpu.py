@@ -984,7 +984,7 @@ def test_training_step_reports_a_handoff_timeout(M, monkeypatch):
     try:
         ops.wmsa2_set_timeout_ms(20)
         for ws in wss:
-            ws[16 + 2 * 3] = -1000                       # pair 3 of the next launch on that stream never completes its arrival count
+            ws[16 + 8 * 3:16 + 8 * 3 + 4] = -1000        # the arrival flags of pair 3 of the next launch on that stream never read as raised
         loss = step(batch)
         torch.cuda.synchronize()
         assert loss.item() != loss.item(), loss.item()   # NaN reached the loss
