@@ -226,9 +226,13 @@ def other_configs(M):
                              "ms_per_batch": round(dt * 1e3, 2), "reports_per_s": round(32 / dt, 1),
                              "tokens_per_s": round(32 * ids.shape[1] / dt, 0),
                              "us_per_2token_step": round(dt / ids.shape[1] * 1e6, 1),
-                             "hbm_floor_us_per_step": 27.1,
-                             "note": "floor = 217 MB of bf16 weights streamed per step (SURVEY 8d) at the 8 TB/s HBM peak; the step is "
-                                     "a chain of ~100 dependent small kernels, i.e. latency bound"}
+                             # per 2-token step: 217 MB of bf16 weights + the valid K / V rows of the cache (12 layers x 2 x
+                             # B x (51 + t) rows x 768 x 2 B, t averaged over the 150 steps: ~149 MB) at the ~5.5 TB/s this chip streams
+                             # reads at (profiles/r5_hbm_write_probe.txt); the weights alone at the nominal 8 TB/s would be 27 us
+                             "hbm_floor_us_per_step": round((217e6 + 12 * 2 * 32 * (51 + (ids.shape[1] - 1) / 2.0) * 768 * 2) / 5.5e12 * 1e6, 1),
+                             "note": "floor = 217 MB of bf16 weights + ~149 MB of valid K/V cache rows per step at the measured ~5.5 TB/s read "
+                                     "rate (weights alone at the nominal 8 TB/s: 27 us); the step is a chain of ~100 dependent small "
+                                     "kernels, i.e. latency bound"}
     del cap
     # config #1: SLAKE Med-VQA forward, B = 2, T = 80 / 23 (the reference's CPU-runnable case, run_vqa.py): latency of one call
     vq = M.MVLBertForVQA(M.MVLBertConfigforVQA()).cuda().eval()

@@ -288,7 +288,7 @@ int mvlt_swin_wmsa_bwd_supported(int dtype, int C, int nH);
 
 /* Second design of the fused forward (csrc/wmsa2.hip, bf16): a workgroup owns TWO windows (98 rows share every weight
  * fragment) and a GROUP of heads; the head groups of a window pair run in different workgroups and meet through
- * attn_out (write-through stores, arrival counter, sc1 loads) before each computes its own output columns of the
+ * attn_out (write-through stores, one arrival flag per head group, sc1 loads) before each computes its own output columns of the
  * projection -- still ONE launch, and 256 workgroups at stage 2 of a B = 32 step where the first design has 128.
  * Same MvltSwinWmsa fields as mvlt_swin_wmsa_fwd (head_split ignored) with two differences: attn_out is REQUIRED (it is
  * the exchange buffer; eval callers pass scratch), and sync_ws is an int32 workspace of mvlt_swin_wmsa2_sync_words(B, res)

@@ -524,7 +524,7 @@ def test_decode_config4_full_size(M, monkeypatch, cd):
     """BASELINE config #4 at its real size (run_report_generation_cxr.py:315-333,385-386): Swin-S + BERT-base, B=32,
     max_length=150, greedy.  The replayed HIP graph (fused last-row head + argmax) must give the token ids of the
     eager per-token loop for all 150 steps, and the first steps must equal the CPU oracle's full-sequence recompute
-    (B=4 slice, 6 steps: the recompute is quadratic on the CPU).  bf16 = the benchmarked path."""
+    (B=8 slice, 16 steps: the recompute is quadratic on the CPU).  bf16 = the benchmarked path."""
     from oracle import mvlt_oracle as O
     cfg = M.MVLBertConfigForImageCaption()
     cfg.max_length = 150
@@ -542,27 +542,48 @@ def test_decode_config4_full_size(M, monkeypatch, cd):
         assert ids.shape == (32, 150)
         outs[graph] = ids.cpu()
     same = (outs["1"] == outs["0"])
+    NS, NT = 8, 16                                # samples x steps pinned to the CPU oracle (was 4 x 6)
+    ocfg = O.BertCfg(eos_token_id=-1)
     if cd == F32:
         assert bool(same.all())
     else:
-        # bf16: the graph path picks from f32 accumulators (mvlt_gemm_argmax), the eager loop from bf16-rounded
-        # logits; a near-tie may flip and the sequence then diverges -- the first tokens must agree for every sample
-        # (each path's picks are pinned to the f32 oracle below / in test_greedy_decode_matches_reference_token_ids)
-        assert bool(same[:, :4].all()) and same.float().mean().item() > 0.5
+        # bf16: the graph path picks from f32 accumulators (mvlt_gemm_argmax), the eager loop from bf16-rounded logits; a
+        # near-tie may flip one pick, after which that sample's two sequences are different (both valid) continuations.  So
+        # the two paths must be IDENTICAL UP TO EACH SAMPLE'S FIRST NEAR-TIE: where they first differ, both candidate tokens
+        # must be within the near-tie margin of the f32 oracle's top logit on the common prefix (checked below for the NS
+        # pinned samples; for all 32 samples the first tokens must agree).  Replaces the round-4 `same.mean() > 0.5`.
+        assert bool(same[:, :4].all())
     with torch.no_grad():
-        ref = O.greedy_decode_recompute(sd, O.SwinCfg(), O.BertCfg(eos_token_id=-1), image[:4], max_len=6)
-    got = outs["1"][:4, :6]
+        ref = O.greedy_decode_recompute(sd, O.SwinCfg(), ocfg, image[:NS], max_len=NT)
+    got = outs["1"][:NS, :NT]
     if cd == F32:
         assert torch.equal(got, ref), (got, ref)
     else:
-        # bf16: every one of the 24 picks is the f32 oracle's argmax on the generated prefix or a near-tie (teacher-forced)
+        # bf16: every one of the NS x NT picks is the f32 oracle's argmax on the generated prefix or a near-tie (teacher-forced)
         with torch.no_grad():
-            exact, near, bad = _teacher_forced_picks_ok(O, sd, O.SwinCfg(), O.BertCfg(eos_token_id=-1), image[:4], got)
+            exact, near, bad = _teacher_forced_picks_ok(O, sd, O.SwinCfg(), ocfg, image[:NS], got)
         assert not bad, (bad, got, ref)
         assert bool((got[:, 0] == ref[:, 0]).all()) and exact >= 4 * near, (exact, near, got, ref)
         with torch.no_grad():          # the eager per-token loop (bf16-rounded logits) is pinned the same way
-            exact, near, bad = _teacher_forced_picks_ok(O, sd, O.SwinCfg(), O.BertCfg(eos_token_id=-1), image[:4], outs["0"][:4, :6])
+            exact, near, bad = _teacher_forced_picks_ok(O, sd, O.SwinCfg(), ocfg, image[:NS], outs["0"][:NS, :NT])
         assert not bad and exact >= 4 * near, (bad, exact, near)
+        # graph vs eager: identical up to each sample's first divergence, and that divergence is a near-tie of the oracle
+        feat = O.conv_layer(image[:NS], sd, O.SwinCfg())
+        for b in range(NS):
+            diff = (outs["1"][b] != outs["0"][b]).nonzero()
+            if diff.numel() == 0:
+                continue
+            t = int(diff[0])
+            if t >= NT:
+                continue                          # (beyond the pinned horizon: covered by the per-path checks above up to NT)
+            with torch.no_grad():
+                inp = torch.cat([outs["1"][b:b + 1, :t], torch.full((1, 1), ocfg.mask_token_id)], 1)
+                o = O.mvlbert_forward(sd, ocfg, inp, feat[b:b + 1], True)
+                L = O.mlm_head(o["hidden"][:, -1], sd, "MLM_head_seq2seq", ocfg).double()[0]
+            spread = float(L.max() - L.mean())
+            for path in ("1", "0"):
+                m = float(L.max() - L[outs[path][b, t]])
+                assert m <= 0.02 * spread, (b, t, path, m, spread)
 
 
 def test_sample_mode_decoding(M, specs_hash):
@@ -966,7 +987,7 @@ def test_training_step_reports_a_handoff_timeout(M, monkeypatch):
     PretrainStep call raises ops.DeviceHandoffError (the error count travels to pinned host memory behind the step, no
     device sync); check_device_errors raises as well.  Provoked on the Swin-S model at B = 16 (stage 2 then has 64 windows: the head
     groups of its 32 window pairs meet inside mvlt_swin_wmsa2_fwd; stages 0 / 1 keep all heads in one workgroup) by mis-arming
-    one window pair's arrival counter with the wait shortened to 20 ms."""
+    one window pair's arrival flags with the wait shortened to 20 ms."""
     from mvlt_amd import ops
     from mvlt_amd.train import PretrainStep, synthetic_batch
     cfg = M.MVLBertPretrainConfig()
