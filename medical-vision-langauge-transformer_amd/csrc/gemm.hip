@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     using T = bf16_t;
     constexpr int BKE = 64, FM = BM / 32, FN = BN / 32;
     static_assert(!BKM || BN == 64 || BN == 128, "k-major B tiles: 64 or 128 columns");
-    static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+    static_assert(NST >= 2 && NST <= 5 && (NST - 2) * (BM / 32 + BN / 32) < 64, "two to five LDS stages (counted vmcnt: 6 bits)");
     // NST stages; beyond the 64 KB a static array may have (160 x 128 tiles: 72 KB) the launcher passes dynamic LDS
     constexpr bool DYN = NST * (BM + BN) * BKE * sizeof(T) > 65536;
     extern __shared__ __attribute__((aligned(16))) char glds_dyn[];
@@ -434,12 +434,16 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmDev p_in) {
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nkt > 0) fill(0, 0);
-    if (NST == 3 && nkt > 1) fill(1, 1);
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) if (st < nkt) fill(st, st);
+    constexpr int PER = BM / 32 + BN / 32;               // LDS-DMA requests per wave and K-tile
     for (int kt = 0; kt < nkt; ++kt) {
-        // this wave's share of tile kt has landed (three stages: the BM / 32 + BN / 32 requests of tile kt + 1 may still be in
-        // flight -- vmcnt completes in order, so a COUNTED wait leaves exactly those outstanding; a fourth stage measured nothing)
-        if (NST == 3 && kt + 1 < nkt) wait_vmcnt<BM / 32 + BN / 32>();
+        // this wave's share of tile kt has landed (NST stages: the requests of the next NST - 2 tiles may still be in flight --
+        // vmcnt completes in order, so a COUNTED wait leaves exactly those outstanding; fewer near the end of the reduction)
+        const int ahead = min(NST - 2, nkt - 1 - kt);
+        if (NST >= 5 && ahead >= 3) wait_vmcnt<(NST >= 5 ? 3 : 0) * PER>();
+        else if (NST >= 4 && ahead == 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * PER>();
+        else if (NST >= 3 && ahead == 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * PER>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // everybody's has; everybody is done reading tile kt-1
         if (kt + NST - 1 < nkt) fill((kt + NST - 1) % NST, kt + NST - 1);
@@ -965,25 +969,18 @@ Plan choose_plan(const MvltGemm* p) {
     static const bool t160 = [] { const char* e = getenv("MVLT_TILE160"); return !e || atoi(e) != 0; }();
     if (t160 && p->N % 128 == 0 && p->N >= 1536 && p->K <= 1024 && !p->b_kmajor && tile160_ok(p)) {
         const long t = (long)ceil_div(p->M, 160) * (p->N / 128);
-        if (t > 340 && t <= 512) { pl.bm = 160; pl.bn = 128; }
-    }
-    // ONE round of 96 x 128 tiles with THREE LDS stages for the narrow-output, long-reduction forward products (round 6): BertLayer
-    // FFN-out (3150..4192 x 768 x 3072) and the stage-2 Mlp.fc2 (6272 x 384 x 1536).  These launches sit on their L2 -> LDS ingest
-    // roof: bytes = 2 M N K (1 / BM + 1 / BN) at the ~70-80 GB/s a CU takes in (MI355X_MICROARCH.md "ldsdma-fill"); 64 x 64 tiles
-    // move 464 MB for FFN-out = 27 us of the 28 us measured.  198 tiles of 96 x 128 (55 FLOP per ingested byte instead of 32) move
-    // 271 MB, one tile per CU; the lone workgroup of a CU keeps two K-tiles in flight (86 KB of dynamic LDS).  Forward products
-    // only (the dgrads of these shapes run beside the weight-gradient workgroups, which leave no room for 86 KB).
-    static const bool t96 = [] { const char* e = getenv("MVLT_TILE96"); return !e || atoi(e) != 0; }();
-    if (t96 && !p->a_kmajor && !p->b_kmajor && p->N % 128 == 0 && p->N <= 768 && p->K >= 1536 && p->K % 64 == 0 && tile160_ok(p)) {
-        const long t = (long)ceil_div(p->M, 96) * (p->N / 128);
-        if (t > 150 && t <= 272) { pl.bm = 96; pl.bn = 128; }
+        // ragged batches (m_dev): M is the dense upper bound; the tiles beyond the packed row count leave at once, so the EFFECTIVE
+        // count is ~3/4 of t (BertLayer FFN-in: 648 launched, ~480 with work).  Round 6: accepted up to 680 launched tiles -- at
+        // worst (every caption at full length) that is a second, quarter-full round: 2 x 13.5 us against 33.6 us on 64 x 128 tiles.
+        static const bool ragged160 = [] { const char* e = getenv("MVLT_TILE160_RAGGED"); return !e || atoi(e) != 0; }();
+        const long tmax = (p->m_dev && ragged160) ? 680 : 512;
+        if (t > 340 && t <= tmax) { pl.bm = 160; pl.bn = 128; }
     }
     if (const char* ov = getenv("MVLT_TILE")) {          // experiments: MVLT_TILE=bm,bn
         int a = 0, b = 0;
         if (sscanf(ov, "%d,%d", &a, &b) == 2 && (a == 128 || a == 64) && (b == 128 || b == 96 || b == 64) &&
             !(a == 128 && b == 64)) { pl.bm = a; pl.bn = b; }
         if (a == 160 && b == 128 && tile160_ok(p)) { pl.bm = 160; pl.bn = 128; }
-        if (a == 96 && b == 128 && tile160_ok(p) && !p->b_kmajor && p->K % 64 == 0) { pl.bm = 96; pl.bn = 128; }
     }
     long tiles = (long)ceil_div(p->M, pl.bm) * ceil_div(p->N, pl.bn);
     int split = p->split_k;
@@ -991,7 +988,7 @@ Plan choose_plan(const MvltGemm* p) {
         split = 1;
         const int bke = (p->dtype == MVLT_BF16) ? 64 : 32;
         const int nkt = ceil_div(p->K, bke);
-        if (tiles < 200 && nkt >= 16 && pl.bm != 160 && pl.bm != 96) {          // small outputs with a long reduction only (wgrads)
+        if (tiles < 200 && nkt >= 16 && pl.bm != 160) {          // small outputs with a long reduction only (wgrads)
             split = (int)((768 + tiles - 1) / tiles);
             if (split > nkt / 8) split = nkt / 8;
             if (split > 96) split = 96;
@@ -1135,7 +1132,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
         // faster on 128x128 tiles and 18-24 % on 64x64; inside the training step the 128x128 form (64 KB of LDS, two
         // workgroups per CU) is SLOWER than the register-staged one (three per CU, shares the CU better with the
         // weight-gradient stream): 16.5 vs 16.1 ms per step.
-        const bool glds_on = pl.bm == 64 || pl.bm == 160 || pl.bm == 96;          // LDS-DMA loop for the 64-row tiles (comment above), the 160- and the 96-row ones
+        const bool glds_on = pl.bm == 64 || pl.bm == 160;          // LDS-DMA loop for the 64-row tiles (comment above) and the 160-row ones
         const int kspan = d.split_k > 1 ? d.k_per_split : p->K;
         const bool bkm_ok = !bk || ((pl.bn == 64 || pl.bn == 128) && p->N % 8 == 0 && p->N >= 8);
         if (glds_on && !ak && bkm_ok && p->K % 64 == 0 && kspan % 64 == 0 && d.a_vec && d.b_vec) {
@@ -1156,14 +1153,6 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
             const long tiles64 = (long)grid.x * grid.y;
             if (pl.bm == 160) {
                 if (bk) GLDS_GO_DYN(160, 128, true); else GLDS_GO_DYN(160, 128, false);
-            }
-            else if (pl.bm == 96) {          // 96 x 128, three stages (86 KB of dynamic LDS, one workgroup per CU), forward form only
-                if (bk || pl.bn != 128) return MVLT_ERR_UNSUPPORTED;
-                constexpr int sh96 = 3 * (96 + 128) * 64 * 2;
-                static const bool ok96 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<96, 128, false, true, 3>),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, sh96) == hipSuccess;
-                if (!ok96) return MVLT_ERR_LAUNCH;
-                hipLaunchKernelGGL((gemm_glds_kernel<96, 128, false, true, 3>), grid, dim3(256), sh96, s, d);
             }
             else if (st3 && pl.bm == 64 && pl.bn == 64 && d.wide && kspan >= 768 && (st3 == 2 || (!bk && tiles64 <= 400))) {
                 if (bk) hipLaunchKernelGGL((gemm_glds_kernel<64, 64, true, true, 3>), grid, dim3(256), 0, s, d);
@@ -1197,7 +1186,7 @@ static int gemm_dispatch(const MvltGemm* p, hipStream_t s) {
             }
         }
     }
-    if (pl.bm == 160 || pl.bm == 96) return MVLT_ERR_UNSUPPORTED;          // (tile160_ok and the conditions above disagree: never launch a mis-sized grid)
+    if (pl.bm == 160) return MVLT_ERR_UNSUPPORTED;          // (tile160_ok and the conditions above disagree: never launch a mis-sized grid)
     if (pl.bm == 128 && pl.bn == 128) launch_layout<T, 128, 128>(d, ak, bk, grid, s);
     else if (pl.bm == 128 && pl.bn == 96) launch_layout<T, 128, 96>(d, ak, bk, grid, s);
     else if (pl.bm == 64 && pl.bn == 128) launch_layout<T, 64, 128>(d, ak, bk, grid, s);

@@ -279,44 +279,6 @@ def test_gemm_tile160_forward_products(ops, M, N, K):
     assert torch.isnan(out2[-(-used // 160) * 160:].float()).all()
 
 
-@pytest.mark.parametrize("M,N,K", [(3150, 768, 3072), (4192, 768, 3072), (6272, 384, 1536)])
-def test_gemm_tile96_forward_products(ops, M, N, K):
-    """Narrow-output, long-reduction forward products (BertLayer FFN-out, stage-2 Mlp.fc2) take ONE round of 96 x 128 tiles with
-    three LDS stages (gemm_glds_kernel<96, 128, false, true, 3>, round 6): the plan says so, the dgrad form does not, and the
-    epilogues the model issues on these shapes -- bias + dropout + residual (BERT), bias + DropPath row scale + residual
-    (Swin), a device-side row count -- equal the fp32 torch statement."""
-    import ctypes as C
-    from mvlt_amd import _lib as L
-    dt = torch.bfloat16
-    A, W = rnd((M, K), dt, 51), rnd((N, K), dt, 52, K ** -0.5)
-    bias = rnd((N,), torch.float32, 53)
-    q = L.MvltGemm()
-    q.dtype, q.M, q.N, q.K, q.lda, q.ldb, q.ldc = L.BF16, M, N, K, K, K, N
-    q.A, q.B, q.C = A.data_ptr(), W.data_ptr(), A.data_ptr()
-    bm, bn, sp = C.c_int(), C.c_int(), C.c_int()
-    assert L.lib().mvlt_gemm_plan(C.byref(q), C.byref(bm), C.byref(bn), C.byref(sp)) == 0
-    assert (bm.value, bn.value, sp.value) == (96, 128, 1)
-    q.b_kmajor = 1
-    assert L.lib().mvlt_gemm_plan(C.byref(q), C.byref(bm), C.byref(bn), C.byref(sp)) == 0 and bm.value != 96
-    base = A.float() @ W.float().t() + bias
-    out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
-    ops.gemm(A, W, bias=bias, out=out)
-    assert torch.isfinite(out.float()).all() and rel(out, base) < tol(dt)
-    res = rnd((M, N), dt, 54)
-    out = ops.gemm(A, W, bias=bias, dropout=(0.1, 77, 6), residual=res)
-    keep = ops.dropout_mask(M * N, 0.1, 77, 6, A.device).view(M, N).float()
-    assert rel(out, res.float() + base * keep / 0.9) < tol(dt)
-    rps = 196
-    rs = torch.rand(M // rps + 1, device="cuda") + 0.5
-    out = ops.gemm(A, W, bias=bias, rowscale=(rs, rps), residual=res)
-    assert rel(out, res.float() + base * rs[torch.arange(M, device="cuda") // rps][:, None]) < tol(dt)
-    used = M - 500
-    out2 = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
-    ops.gemm(A, W, bias=bias, out=out2, m_dev=torch.tensor([used], dtype=torch.int32, device="cuda"))
-    assert rel(out2[:used], base[:used]) < tol(dt)
-    assert torch.isnan(out2[-(-used // 96) * 96:].float()).all()
-
-
 # (K, N, b_kmajor, epilogue): the nine products mvlt_gemm routes to the row-streaming kernel (csrc/rowstream.hip)
 _ROWSTREAM = [(96, 384, False, "gelu_pre"), (96, 384, False, "gelu"), (384, 96, False, "scale_res"), (384, 96, False, "res"),
               (192, 768, False, "gelu_pre"), (96, 384, True, "aux"), (384, 96, True, ""), (96, 96, True, ""), (288, 96, True, ""),
