@@ -166,6 +166,11 @@ def timed_run(step, batch, steps, use_dist, dist, blocks=5):
     times of the same run can be quoted: median / min / max of `blocks` blocks."""
     per = max(1, steps // blocks) if steps >= 2 * blocks else 0
     stamps = []
+    # (a deferred optimizer tail of the last warm-up step is applied BEFORE the region starts and the last timed step's tail
+    # INSIDE it: the region holds the complete work of exactly `steps` steps -- PretrainStep(defer_optimizer_tail=True))
+    flush = getattr(step, "flush", None)
+    if flush is not None:
+        flush()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -177,6 +182,8 @@ def timed_run(step, batch, steps, use_dist, dist, blocks=5):
         loss = step(batch)
         if per and (i + 1) % per == 0 and (i + 1) // per <= blocks:
             e = torch.cuda.Event(enable_timing=True); e.record(); stamps.append((i + 1, e))
+    if flush is not None:
+        flush()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -398,7 +405,11 @@ def main():
     comm = torch.bfloat16 if os.environ.get("MVLT_DDP_BF16") == "1" else torch.float32
     bucket_mb = int(os.environ.get("MVLT_DDP_BUCKET_MB", "64"))
     reducer = GradReducer(model, comm_dtype=comm, bucket_bytes=bucket_mb << 20) if use_dist else None
-    step = PretrainStep(model, reducer=reducer, world_size=world)
+    # MVLT_DEFER_OPT_TAIL=1 (A/B switch, off by default): the AdamW sweep over BertLayers 1.. and the heads runs beside the NEXT
+    # step's encoder forward (mvlt_amd/optim.py).  Measured 11.41 / 11.41 / 11.43 against 11.46 / 11.47 / 11.40 ms: inside the box's
+    # noise -- the encoder forward gives back what the sweep gains (profiles/HISTORY.md, round 6)
+    defer_tail = os.environ.get("MVLT_DEFER_OPT_TAIL", "0") == "1"
+    step = PretrainStep(model, reducer=reducer, world_size=world, defer_optimizer_tail=defer_tail)
     lens = None
     if world > 1:
         # caption lengths of the GLOBAL batch (same draw on every rank), dealt to the ranks with equal sums: with packed rows a

@@ -300,11 +300,16 @@ class Arena:
         """Call after writing parameter values by any route the arena cannot see."""
         self._scan_ok = False
 
-    def refresh_shadow(self) -> None:
+    def refresh_shadow(self, tail: bool = True) -> None:
         """bf16 compute copy <- f32 master (one pass, 6 B/param) whenever the master was modified through
         torch: in-place ops on ``flat`` itself bump ``flat._version``; writes through the Parameters
         (load_state_dict, a stock torch optimizer) are seen through the parameter version scan.  The fused
-        AdamW kernel refreshes the copy itself and leaves all versions untouched."""
+        AdamW kernel refreshes the copy itself and leaves all versions untouched.
+        ``tail``: a forward pass is about to read parameters; an optimizer tail that FusedAdamW deferred (optim.py) is
+        applied first, in stream order.  Only the two callers that handle the tail themselves pass False: the Swin forward
+        (its parameters are never deferred) and MVLBert._forward (which launches the tail beside the encoder)."""
+        if tail and self.__dict__.get("_opt_tail") is not None:
+            self._opt_tail.flush()
         self._in_backward = False        # a forward pass: any earlier backward pass is over (also an aborted one)
         if self.shadow is None:
             return

@@ -262,7 +262,14 @@ class MVLBert(nn.Module):
         cfg = self.config
         cd = feat.dtype
         ar = Arena.of(self, cd)
-        ar.refresh_shadow()
+        ar.refresh_shadow(tail=False)
+        # a deferred optimizer tail (optim.FusedAdamW(defer_tail=True): BertLayers 1.., pooler, heads) starts HERE, on the
+        # optimizer stream, behind the image tower and beside the encoder; a layer waits for its chunk right before it runs
+        tail = ar.__dict__.get("_opt_tail")
+        tail_at = None
+        if tail is not None:
+            tail.launch()
+            tail_at = [ar.offset[id(layer.attention.self.query.weight)] + 1 for layer in self.encoder.layer]
         B, n_img, H = feat.shape
         T = 0 if text_idx is None else text_idx.shape[1]
         Lq = n_img + 2 + T
@@ -289,6 +296,8 @@ class MVLBert(nn.Module):
             attn_desc = self._attn_desc(mode, B, Lq, nH, mask_ids, T, image_mask, n_img + 1, pack)
             sd = ops.s64(seed)
             for i, layer in enumerate(self.encoder.layer):
+                if tail_at is not None and ar.__dict__.get("_opt_tail") is not None:
+                    tail.wait_for(tail_at[i])
                 w, f, _ = self._layer_desc(ar, layer)
                 out = hx.bert_layer_fwd(x, w, f, H, cfg.intermediate_size, layer.output.LayerNorm.eps, attn_desc,
                                         p_h, p_a, sd, i, save, st)
@@ -296,6 +305,8 @@ class MVLBert(nn.Module):
                 if save:
                     layers.append(out[1:])
         for i, layer in enumerate(() if native else self.encoder.layer):
+            if tail_at is not None and ar.__dict__.get("_opt_tail") is not None:
+                tail.wait_for(tail_at[i])
             sa, so = layer.attention.self, layer.attention.output
             qkv = ops.gemm(x, ar.compute(sa.query.weight, 3 * H), bias=ar.master_span(sa.query.bias, 3 * H), m_dev=rd)
             ctx, lse = ops.attn_fwd(qkv, mode, B, Lq, nH, H // nH, (H // nH) ** -0.5,
@@ -316,6 +327,8 @@ class MVLBert(nn.Module):
             x = x2
         hidden = x.view(B, Lq, H) if pack is None else x
         pooled = cls = None
+        if tail is not None and ar.__dict__.get("_opt_tail") is not None:
+            tail.wait_for(None)              # pooler and heads: the last chunk
         if self.pooler is not None:          # tanh(Linear(h[:,0]))  (modeling_bert.py:451-463)
             cls = hidden[:, 0] if pack is None else x.index_select(0, pack[3])
             pooled = ops.tanh_fwd(ops.gemm(cls, ar.compute(self.pooler.dense.weight),

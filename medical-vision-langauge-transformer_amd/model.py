@@ -412,6 +412,20 @@ class MVLBertPretrainedModel(nn.Module):
         synchronises anyway (after loss.item(), before writing a checkpoint)."""
         ops.wmsa2_check(sync=True)
 
+    def _flush_optimizer_tail(self):
+        """A deferred optimizer tail (optim.FusedAdamW(defer_tail=True)) is applied before parameters are read or replaced."""
+        ar = self.__dict__.get("_mvlt_arena")
+        if ar is not None and ar.__dict__.get("_opt_tail") is not None:
+            ar._opt_tail.flush()
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_optimizer_tail()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._flush_optimizer_tail()
+        return super().load_state_dict(*args, **kwargs)
+
     def save_pretrained(self, path):
         if any(p.is_cuda for p in self.parameters()):
             self.check_device_errors()          # (the copy to the host below synchronises anyway) never persist poisoned weights

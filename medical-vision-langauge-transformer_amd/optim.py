@@ -23,9 +23,78 @@ from .arena import ALIGN, Arena
 from .runtime import compute_dtype_of
 
 
+class _OptTail:
+    """The part of one optimizer step that FusedAdamW(defer_tail=True) has NOT launched yet: the runs of the arena above
+    ``split`` (BertLayers 1.. and the heads), in chunks.  The next forward pass launches them on the optimizer stream
+    beside the encoder (``launch``: MVLBert._forward, behind the Swin tower) and waits for a chunk right before the first
+    layer that reads its parameters (``wait_for``); anything else that is about to read parameters applies what is left in
+    stream order (``flush``: Arena.refresh_shadow, the next step(), state_dict, PretrainStep.flush)."""
+
+    def __init__(self, opt, ar, chunks):
+        self.ar = ar
+        self.chunks = chunks            # [dict(lo=, runs=[(lo, hi, step)], event=None, waited=False)] in arena order
+        self.launched = False
+        # the hyper-parameters of the step this tail belongs to (an LR schedule may move opt.lr before the tail runs)
+        self.hyper = (opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, opt.grad_scale)
+
+    def _run(self, ch):
+        lr, b1, b2, eps, wd, gs = self.hyper
+        ar = self.ar
+        for lo, hi, st in ch["runs"]:
+            ops.adamw(ar.flat[lo:hi], ar.grad[lo:hi], ar.exp_avg[lo:hi], ar.exp_avg_sq[lo:hi],
+                      ar.shadow[lo:hi] if ar.shadow is not None else None, lr, b1, b2, eps, wd, st + 1, gs)
+
+    def launch(self):
+        """Queue every chunk on the optimizer stream behind what the current stream has queued so far."""
+        if self.launched:
+            return
+        self.launched = True
+        dev = self.ar.flat.device
+        st = ops.opt_stream(dev)
+        st.wait_stream(torch.cuda.current_stream())
+        with ops.on_stream(st, "opt"):
+            for ch in self.chunks:
+                self._run(ch)
+                ch["event"] = torch.cuda.Event()
+                ch["event"].record(st)
+
+    def wait_for(self, offset=None):
+        """The current stream waits for every chunk that holds parameters below ``offset`` (None: all of them)."""
+        done = True
+        for ch in self.chunks:
+            if ch["waited"]:
+                continue
+            if offset is None or ch["lo"] < offset:
+                torch.cuda.current_stream().wait_event(ch["event"])
+                ch["waited"] = True
+            else:
+                done = False
+        if done:
+            self.ar.__dict__["_opt_tail"] = None
+
+    def flush(self):
+        """Apply what has not been launched in stream order on the CURRENT stream; wait for what has."""
+        if not self.launched:
+            self.launched = True
+            for ch in self.chunks:
+                self._run(ch)
+                ch["waited"] = True
+            self.ar.__dict__["_opt_tail"] = None
+        else:
+            self.wait_for(None)
+
+
 class FusedAdamW:
-    def __init__(self, model, lr=4e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=1e-4, grad_scale=1.0):
+    def __init__(self, model, lr=4e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=1e-4, grad_scale=1.0, defer_tail=False):
         self.model = model
+        # defer_tail (opt-in, mvlt_amd.train.PretrainStep(defer_optimizer_tail=True)): step() updates the parameters the next
+        # forward pass reads FIRST (Swin tower, embeddings, BertLayer 0) and leaves the rest -- BertLayers 1.., pooler, heads:
+        # 102 M of the 182 M updated parameters, 3.1 GB of the sweep's 5.5 GB -- to the next forward pass, which runs them on the
+        # optimizer stream BESIDE the encoder: the sweep is HBM-bound (6 TB/s, no LDS, 57 registers), the BertLayer forward is
+        # bound by its GEMMs' L2 -> LDS traffic and moves < 1 TB/s of HBM bytes.  (Not beside the Swin tower: its fused W-MSA
+        # workgroups take a whole CU's registers and would queue behind the sweep's waves.)  Same arithmetic, same result:
+        # tests/test_model_gpu.py::test_deferred_optimizer_tail_equals_plain_steps.
+        self.defer_tail = bool(defer_tail)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.grad_scale = grad_scale           # 1/world_size under DDP (gradients are summed, not averaged)
         self._arena = None
@@ -67,6 +136,7 @@ class FusedAdamW:
     def state_dict(self):
         """Moments and per-parameter step counts keyed by parameter NAME (independent of the arena layout)."""
         ar = self._state()
+        self.flush()
         out = {"hyper": dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay),
                "state": {}}
         for name, p in zip(ar.names, ar.params):
@@ -79,6 +149,7 @@ class FusedAdamW:
 
     def load_state_dict(self, sd):
         ar = self._state()
+        self.flush()
         hp = sd.get("hyper", {})
         self.lr = hp.get("lr", self.lr)
         self.betas = tuple(hp.get("betas", self.betas))
@@ -192,9 +263,40 @@ class FusedAdamW:
         self._stepped.update(id(p) for p in params)
 
     # ------------------------------------------------------------------ the torch.optim-style entry point
+    def flush(self):
+        """Apply a deferred optimizer tail now (in stream order).  No-op otherwise."""
+        ar = self._arena
+        if ar is not None and ar.__dict__.get("_opt_tail") is not None:
+            ar._opt_tail.flush()
+
+    def _tail_bounds(self, ar: Arena):
+        """Arena offsets that cut the deferred tail into chunks: [BertLayer 1, BertLayer 4, BertLayer 8, behind the last
+        BertLayer]; None when the model has no such layers (nothing is deferred then)."""
+        key = id(ar)
+        cached = self.__dict__.get("_tail_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        first = {}
+        last_enc = 0
+        for name, p in zip(ar.names, ar.params):
+            k = name.find("encoder.layer.")
+            if k >= 0:
+                i = int(name[k + 14:].split(".")[0])
+                o = ar.offset[id(p)]
+                first[i] = min(first.get(i, o), o)
+                last_enc = max(last_enc, o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN)
+        bounds = None
+        if len(first) >= 2 and all(first[i] < first[i + 1] for i in range(len(first) - 1)):
+            n = len(first)
+            cuts = sorted({1, min(4, n - 1), min(8, n - 1)} - {0})
+            bounds = [first[c] for c in cuts] + [last_enc]
+        self._tail_cache = (key, bounds)
+        return bounds
+
     @torch.no_grad()
     def step(self):
         ar = self._state()
+        self.flush()                     # (a tail no forward pass has picked up: apply it before this step's update)
         if self._overlap is None:
             # the set of parameters with a gradient takes two values in pre-training (seq2seq / bidirectional head):
             # the contiguous runs are planned once per set, not rebuilt from 582 parameters every step
@@ -213,10 +315,27 @@ class FusedAdamW:
                 if key is not None:
                     self._plans[key] = plan
             b1, b2 = self.betas
+            bounds = self._tail_bounds(ar) if (self.defer_tail and ar.flat.is_cuda) else None
+            tail = []                    # (lo, hi, step) pieces above the split, in arena order
             for lo, hi, ids in plan:
-                ops.adamw(ar.flat[lo:hi], ar.grad[lo:hi], ar.exp_avg[lo:hi], ar.exp_avg_sq[lo:hi],
-                          ar.shadow[lo:hi] if ar.shadow is not None else None,
-                          self.lr, b1, b2, self.eps, self.weight_decay, steps[ids[0]] + 1, self.grad_scale)
+                st = steps[ids[0]]
+                if bounds is not None and hi > bounds[0]:
+                    cut = max(lo, bounds[0])
+                    tail.append((cut, hi, st))
+                    hi = cut
+                if hi > lo:
+                    ops.adamw(ar.flat[lo:hi], ar.grad[lo:hi], ar.exp_avg[lo:hi], ar.exp_avg_sq[lo:hi],
+                              ar.shadow[lo:hi] if ar.shadow is not None else None,
+                              self.lr, b1, b2, self.eps, self.weight_decay, st + 1, self.grad_scale)
+            if tail:
+                edges = bounds + [ar.total]
+                chunks = []
+                for c in range(len(edges) - 1):
+                    a, b = edges[c], edges[c + 1]
+                    runs = [(max(lo, a), min(hi, b), st) for lo, hi, st in tail if min(hi, b) > max(lo, a)]
+                    if runs:
+                        chunks.append(dict(lo=a, runs=runs, event=None, waited=False))
+                ar.__dict__["_opt_tail"] = _OptTail(self, ar, chunks)
         else:
             self._apply(ar, [p for p in ar.params if ar.has_grad[id(p)] and id(p) not in self._stepped])
             torch.cuda.current_stream().wait_stream(ops.opt_stream(ar.device))

@@ -236,7 +236,7 @@ class SwinTransformer(nn.Module):
     def _forward(self, img, fuse_gelu, save):
         cd = compute_dtype_of(self)
         ar = Arena.of(self, cd)
-        ar.refresh_shadow()
+        ar.refresh_shadow(tail=False)          # (Swin parameters are never part of a deferred optimizer tail)
         B = img.shape[0]
         pe = self.patch_embed
         P = pe.patch_size[0]

@@ -39,12 +39,15 @@ class PretrainStep:
     """loss = model(batch); loss.backward(); optimizer.step()  -- one call per step.
     ``reducer`` (mvlt_amd.ddp.GradReducer) makes it data parallel."""
 
-    def __init__(self, model, lr=None, reducer=None, world_size=1, overlap_optimizer=False):
+    def __init__(self, model, lr=None, reducer=None, world_size=1, overlap_optimizer=False, defer_optimizer_tail=False):
+        """defer_optimizer_tail (opt-in): the AdamW sweep over BertLayers 1.., pooler and heads is left to the NEXT call, which
+        runs it beside its encoder forward (optim.FusedAdamW(defer_tail=True)); between two calls those parameters are one
+        update behind until something reads them -- a forward pass, ``flush()``, state_dict() / save_pretrained() all apply it."""
         self.model = model
         # the reducer hands out rank-averaged gradients by default (like torch DDP); a SUM reducer is rescaled here
         gs = 1.0 if (reducer is None or getattr(reducer, "average", False)) else 1.0 / world_size
         self.opt = FusedAdamW(model, lr=lr if lr is not None else model.config.lr, betas=(0.9, 0.999), eps=1e-6,
-                              weight_decay=1e-4, grad_scale=gs)
+                              weight_decay=1e-4, grad_scale=gs, defer_tail=defer_optimizer_tail and not overlap_optimizer)
         self.reducer = reducer
         if overlap_optimizer:
             # opt-in: AdamW of finished arena slices is queued beside the rest of the backward pass.  On one
@@ -61,3 +64,7 @@ class PretrainStep:
         # the error counts travel to pinned host memory behind the step's kernels, no device sync (ops.wmsa2_check)
         ops.wmsa2_check(sync=False)
         return loss
+
+    def flush(self):
+        """Apply a deferred optimizer tail (end of training, before parameters are read through torch)."""
+        self.opt.flush()

@@ -981,6 +981,61 @@ def test_config2_batch32_loss_and_gradients_vs_oracle(M, golden, specs_hash, nam
     assert not bad, bad
 
 
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_deferred_optimizer_tail_equals_plain_steps(M, specs, monkeypatch, native):
+    """PretrainStep(defer_optimizer_tail=True) leaves the AdamW sweep over BertLayers 1.., pooler and heads to the next call, which
+    runs it on the optimizer stream beside its encoder forward (round 6).  Same arithmetic, same order of everything that reads or
+    writes a parameter: a state_dict() taken right after the first step already holds the deferred update, bit-identical to
+    the plain step's; after three steps (train mode, dropout, both coin flips) every parameter, both moments and the bf16 copy
+    agree to 1e-5 (two runs differ at rounding level through the float-atomic gradients, with or without the deferral)."""
+    from mvlt_amd.train import PretrainStep, synthetic_batch
+    from mvlt_amd.arena import Arena
+    from mvlt_amd.runtime import compute_dtype_of
+    monkeypatch.setattr(M.ops, "NATIVE", native == "1")
+    cfg = tiny_cfg(M)
+    cfg.num_hidden_layers = 4                      # BertLayers 1, 2, 3 + heads are deferred, in chunks
+    cfg.ITM_task = True
+    batches = [synthetic_batch(4, 24, "cuda", 300 + i, vocab=3000)[:4] for i in range(3)]
+    flips = [0.1, 0.9, 0.1]
+    out = {}
+    for mode in ("plain", "deferred"):
+        torch.manual_seed(5)
+        model = M.MVLBertForPretraining(cfg).cuda().train()
+        M.manual_seed(77)
+        step = PretrainStep(model, lr=1e-3, defer_optimizer_tail=(mode == "deferred"))
+        mid = None
+        for b, fl in zip(batches, flips):
+            monkeypatch.setattr(random, "random", lambda v=fl: v)
+            step(b)
+            if mid is None:
+                if mode == "deferred":
+                    ar = Arena.of(model, compute_dtype_of(model))
+                    assert ar.__dict__.get("_opt_tail") is not None, "nothing was deferred"
+                mid = {k: v.detach().clone() for k, v in model.state_dict().items()}      # (applies a pending tail)
+        step.flush()
+        torch.cuda.synchronize()
+        ar = Arena.of(model, compute_dtype_of(model))
+        assert ar.__dict__.get("_opt_tail") is None
+        out[mode] = (mid, {k: v.detach().clone() for k, v in model.state_dict().items()}, ar.exp_avg.clone(), ar.exp_avg_sq.clone(),
+                     ar.shadow.clone() if ar.shadow is not None else None)
+        del model, step
+    # After the FIRST step the deferred parameters (BertLayers 1.., pooler, heads: their gradients involve no float atomics) are
+    # bit-identical.  The relative-position-bias and word-embedding gradients are accumulated with float atomics (not
+    # bit-reproducible run to run, test_config2_step_is_bit_reproducible_*), so from the second step on two RUNS differ at
+    # rounding level whatever the optimizer does: everything is held at 1e-5 there (a missed or doubled update is 1e-3: lr).
+    deferred_keys = [k for k in out["plain"][0] if "encoder.layer." in k and ".layer.0." not in k or k.startswith(("MLM_head", "ITM_mlp", "MVLBert.pooler"))]
+    assert len(deferred_keys) > 40
+    for k in deferred_keys:
+        assert torch.equal(out["plain"][0][k], out["deferred"][0][k]), ("after the first step", k)
+    for k in out["plain"][1]:
+        a, b = out["plain"][1][k], out["deferred"][1][k]
+        if a.dtype.is_floating_point:
+            assert rel_err(b, a) < 1e-5, (k, rel_err(b, a))
+    assert rel_err(out["deferred"][2], out["plain"][2]) < 1e-5 and rel_err(out["deferred"][3], out["plain"][3]) < 1e-5
+    if out["plain"][4] is not None:
+        assert rel_err(out["deferred"][4], out["plain"][4]) < 1e-5          # the bf16 compute copy too
+
+
 def test_training_step_reports_a_handoff_timeout(M, monkeypatch):
     """VERDICT r4 weak #4, end to end: a hand-off wait of the fused Swin attention that runs out inside a TRAINING step must
     not pass silently -- the loss of that step is NaN (the unit's rows of the block output were poisoned) and the NEXT
