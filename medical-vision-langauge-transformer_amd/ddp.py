@@ -230,8 +230,40 @@ class GradReducer:
         """count: f32 [1] on this rank's device = labelled tokens of this rank's shard.  Returns N_global / world (f32 [1]):
         one 4-byte SUM all-reduce, enqueued on the current stream (no host sync)."""
         g = count.detach().clone()
+        err = None
+        if g.is_cuda:
+            # ADVICE r5: a hand-off time-out of the fused Swin attention (ops.DeviceHandoffError) poisons THIS rank's loss with NaN,
+            # the all-reduce then hands the NaN gradients to every rank -- but only the rank that timed out used to raise, and the
+            # others stalled at their next collective.  The sticky error count rides along with the label count (8 bytes instead
+            # of 4, same collective): every rank sees the global count and raises one step late (check_handoff, PretrainStep).
+            from . import ops
+            err = ops.wmsa2_error_tensor(g.device)
+        if err is not None:
+            g = torch.cat([g, err])
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+        if err is not None:
+            slot = self.__dict__.get("_err_slot")
+            if slot is None:
+                slot = self._err_slot = [torch.zeros(1, dtype=torch.float32).pin_memory(), None]
+            host, ev = slot
+            if ev is None or ev.query():          # (never rewrite the pinned word while a copy into it is in flight)
+                host.copy_(g[1:2], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                slot[1] = ev
+            g = g[:1]
         return g / float(self.world)
+
+    def check_handoff(self) -> None:
+        """Raise ops.DeviceHandoffError on EVERY rank when any rank's fused W-MSA hand-off timed out in an earlier step (the
+        globally summed count travelled with the label count; looked at without a device sync, so one step late).  The loss of
+        that step was NaN and the NaN gradients have been applied by then: the only recovery is the last checkpoint."""
+        slot = self.__dict__.get("_err_slot")
+        if slot is not None and slot[1] is not None and slot[1].query() and float(slot[0][0]) > 0:
+            from . import ops
+            n = int(slot[0][0])
+            slot[0].zero_()
+            ops._wmsa2_raise(n)
 
     # ---- hooks called by the engines (runtime.backward_begin / arena.watermark / backward_end)
     def _begin(self, arena: Arena) -> None:

@@ -791,6 +791,16 @@ def wmsa2_check(sync=True):
             slot[1] = ev
 
 
+def wmsa2_error_tensor(device):
+    """f32 [1] on `device`: the sum of the sticky error counts of its hand-off workspaces (no sync), or None if the fused W-MSA
+    kernel has not run there.  ddp.GradReducer sends it along with the label count so that EVERY rank learns of a time-out."""
+    dev = torch.device(device)
+    ws = [w for k, w in _WMSA2_SYNC.items() if k[0] == dev]
+    if not ws:
+        return None
+    return torch.stack([w[0] for w in ws]).sum().to(torch.float32).reshape(1)
+
+
 def wmsa2_clear_errors():
     """Zero the error counts and the counters (after a reported failure; the caller has synchronised)."""
     torch.cuda.synchronize()

@@ -63,6 +63,10 @@ class PretrainStep:
         # in-launch hand-offs (mvlt_swin_wmsa2_fwd) that timed out poison the loss with NaN AND raise here, one step late:
         # the error counts travel to pinned host memory behind the step's kernels, no device sync (ops.wmsa2_check)
         ops.wmsa2_check(sync=False)
+        if self.reducer is not None:
+            # data parallel: the error count of ALL ranks (it travelled with the label count): every rank raises, not only the one
+            # whose wait ran out.  By now the NaN gradients of that step have been applied -- reload the last checkpoint.
+            self.reducer.check_handoff()
         return loss
 
     def flush(self):

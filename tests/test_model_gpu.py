@@ -725,6 +725,34 @@ def test_ddp_buckets_carry_final_gradients(M, specs, monkeypatch):
     assert not bad, bad[:10]
 
 
+def test_handoff_error_count_reaches_every_rank(M, monkeypatch):
+    """under data parallelism a hand-off time-out on ONE rank must raise on ALL of them.  The sticky error count rides
+    along with the label-count all-reduce (GradReducer.label_sync) and GradReducer.check_handoff raises from the summed value,
+    one step late and without a device sync.  Emulated world of two: this process is the rank WITHOUT an error, the fake
+    all-reduce adds the other rank's count of 3."""
+    from mvlt_amd import ddp, ops
+    seen = []
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        seen.append(t.numel())
+        if t.numel() == 2:
+            t += torch.tensor([7.0, 3.0], device=t.device)          # the other rank: 7 labelled tokens, 3 time-outs
+        return None
+    monkeypatch.setattr(ddp.dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setattr(ddp.dist, "broadcast", lambda *a, **k: None)
+    monkeypatch.setattr(ddp.dist, "get_world_size", lambda *a, **k: 2)
+    model = M.MVLBertForPretraining(tiny_cfg(M)).cuda()
+    red = ddp.GradReducer(model, bucket_bytes=64 << 10)
+    ops.wmsa2_sync_ws(torch.device("cuda", torch.cuda.current_device()), 64)          # this rank's (clean) hand-off workspace
+    assert ops.wmsa2_sync_errors() == 0
+    denom = red.label_sync(torch.tensor([5.0], device="cuda"))
+    assert seen[-1] == 2 and float(denom) == 6.0                     # (5 + 7) / world: the label count is untouched by the rider
+    torch.cuda.synchronize()
+    with pytest.raises(ops.DeviceHandoffError):
+        red.check_handoff()
+    red.check_handoff()                                              # reported once
+
+
 def test_image_pair_input_gradients_are_summed_over_both_views(M, specs):
     """5-D input (IU-Xray pairs, model.py:240-253): the two views share the Swin weights, so the weight
     gradient is the sum of the two single-view gradients."""
