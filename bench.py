@@ -32,7 +32,7 @@ PER_GPU_BATCH, SEQ = 32, 80
 
 DOMINANT_NAME = ("forward + dgrad GEMM family of the Swin blocks / BertLayers: gemm_kernel<bf16,{128|64},{128|96|64},row,{row|kmajor}>, "
                  "gemm_glds_kernel<{64|128},{64|96|128}>, gemm8_kernel, rowstream_kernel (x W^T and dy W with fused epilogues; main "
-                 "stream) -- the family with the largest share of GPU time (~45 %, profiles/r5_bench_kernel_stats.csv)")
+                 "stream) -- the family with the largest share of GPU time (~45 %, profiles/r6_bench_kernel_stats.csv)")
 WGRAD_NAME = ("gemm_group_kernel<bf16,{128|64},{128|96},kmajor,kmajor> (grouped weight-gradient GEMMs dW_i = dY_i^T X_i "
               "+ bias gradients of one layer per launch; side stream, beside the dgrad chain)")
 DOMINANT = ("group", 1, 64, 128)   # gemm_group_kernel<bf16, BM=128|64, BN=128, A k-major, B k-major>: the grouped weight-
@@ -309,9 +309,9 @@ def one_rank_rccl(steps=40, warmup=10):
 
 def profiled_traffic(key):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (cannot be collected inside this
-    process): profiles/r5_dominant_kernel_traffic.json {"family": {...}, "wgrad_group": {...}}, filled in from the
+    process): profiles/r6_dominant_kernel_traffic.json {"family": {...}, "wgrad_group": {...}}, filled in from the
     scripts/pmc.py passes over scripts/profile_step.py (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)."""
-    name = "profiles/r5_dominant_kernel_traffic.json"
+    name = "profiles/r6_dominant_kernel_traffic.json"
     try:
         with open(os.path.join(ROOT, name)) as fh:
             d = json.load(fh)
