@@ -565,7 +565,9 @@ def test_decode_config4_full_size(M, monkeypatch, cd):
         with torch.no_grad():
             exact, near, bad = _teacher_forced_picks_ok(O, sd, O.SwinCfg(), ocfg, image[:NS], got)
         assert not bad, (bad, got, ref)
-        assert bool((got[:, 0] == ref[:, 0]).all()) and exact >= 4 * near, (exact, near, got, ref)
+        # (no separate first-token equality: at t = 0 the teacher-forced check IS the comparison with the oracle's first pick, and
+        # with 8 samples one of the 128 picks may be a near-tie there -- 125 exact / 3 near-ties measured in round 6)
+        assert exact >= 4 * near, (exact, near, got, ref)
         with torch.no_grad():          # the eager per-token loop (bf16-rounded logits) is pinned the same way
             exact, near, bad = _teacher_forced_picks_ok(O, sd, O.SwinCfg(), ocfg, image[:NS], outs["0"][:NS, :NT])
         assert not bad and exact >= 4 * near, (bad, exact, near)
