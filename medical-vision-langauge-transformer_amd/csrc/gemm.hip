@@ -517,6 +517,20 @@ constexpr int SKINNY_WAVES = 8, SKINNY_UNROLL = 3;
 // columns to (max, first index of the max) per row -> part_val/part_idx [M][gridDim.x]; argmax_parts_kernel
 // finishes the rows.  The maximum is taken over the f32 accumulators (+ bias).
 struct ArgmaxOut { float* part_val; int* part_idx; };
+// Weight fragments of the skinny products: every workgroup reads ITS 16 (or 128) weight rows exactly once, and in decoding the
+// 217 MB of weights + ~150 MB of K / V rows per step cycle through a 256 MB Infinity Cache -- non-temporal loads
+// (MI355X_MICROARCH.md "nt-weights": once-read streamed weights, 5-10 % per decode layer).  -DMVLT_SKINNY_NT=0 restores the
+// default cache policy (A/B builds).
+#ifndef MVLT_SKINNY_NT
+#define MVLT_SKINNY_NT 1
+#endif
+template <typename F> MVLT_DEV F skinny_wload(const F* q) {
+#if MVLT_SKINNY_NT
+    return __builtin_nontemporal_load(q);
+#else
+    return *q;
+#endif
+}
 template <typename T, bool ARGMAX = false>
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const GemmDev p_in, const ArgmaxOut am) {
     const GemmDev p = effective<false>(p_in);          // ragged row counts (m_dev): rows beyond it are neither read nor written
@@ -553,7 +567,7 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Ge
         for (int u = 0; u < SKINNY_UNROLL; ++u) {
             const int kb = kb0 + u * SKINNY_WAVES;
             const int k = (kb < nkb ? kb : kb0) * KB;          // past the end: reload a valid block, never multiplied
-            fb[u] = *reinterpret_cast<const Frag*>(brow + k);
+            fb[u] = skinny_wload(reinterpret_cast<const Frag*>(brow + k));
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[u][i] = *reinterpret_cast<const Frag*>(arow[i] + k);
         }
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_accum_kernel(co
         for (int u = 0; u < SKINNY_UNROLL; ++u) {
             const int kb = kb0 + u * SKINNY_WAVES;
             const int k = (kb < kb_hi ? kb : kb0) * KB;
-            fb[u] = *reinterpret_cast<const Frag*>(brow + k);
+            fb[u] = skinny_wload(reinterpret_cast<const Frag*>(brow + k));
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[u][i] = *reinterpret_cast<const Frag*>(arow[i] + k);
         }
@@ -713,7 +727,7 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_argmax128_kernel(const
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int k = min(kb0 + u, nkb - 1) * KB;          // past the end: reload the last block, never multiplied
-            fb[u] = *reinterpret_cast<const Frag*>(brow + k);
+            fb[u] = skinny_wload(reinterpret_cast<const Frag*>(brow + k));
 #pragma unroll
             for (int i = 0; i < NRT; ++i) fa[u][i] = *reinterpret_cast<const Frag*>(arow[i] + k);
         }
