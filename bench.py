@@ -290,7 +290,7 @@ def one_rank_rccl(steps=40, warmup=10):
             # bucket copied twice by 32 persistent workgroups at a few hundred GB/s on a third stream, the shape of a ring
             # all-reduce that is xGMI-bound for milliseconds (mvlt_amd/ddp.py: MVLT_DDP_DEFER_WAIT, MVLT_DDP_REHEARSE)
             ("ms_per_step_wait_deferred", {"MVLT_DDP_DEFER_WAIT": "1"}),
-            ("ms_per_step_ring_rehearsal_32wg", {"MVLT_DDP_REHEARSE": "32,2"}))
+            ("ms_per_step_ring_rehearsal_64wg", {"MVLT_DDP_REHEARSE": "64,4"}))
     for key, extra in arms:
         env = dict(os.environ, MVLT_FORCE_DDP="1", **extra)
         try:
@@ -303,7 +303,7 @@ def one_rank_rccl(steps=40, warmup=10):
             out["error"] = repr(e)[:200]
     out["workload"] = ("config #2 step with GradReducer over RCCL on one rank (MVLT_FORCE_DDP=1): 64 MiB buckets (8 MiB for the last 32 MB "
                        "of the arena) exchanged one bucket late on the main stream; second figure: reducer without the collective; third: "
-                       "collective issued, end-of-backward wait deferred; fourth: ring-collective rehearsal (2 x bucket bytes, 32 workgroups)")
+                       "collective issued, end-of-backward wait deferred; fourth: ring-collective rehearsal (2 x bucket bytes, 64 workgroups, ~400 GB/s)")
     return out
 
 
