@@ -824,6 +824,114 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* part_val,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-gradient tile with BOTH operands k-major through LDS-DMA (round 6): dW[m, n] = sum_k dY[k, m] X[k, n].
+// The register-staged form (gemm_body, DEEP = 2) keeps two register sets of the next tiles beside 64 accumulators: 243 VGPRs
+// at 128 x 128, i.e. two waves per SIMD and NOTHING else resident on a CU that holds two such workgroups
+// (profiles/r6_ln_bwd.md).  Here the tiles go global -> LDS by LDS-DMA in the k-major image the transposing fragment reads
+// expect ([64 k][R] with the 32-byte units XOR-swizzled by kswz<R>(k), the swizzle applied to the per-lane SOURCE address
+// exactly as gemm_glds_kernel<.., BKM> does for its B tile): no staging registers, no ds_write pass.
+//   * K tail / ragged reductions (m_dev): k-rows at or beyond the reduction length are fetched from a 256-byte page of
+//     zeros instead of the operand (a per-lane pointer select per request), for BOTH operands (0 x NaN of an unwritten
+//     tail row would poison the sum);
+//   * bias gradient db[m] = sum_k dY[k, m]: on the matrix pipe, dY^T . 1 (one extra MFMA per A fragment and k-block in the
+//     wn = 0 waves of the first column tile of every tile row; accumulator column 0 holds the sum) -- the staging registers
+//     the register form sums from do not exist here;
+//   * two LDS stages, one barrier per k-tile, counted by hand (the DMA is inline asm: gemm_dev.h).
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];          // zero-initialised device memory
+
+template <int BM, int BN>
+MVLT_DEV void wgrad_glds_tile(const GemmDev& p, const int bx, const int by, bf16_t* smem) {
+    using T = bf16_t;
+    constexpr int BKE = 64, FM = BM / 32, FN = BN / 32;
+    static_assert((BM == 64 || BM == 128) && (BN == 64 || BN == 128), "k-major LDS-DMA tiles: 64 or 128 wide");
+    const int m0 = by * BM, n0 = bx * BN;
+    const int ke = p.K;
+    const int nkt = (ke + BKE - 1) / BKE;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wm = wave >> 1, wn = wave & 1;
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+    constexpr int STAGE = (BM + BN) * BKE;            // elements per LDS stage: A image [64][BM], then B image [64][BN]
+    const T* srcA[BM / 32];
+    const T* srcB[BN / 32];
+    int krowA[BM / 32], krowB[BN / 32];
+#pragma unroll
+    for (int j = 0; j < BM / 32; ++j) {
+        constexpr int KPI = 512 / BM, XM = BM / 8 - 1;
+        const int krow = (wave * (BM / 32) + j) * KPI + lane / (BM / 8), x = lane & XM;
+        const int ch = (((x >> 1) ^ kswz<BM>(krow)) << 1) | (x & 1);
+        krowA[j] = krow;
+        srcA[j] = A + (long)krow * p.lda + min(m0 + ch * 8, max(p.M - 8, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j) {
+        constexpr int KPI = 512 / BN, XM = BN / 8 - 1;
+        const int krow = (wave * (BN / 32) + j) * KPI + lane / (BN / 8), x = lane & XM;
+        const int ch = (((x >> 1) ^ kswz<BN>(krow)) << 1) | (x & 1);
+        krowB[j] = krow;
+        srcB[j] = B + (long)krow * p.ldb + min(n0 + ch * 8, max(p.N - 8, 0));
+    }
+    const T* zero = reinterpret_cast<const T*>(g_zero_page) + (lane & 15) * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)smem;
+    auto fill = [&](int stage, int kt) {
+        const unsigned sa = lds0 + (unsigned)(stage * STAGE) * 2u, sb = sa + (unsigned)(BM * BKE) * 2u;
+        const int k0 = kt * BKE;
+#pragma unroll
+        for (int j = 0; j < BM / 32; ++j)
+            glds16_asm(k0 + krowA[j] < ke ? srcA[j] + (long)k0 * p.lda : zero, sa + (wave * (BM / 32) + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j)
+            glds16_asm(k0 + krowB[j] < ke ? srcB[j] + (long)k0 * p.ldb : zero, sb + (wave * (BN / 32) + j) * 1024);
+    };
+    f32x4 acc[FM][FN], cacc[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        cacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_colsum = p.a_colsum != nullptr && bx == 0 && wn == 0;          // (wave-uniform)
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    if (nkt > 0) fill(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile kt has landed
+        __syncthreads();                                       // everybody's has; everybody is done reading tile kt - 1
+        if (kt + 1 < nkt) fill((kt + 1) & 1, kt + 1);
+        const T* a = smem + (kt & 1) * STAGE;
+        const T* b = a + BM * BKE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            Mma<T>::Frag fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = tile_frag<T, BM, true>(a, wm * (BM / 2) + i * 16, kb);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = tile_frag<T, BN, true>(b, wn * (BN / 2) + j * 16, kb);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) Mma<T>::mma(cacc[i], ones, fa[i]);
+            }
+        }
+    }
+    if (do_colsum && lane < 16) {
+        // cacc[i][r] = sum_k A[k, m] for m = m0 + wm BM/2 + 16 i + lane (every r: the first operand's rows are all ones)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + lane;
+            if (m < p.M) p.a_colsum[m] = (p.epi & MVLT_EPI_ACCUM) ? p.a_colsum[m] + cacc[i][0] : cacc[i][0];
+        }
+    }
+    tile_epilogue<T, FM, FN>(p, m0 + wm * (BM / 2), n0 + wn * (BN / 2), acc);
+    __syncthreads();                                           // (persistent callers refill stage 0)
+}
+
 // Several independent products in one launch (the weight gradients of one layer): the tile lists of the
 // items are concatenated, a workgroup finds its item by a scan of the (<= 8) prefix counts.
 constexpr int GROUP_MAX = 8;
@@ -850,6 +958,25 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GemmGroupDev g
         if (gx > gy) { bx = tile / gy; by = tile - bx * gy; }
         else { by = tile / gx; bx = tile - by * gx; }
         gemm_body<T, BM, BN, AK, BK_, false, DEEP>(p, bx, by, bz, sA, sB);
+    }
+}
+
+// the same list walked by the LDS-DMA tile (bf16, both operands k-major, no k-slices): ~150 instead of 243 VGPRs at 128 x 128
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_group_glds_kernel(const GemmGroupDev gp) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * 64];
+    const int total = gp.start[gp.n];
+    for (int t0 = blockIdx.x; t0 < total; t0 += gridDim.x) {
+        const int t = xcd_remap(t0, total);
+        int i = 0;
+        while (i + 1 < gp.n && t >= gp.start[i + 1]) ++i;
+        const GemmDev p = effective<true>(gp.g[i]);
+        const int gx = (p.N + BN - 1) / BN, gy = (p.M + BM - 1) / BM;
+        const int tile = t - gp.start[i];
+        int by, bx;
+        if (gx > gy) { bx = tile / gy; by = tile - bx * gy; }
+        else { by = tile / gx; bx = tile - by * gx; }
+        wgrad_glds_tile<BM, BN>(p, bx, by, smem);
     }
 }
 
@@ -1333,6 +1460,26 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
     // bf16: two LDS stages + two register sets, one barrier per k-tile (the single-stage form measured 1.3 % slower in the step)
 #define GROUP_LAUNCH(BM_, BN_, D_) hipLaunchKernelGGL((gemm_group_kernel<T, BM_, BN_, true, true, D_>), dim3(total), dim3(256), 0, s, g)
     if constexpr (sizeof(T) == 2) {
+        // LDS-DMA form (round 6; MVLT_WGRAD_GLDS=0: the register-staged kernel): bf16, no k-slices, 128-wide column tiles, every
+        // operand row 16-byte aligned in 8-element chunks, f32 output through the vector epilogue
+        static const bool glds_wg = [] { const char* e = getenv("MVLT_WGRAD_GLDS"); return !e || atoi(e) != 0; }();
+        // 128 x 128 tiles only (BertLayer and stage-3 groups: 62.2 against 77.1 us and 36.3 against 43.9 us stand-alone).  At 64 x 128
+        // (stage 2: 216 tiles, one workgroup per CU) the two-stage LDS-DMA loop is SLOWER than the register-staged one with its two
+        // register sets + two LDS stages in flight (87.0 against 63.2 us): a lone workgroup needs the deeper pipeline.
+        // MVLT_WGRAD_GLDS=2 sends the 64 x 128 groups here too (experiments).
+        static const int glds_mode = [] { const char* e = getenv("MVLT_WGRAD_GLDS"); return e ? atoi(e) : 1; }();
+        bool ok = glds_wg && split == 1 && bn == 128 && (bm == 128 || glds_mode == 2);
+        for (int i = 0; i < n && ok; ++i) {
+            const GemmDev& d = g.g[i];
+            ok = d.a_vec && d.b_vec && d.epi_vec && (d.M % 8 == 0) && (d.N % 8 == 0) && d.M >= 8 && d.N >= 8 &&
+                 (d.epi & ~(MVLT_EPI_OUT_F32 | MVLT_EPI_ACCUM)) == 0 && (d.epi & MVLT_EPI_OUT_F32) && !d.atomic_out && d.split_k <= 1;
+        }
+        if (ok) {
+            if (bm == 128) hipLaunchKernelGGL((gemm_group_glds_kernel<128, 128>), dim3(total), dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((gemm_group_glds_kernel<64, 128>), dim3(total), dim3(256), 0, s, g);
+            MVLT_LAUNCH_CHECK();
+            return MVLT_OK;
+        }
         if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 2); else if (bn == 128) GROUP_LAUNCH(64, 128, 2); else GROUP_LAUNCH(64, 96, 2);
     } else {
         if (bn == 128 && bm == 128) GROUP_LAUNCH(128, 128, 0); else if (bn == 128) GROUP_LAUNCH(64, 128, 0); else GROUP_LAUNCH(64, 96, 0);
