@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* part_val,
 //   * two LDS stages, one barrier per k-tile, counted by hand (the DMA is inline asm: gemm_dev.h).
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];          // zero-initialised device memory
 
-template <int BM, int BN>
+template <int BM, int BN, int NST>
 MVLT_DEV void wgrad_glds_tile(const GemmDev& p, const int bx, const int by, bf16_t* smem) {
     using T = bf16_t;
     constexpr int BKE = 64, FM = BM / 32, FN = BN / 32;
@@ -896,12 +896,19 @@ MVLT_DEV void wgrad_glds_tile(const GemmDev& p, const int bx, const int by, bf16
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
-    if (nkt > 0) fill(0, 0);
+    static_assert(NST >= 2 && NST <= 4, "two to four LDS stages (four measured slower than three: not instantiated)");
+    constexpr int PER = BM / 32 + BN / 32;                     // LDS-DMA requests per wave and k-tile
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) if (st < nkt) fill(st, st);
     for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile kt has landed
+        // this wave's share of tile kt has landed (NST stages: the requests of the next NST - 2 tiles may still be in flight -- counted)
+        const int ahead = min(NST - 2, nkt - 1 - kt);
+        if (NST >= 4 && ahead >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * PER>();
+        else if (NST >= 3 && ahead == 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * PER>();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // everybody's has; everybody is done reading tile kt - 1
-        if (kt + 1 < nkt) fill((kt + 1) & 1, kt + 1);
-        const T* a = smem + (kt & 1) * STAGE;
+        if (kt + NST - 1 < nkt) fill((kt + NST - 1) % NST, kt + NST - 1);
+        const T* a = smem + (kt % NST) * STAGE;
         const T* b = a + BM * BKE;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -962,9 +969,12 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GemmGroupDev g
 }
 
 // the same list walked by the LDS-DMA tile (bf16, both operands k-major, no k-slices): ~150 instead of 243 VGPRs at 128 x 128
-template <int BM, int BN>
+template <int BM, int BN, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_group_glds_kernel(const GemmGroupDev gp) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * 64];
+    constexpr bool DYN = NST * (BM + BN) * 64 * 2 > 65536;
+    extern __shared__ __attribute__((aligned(16))) char wg_dyn[];
+    __shared__ __attribute__((aligned(16))) bf16_t wg_static[DYN ? 8 : NST * (BM + BN) * 64];
+    bf16_t* const smem = DYN ? reinterpret_cast<bf16_t*>(wg_dyn) : wg_static;
     const int total = gp.start[gp.n];
     for (int t0 = blockIdx.x; t0 < total; t0 += gridDim.x) {
         const int t = xcd_remap(t0, total);
@@ -976,7 +986,7 @@ __global__ __launch_bounds__(256, 2) void gemm_group_glds_kernel(const GemmGroup
         int by, bx;
         if (gx > gy) { bx = tile / gy; by = tile - bx * gy; }
         else { by = tile / gx; bx = tile - by * gx; }
-        wgrad_glds_tile<BM, BN>(p, bx, by, smem);
+        wgrad_glds_tile<BM, BN, NST>(p, bx, by, smem);
     }
 }
 
@@ -1463,20 +1473,30 @@ static int gemm_group_dispatch(const MvltGemm* items, int n, hipStream_t s) {
         // LDS-DMA form (round 6; MVLT_WGRAD_GLDS=0: the register-staged kernel): bf16, no k-slices, 128-wide column tiles, every
         // operand row 16-byte aligned in 8-element chunks, f32 output through the vector epilogue
         static const bool glds_wg = [] { const char* e = getenv("MVLT_WGRAD_GLDS"); return !e || atoi(e) != 0; }();
-        // 128 x 128 tiles only (BertLayer and stage-3 groups: 62.2 against 77.1 us and 36.3 against 43.9 us stand-alone).  At 64 x 128
-        // (stage 2: 216 tiles, one workgroup per CU) the two-stage LDS-DMA loop is SLOWER than the register-staged one with its two
-        // register sets + two LDS stages in flight (87.0 against 63.2 us): a lone workgroup needs the deeper pipeline.
-        // MVLT_WGRAD_GLDS=2 sends the 64 x 128 groups here too (experiments).
-        static const int glds_mode = [] { const char* e = getenv("MVLT_WGRAD_GLDS"); return e ? atoi(e) : 1; }();
-        bool ok = glds_wg && split == 1 && bn == 128 && (bm == 128 || glds_mode == 2);
+        // 128 x 128 tiles (BertLayer and stage-3 groups, two stages, two workgroups per CU): 62.2 against 77.1 us and 36.3 against 43.9 us
+        // stand-alone.  64 x 128 tiles (stage 2: 216 tiles, ONE workgroup per CU): a lone workgroup needs the deeper pipeline -- two
+        // stages 88 us, three stages (72 KB of dynamic LDS, two k-tiles in flight) 75 us, four 89 us, against 62 us for the
+        // register-staged form stand-alone; INSIDE the step the order turns round, because the dgrad chain's kernels run beside
+        // 128-register waves instead of 162-register ones: 11.45 / 11.45 / 11.36 ms per step with three stages against 11.55 / 11.50 /
+        // 11.57 with the register-staged kernels (two stages 11.53 / 11.51 / 11.51; profiles/r6_wgrad_glds.md).
+        // MVLT_WGRAD_GLDS: 0 = register-staged kernels, 1 = 128 x 128 groups only, 2 = 64 x 128 with two stages, 3 (default) = three.
+        static const int glds_mode = [] { const char* e = getenv("MVLT_WGRAD_GLDS"); return e ? atoi(e) : 3; }();
+        bool ok = glds_wg && split == 1 && bn == 128 && (bm == 128 || glds_mode >= 2);
         for (int i = 0; i < n && ok; ++i) {
             const GemmDev& d = g.g[i];
             ok = d.a_vec && d.b_vec && d.epi_vec && (d.M % 8 == 0) && (d.N % 8 == 0) && d.M >= 8 && d.N >= 8 &&
                  (d.epi & ~(MVLT_EPI_OUT_F32 | MVLT_EPI_ACCUM)) == 0 && (d.epi & MVLT_EPI_OUT_F32) && !d.atomic_out && d.split_k <= 1;
         }
         if (ok) {
-            if (bm == 128) hipLaunchKernelGGL((gemm_group_glds_kernel<128, 128>), dim3(total), dim3(256), 0, s, g);
-            else hipLaunchKernelGGL((gemm_group_glds_kernel<64, 128>), dim3(total), dim3(256), 0, s, g);
+            if (bm == 128) hipLaunchKernelGGL((gemm_group_glds_kernel<128, 128, 2>), dim3(total), dim3(256), 0, s, g);
+            else if (glds_mode == 3) {          // 64 x 128 with three stages (72 KB of dynamic LDS: two k-tiles in flight for a lone workgroup)
+                constexpr int sh3 = 3 * (64 + 128) * 64 * 2;
+                static const bool ok3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_glds_kernel<64, 128, 3>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, sh3) == hipSuccess;
+                if (!ok3) return MVLT_ERR_LAUNCH;
+                hipLaunchKernelGGL((gemm_group_glds_kernel<64, 128, 3>), dim3(total), dim3(256), sh3, s, g);
+            }
+            else hipLaunchKernelGGL((gemm_group_glds_kernel<64, 128, 2>), dim3(total), dim3(256), 0, s, g);
             MVLT_LAUNCH_CHECK();
             return MVLT_OK;
         }
