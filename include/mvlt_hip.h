@@ -36,7 +36,7 @@ enum { MVLT_OK = 0, MVLT_ERR_ARG = -1, MVLT_ERR_LAUNCH = -2, MVLT_ERR_UNSUPPORTE
  * signature; a binding compiles / hard-codes the value it was written against and compares it with what the
  * loaded library returns.  mvlt_sizeof(MVLT_STRUCT_*) lets a binding that mirrors the structs by hand (ctypes,
  * cgo, JNI) prove that its mirror has the size the library was compiled with (0 for an unknown id). */
-#define MVLT_ABI_VERSION 7
+#define MVLT_ABI_VERSION 8
 int mvlt_version(void);            /* MVLT_ABI_VERSION of the loaded library */
 const char* mvlt_arch(void);       /* "gfx950" */
 enum { MVLT_STRUCT_GEMM = 0, MVLT_STRUCT_LAYERNORM = 1, MVLT_STRUCT_LAYERNORM_BWD = 2, MVLT_STRUCT_LN_REDUCE_ITEM = 3,
@@ -234,6 +234,16 @@ typedef struct MvltAttn {
      * (they are masked keys in BIDIR mode and lie above the causal diagonal in SEQ2SEQ mode, so no kept
      * row ever reads them).  lse / delta_ws keep the [nseq,nH,L] layout.  NULL = dense [nseq*L] rows. */
     const int32_t* row_start; const int32_t* seq_len;
+    /* backward only, MVLT_ATTN_SWIN only (optional): the output projection's dgrad inside the launch.  When non-NULL, `dout`
+     * is the gradient of the PROJECTION's output ([nseq*L, nH*hd], window order) and dout_weight the projection weight
+     * [nH*hd (out), nH*hd (in)] row-major in the compute dtype (WindowAttention.proj, visual_feature_extractor.py:252):
+     * the kernel forms dO_h = dout . W[:, hd*h .. hd*h + hd - 1] per head itself (rounded to the compute dtype, as the
+     * separate product would).  bf16, hd 32, nH 3 / 6 / 12, no attention dropout, shift 0 or 3; anything else:
+     * MVLT_ERR_UNSUPPORTED. */
+    const void* dout_weight;
+    /* backward only (optional; honoured by the bf16 Swin launch, ignored elsewhere): a byte range a LATER kernel will stream,
+     * same contract as MvltGemm.prefetch (one dword of every 128-byte line is read and dropped) */
+    const void* prefetch; int64_t prefetch_bytes;
 } MvltAttn;
 int mvlt_attn_fwd(const MvltAttn* p, void* stream);
 int mvlt_attn_bwd(const MvltAttn* p, void* stream);   /* delta_ws: f32 [nseq,nH,L] */

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmvlt_hip.so")
 
 F32, BF16 = 0, 1
 OK = 0
-ABI_VERSION = 7          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
+ABI_VERSION = 8          # == MVLT_ABI_VERSION of the include/mvlt_hip.h these mirrors were written against
 ERRORS = {-1: "MVLT_ERR_ARG", -2: "MVLT_ERR_LAUNCH", -3: "MVLT_ERR_UNSUPPORTED"}
 
 EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_DROPOUT = 1, 2, 4, 8
@@ -66,7 +66,7 @@ class MvltAttn(C.Structure):
                 ("text_ids", vp), ("T", i32), ("image_mask", vp), ("obj_end", i32),
                 ("dropout_p", f32), ("seed", u64), ("tag", u32),
                 ("dout", vp), ("dqkv", vp), ("dbias_table", vp), ("delta_ws", vp),
-                ("row_start", vp), ("seq_len", vp)]
+                ("row_start", vp), ("seq_len", vp), ("dout_weight", vp), ("prefetch", vp), ("prefetch_bytes", i64)]
 
 
 class MvltSwinWmsa(C.Structure):

@@ -34,6 +34,8 @@ struct AttnDev {
     const int64_t* text_ids; int T; const uint8_t* image_mask; int obj_end;
     uint32_t drop_thresh; float drop_scale; uint64_t seed; uint32_t tag;
     const void* dout; void* dqkv; float* dbias; float* delta_ws;
+    const void* dw;                             // Swin backward: output-projection weight when the kernel applies its transpose itself, or null
+    const char* pf; long pf_lines;              // Swin backward (scores-once kernel): byte range a LATER kernel streams (MvltAttn.prefetch)
     const int* row_start; const int* seq_len;   // packed rows (MVLBert modes), or null
     int ld;          // LDS row stride (elements)
     int rows_alloc;  // LDS rows per image
@@ -591,14 +593,24 @@ constexpr int SW2_LDP = 72;                                  // row stride of th
 constexpr int SW2_IMG = 64 * SW2_LD * 2, SW2_PIMG = 64 * SW2_LDP * 2;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr size_t SW2_SMEM = 3 * SW2_IMG + 2 * SW2_PIMG + 4 * 256 * sizeof(f32x4) + 64 * 4;
+// KS > 0 (round 6): the output projection's dgrad inside this launch.  `dout` is then the gradient of the projection's OUTPUT
+// (window order, [nseq * 49, C], C = 32 KS) and `dw` the projection weight [C_out][C_in]: a workgroup keeps the 32 input columns
+// of its head as a [32][C + 8] LDS image (read once: the head is fixed for the workgroup's whole walk), and every wave forms ITS
+// 16 rows of dO_h = dY W[:, 32 h .. 32 h + 31] at the top of a window -- 2 KS MFMAs whose row operand comes straight from global
+// memory into registers one window ahead (KS b128 loads per lane) -- and writes them, rounded to bf16 as the stand-alone
+// product would, where the staged dO rows went.  One launch and one [rows, C] round trip less per Swin block.
+// The weight image is k-major, [C][SW2_LD] like the Q / K images (16-byte writes, transposing fragment reads); the rows of every
+// 32-row block are permuted so that frag_tok's k-slot order (tokens 4 g + e and 16 + 4 g + e) meets the natural order of the row
+// operand's 16-byte chunk (k = 8 g + e).
+constexpr size_t sw2_smem(int ks) { return SW2_SMEM + (size_t)ks * 32 * SW2_LD * 2; }
 
 #ifdef SW2_TRACE
 #define SW2_T(i) do { if (p.delta_ws && threadIdx.x == 0) reinterpret_cast<long long*>(p.delta_ws)[((long)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define SW2_T(i) do { } while (0)
 #endif
-template <bool SHIFT>
-__global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p) {
+template <bool SHIFT, int KS>
+__global__ __launch_bounds__(256, KS ? 2 : 3) void swin_attn_bwd2_kernel(const AttnDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using T = bf16_t;
     using M = Mma<T>;
@@ -612,6 +624,7 @@ __global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p)
     T* si = reinterpret_cast<T*>(smem_raw + 3 * SW2_IMG + SW2_PIMG);
     f32x4* lbA = reinterpret_cast<f32x4*>(smem_raw + 3 * SW2_IMG + 2 * SW2_PIMG);        // [4 key tiles][256 threads]
     float* lse_s = reinterpret_cast<float*>(lbA + 4 * 256);
+    T* wt = reinterpret_cast<T*>(smem_raw + SW2_SMEM);                                   // KS: [32 KS][SW2_LD]
     const T* qkv_g = reinterpret_cast<const T*>(p.qkv);
     const T* dout = reinterpret_cast<const T*>(p.dout);
     T* dqkv = reinterpret_cast<T*>(p.dqkv);
@@ -631,6 +644,7 @@ __global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p)
     // the loop top, and the stores further down are buffer stores whose out-of-range lanes are dropped by the hardware.
     const int srow = min((int)threadIdx.x >> 2, 48), sch = (threadIdx.x & 3) * 8;
     bf16x8 gq, gk, gd;            // this thread's 16-byte chunk of the Q / K / dO rows
+    bf16x8 fy[KS ? KS : 1];       // KS: this lane's row of dY (16 wave + c15, clamped), k-slots 32 k + 8 g .. + 7
     bf16x8 fv[4];                 // V fragments: rows = keys 16t + c15, k-slots = d 8g..8g+7 (clamped row: P is 0 beyond key 48)
     float lse_pre = 0.f;
     auto issue = [&](int sq) {
@@ -638,7 +652,12 @@ __global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p)
         const T* src = qkv_g + (r0 + srow) * 3 * C + h * 32 + sch;
         gq = *reinterpret_cast<const bf16x8*>(src);
         gk = *reinterpret_cast<const bf16x8*>(src + C);
-        gd = *reinterpret_cast<const bf16x8*>(dout + (r0 + srow) * C + h * 32 + sch);
+        if constexpr (KS == 0) gd = *reinterpret_cast<const bf16x8*>(dout + (r0 + srow) * C + h * 32 + sch);
+        else {
+            const T* yr = dout + (r0 + min(16 * wave + c15, 48)) * C + g * 8;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) fy[k] = *reinterpret_cast<const bf16x8*>(yr + 32 * k);
+        }
         lse_pre = p.lse[((long)sq * p.nH + h) * p.L + min((int)threadIdx.x, 48)];
     };
     auto issue_v = [&](int sq) {
@@ -647,6 +666,17 @@ __global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p)
         for (int t = 0; t < 4; ++t) fv[t] = *reinterpret_cast<const bf16x8*>(base + (long)min(16 * t + c15, 48) * 3 * C);
     };
     { const int first = min((int)blockIdx.x, p.nseq - 1); issue(first); issue_v(first); }
+    // KS: W[o][32 h .. 32 h + 31] requested now, written to LDS behind the bias set-up below (its gathers are in flight meanwhile)
+    constexpr int WCH = KS ? (KS * 128 + 255) / 256 : 1;
+    bf16x8 wv[WCH];
+    if constexpr (KS > 0) {
+        const T* wg = reinterpret_cast<const T*>(p.dw) + h * 32;
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int idx = min((int)threadIdx.x + 256 * i, KS * 128 - 1);
+            wv[i] = *reinterpret_cast<const bf16x8*>(wg + (long)(idx >> 2) * C + (idx & 3) * 8);
+        }
+    }
     const __amdgpu_buffer_rsrc_t dq_rsrc = __builtin_amdgcn_make_buffer_rsrc(dqkv, 0, (int)((long)p.nseq * 49 * 3 * C * 2), 0x00020000);
     auto store_rows = [&](int tok, bool valid, int col, const f32x4& v) {     // 4 bf16 at dqkv[tok][col..col+3]
         bf16x4 r; r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
@@ -677,6 +707,16 @@ __global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p)
         }
     }
     SW2_T(2);
+    if constexpr (KS > 0) {
+        // (once; the barrier at the top of the first window orders the writes before the reads)
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int idx = (int)threadIdx.x + 256 * i;
+            const int o = idx >> 2, e = o & 7;
+            const int r = (o & ~31) + 4 * ((o >> 3) & 3) + (e & 3) + (e >= 4 ? 16 : 0);
+            if (idx < KS * 128) *reinterpret_cast<bf16x8*>(wt + r * SW2_LD + (idx & 3) * 8) = wv[i];
+        }
+    }
     uint32_t rowA = 0, colA = 0;
     if (SHIFT) { const uint32_t b = SWIN_PAIRS.bits3[threadIdx.x]; rowA = b & 0xffffu; colA = b >> 16; }      // shift == 3 (host check)
     f32x4 dbacc[4];
@@ -697,7 +737,24 @@ __global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p)
             const bf16x8 z = zero_vec<T>();
             *reinterpret_cast<bf16x8*>(qi + row * SW2_LD + sch) = ok ? gq : z;
             *reinterpret_cast<bf16x8*>(ki + row * SW2_LD + sch) = ok ? gk : z;
-            *reinterpret_cast<bf16x8*>(di + row * SW2_LD + sch) = ok ? gd : z;
+            if constexpr (KS == 0) *reinterpret_cast<bf16x8*>(di + row * SW2_LD + sch) = ok ? gd : z;
+        }
+        if constexpr (KS > 0) {
+            // acc[jt][r] <-> (j = 16 jt + 4 g + r, q = c15): dO_h[q][j] = sum_o dY[q][o] W[o][32 h + j]
+            f32x4 o2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) M::mma(o2[jt], frag_tok(wt, SW2_LD, 16 * jt, k), fy[k]);
+            }
+            const int row = 16 * wave + c15;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                bf16x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = row < 49 ? (bf16_t)o2[jt][e] : (bf16_t)0.f;
+                *reinterpret_cast<bf16x4*>(di + row * SW2_LD + 16 * jt + 4 * g) = r;
+            }
         }
         if (threadIdx.x < 64) lse_s[threadIdx.x] = threadIdx.x < 49 ? lse_pre * LOG2E : 0.f;
         __syncthreads();
@@ -787,6 +844,13 @@ __global__ __launch_bounds__(256, 3) void swin_attn_bwd2_kernel(const AttnDev p)
         if (seq == (int)blockIdx.x) SW2_T(8);
     }
     SW2_T(9);
+    if (p.pf) {          // MvltAttn.prefetch: one dword of every 128-byte line, dropped
+        const long nthr = (long)gridDim.x * gridDim.y * 256;
+        unsigned acc = 0;
+        for (long l = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; l < p.pf_lines; l += nthr)
+            acc ^= *reinterpret_cast<const unsigned*>(p.pf + (l << 7));
+        asm volatile("" :: "v"(acc));
+    }
     if (p.dbias) {
         // dBias[rel(q, k)] = sum of dS[q, k] over the windows of this workgroup: the per-lane sums go to LDS as a [q][k]
         // matrix (over the P / dS images), then one thread per table entry adds up its diagonal (LDS float atomics run at
@@ -1283,10 +1347,24 @@ static int launch_swin_bwd2(const AttnDev& d, hipStream_t s) {
     const int cap = per_cu * cu_count() / d.nH;
     if (gx > cap) gx = cap < 1 ? 1 : cap;
     dim3 grid(gx, d.nH);
-    auto k0 = swin_attn_bwd2_kernel<false>;
-    auto k1 = swin_attn_bwd2_kernel<true>;
-    if (d.shift != 0) ATTN_LAUNCH_LAST(k1, grid, dim3(256), SW2_SMEM, s, d);
-    else ATTN_LAUNCH_LAST(k0, grid, dim3(256), SW2_SMEM, s, d);
+#define SW2_GO(KS_) do {                                                                                                      \
+        auto k0 = swin_attn_bwd2_kernel<false, KS_>;                                                                          \
+        auto k1 = swin_attn_bwd2_kernel<true, KS_>;                                                                           \
+        constexpr size_t sh = sw2_smem(KS_);                                                                                  \
+        if (sh > 64 * 1024) {                                                                                                 \
+            static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) == hipSuccess && \
+                                   hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) == hipSuccess; \
+            if (!ok) return MVLT_ERR_LAUNCH;                                                                                  \
+        }                                                                                                                     \
+        if (d.shift != 0) ATTN_LAUNCH_LAST(k1, grid, dim3(256), sh, s, d);                                                    \
+        else ATTN_LAUNCH_LAST(k0, grid, dim3(256), sh, s, d);                                                                 \
+    } while (0)
+    if (!d.dw) SW2_GO(0);
+    else if (d.nH == 3) SW2_GO(3);
+    else if (d.nH == 6) SW2_GO(6);
+    else if (d.nH == 12) SW2_GO(12);
+    else return MVLT_ERR_UNSUPPORTED;
+#undef SW2_GO
     MVLT_LAUNCH_CHECK();
     return MVLT_OK;
 }
@@ -1301,6 +1379,7 @@ int dispatch(AttnDev d, bool bwd, int dtype, hipStream_t s) {
         if (d.hd != 32 || d.L != 49) return MVLT_ERR_UNSUPPORTED;
         if (bwd && sizeof(T) == 2 && d.drop_thresh == 0 && swin_bwd_form() && (d.shift == 0 || d.shift == 3) &&
             (double)d.nseq * 49 * 3 * d.nH * 32 * 2 < 2147483648.0) return launch_swin_bwd2(d, s);     // buffer-store range check: < 2 GB
+        if (d.dw) return MVLT_ERR_UNSUPPORTED;          // the projection dgrad only rides on the scores-once kernel
         return launch<T, 32, 4, true>(d, bwd, dtype, s);
     }
     if (d.hd != 64) return MVLT_ERR_UNSUPPORTED;
@@ -1340,6 +1419,12 @@ int run(const MvltAttn* p, bool bwd, void* stream) {
     d.drop_scale = 1.0f / (1.0f - p->dropout_p);
     d.seed = p->seed; d.tag = p->tag;
     d.dout = p->dout; d.dqkv = p->dqkv; d.dbias = p->dbias_table; d.delta_ws = p->delta_ws;
+    if (bwd && p->dout_weight) {
+        MVLT_CHECK(p->mode == MVLT_ATTN_SWIN && aligned16(p->dout_weight), MVLT_ERR_ARG);
+        if (!(p->dtype == MVLT_BF16 && p->hd == 32 && (p->nH == 3 || p->nH == 6 || p->nH == 12) && p->dropout_p == 0.f)) return MVLT_ERR_UNSUPPORTED;
+        d.dw = p->dout_weight;
+    }
+    if (bwd && p->prefetch && p->prefetch_bytes >= 128) { d.pf = reinterpret_cast<const char*>(p->prefetch); d.pf_lines = (long)(p->prefetch_bytes >> 7); }
     MVLT_CHECK((p->row_start == nullptr) == (p->seq_len == nullptr), MVLT_ERR_ARG);
     MVLT_CHECK(p->row_start == nullptr || p->mode != MVLT_ATTN_SWIN, MVLT_ERR_ARG);
     d.row_start = p->row_start; d.seq_len = p->seq_len;

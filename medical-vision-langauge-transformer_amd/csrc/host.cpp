@@ -486,13 +486,21 @@ std::vector<Tensor> swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>&
     Tensor dx1 = empty2(rows, C, x), dyw = empty2(rows, C, x);
     { LnBranch br; br.dz = dp(dyw); br.rowmap = n2w; if (s1) { br.rowscale = P<float>(s1); br.rps = Lt; }
       ln_bwd(dxn2, nullptr, x1, fp(stat2), fp(stat2) + rows, (int)rows, C, f[5], g[7], g[8], dp(dx2), dx1, br, st); }
-    Tensor dao = empty2(rows, C, x);
-    { Epi e; e.pf = P(w[0]); e.pf_bytes = (int64_t)3 * C * C * esz; dgrad(dyw, w[1], C, dao, e, st); }
+    // the output projection's dgrad rides inside the attention backward where the kernel takes it (MvltAttn.dout_weight: bf16,
+    // 3 / 6 / 12 heads of 32; MVLT_SWIN_BWD_PROJ=0: the separate product)
+    static const bool proj_in_attn = [] { const char* e = getenv("MVLT_SWIN_BWD_PROJ"); return !e || e[0] != '0'; }();
+    const bool fuse_proj = proj_in_attn && dtype == MVLT_BF16 && C == 32 * nH && (nH == 3 || nH == 6 || nH == 12) && (shift == 0 || shift == 3);
+    Tensor dao = dyw;
+    if (!fuse_proj) {
+        dao = empty2(rows, C, x);
+        Epi e; e.pf = P(w[0]); e.pf_bytes = (int64_t)3 * C * C * esz; dgrad(dyw, w[1], C, dao, e, st);
+    }
     Tensor dqkv = empty2(rows, 3 * C, x);
     { MvltAttn p{}; p.dtype = dtype; p.mode = MVLT_ATTN_SWIN; p.nseq = B * nW; p.L = 49; p.nH = nH; p.hd = C / nH;
       p.qkv = dp(qkv); p.out = dp(ao); p.lse = fp(lse); p.scale = (float)scale;
       p.bias_table = P<float>(f[4]); p.nW = nW; p.win_res = res; p.shift = shift;
       p.dout = dp(dao); p.dqkv = dp(dqkv); p.dbias_table = P<float>(g[6]);
+      if (fuse_proj) { p.dout_weight = P(w[1]); p.prefetch = P(w[0]); p.prefetch_bytes = (int64_t)3 * C * C * esz; }
       attn_bwd_fork(p, ss); }
     for (const Tensor* t : std::initializer_list<const Tensor*>{&dy2, &act, &dh, &xn2, &dyw, &ao, &dqkv, &xn1w}) g_side_keepalive.push_back(*t);
     wgrad_group({{&dy2, &act, g[11], g[12]}, {&dh, &xn2, g[9], g[10]}, {&dyw, &ao, g[4], g[5]}, {&dqkv, &xn1w, g[2], g[3]}},

@@ -636,14 +636,23 @@ def attn_fwd(qkv, mode, nseq, Lq, nH, hd, scale, **kw):
     return out, lse
 
 
-def attn_bwd(dout, qkv, out, lse, mode, nseq, Lq, nH, hd, scale, dbias_table=None, event=None, **kw):
+def swin_bwd_proj_supported(dtype, nH, hd, shift):
+    """MvltAttn.dout_weight (the output projection's dgrad inside the Swin attention backward): bf16, head_dim 32, 3 / 6 / 12 heads."""
+    return dtype == torch.bfloat16 and hd == 32 and nH in (3, 6, 12) and shift in (0, 3)
+
+
+def attn_bwd(dout, qkv, out, lse, mode, nseq, Lq, nH, hd, scale, dbias_table=None, event=None, dout_weight=None, **kw):
     """event: a hipEvent_t handle (int) that completes with the call's last kernel (mvlt_attn_bwd_ev: the fork of the
-    weight-gradient stream without a marker packet on this stream)."""
+    weight-gradient stream without a marker packet on this stream).  dout_weight (Swin only): `dout` is the gradient of the output
+    projection's OUTPUT and the kernel applies proj.weight's transpose per head itself (MvltAttn.dout_weight)."""
     _need_cuda(qkv, dout)
     assert dout.is_contiguous() and dout.shape == out.shape
     dqkv = torch.empty_like(qkv)
     p = _attn_struct(qkv, out, lse, mode, nseq, Lq, nH, hd, scale, **kw)
     p.dout, p.dqkv = _p(dout), _p(dqkv)
+    if dout_weight is not None:
+        assert mode == L.ATTN_SWIN and dout_weight.dtype == qkv.dtype and dout_weight.is_contiguous() and dout_weight.shape == (nH * hd, nH * hd)
+        p.dout_weight = _p(dout_weight)
     if mode != L.ATTN_SWIN:
         delta = torch.empty_like(lse)          # delta_q hand-over between the two backward launches
         p.delta_ws = _p(delta)

@@ -107,6 +107,7 @@ class PatchEmbed(nn.Module):
 _FUSED_WMSA_BWD = False      # mvlt_swin_wmsa_bwd (one-launch backward of the first design) is parity-tested but 1.3-3.5x slower than the
                              # three launches at B = 32: the tests switch it on through this attribute (Python host path)
 _FUSED_WMSA = os.environ.get("MVLT_FUSED_WMSA", "auto")     # "0" never, "1" wherever supported, "auto" where it wins
+_SWIN_BWD_PROJ = os.environ.get("MVLT_SWIN_BWD_PROJ", "1") != "0"     # proj dgrad inside the attention backward (A/B switch; host.cpp reads it too)
 _WMSA2 = os.environ.get("MVLT_WMSA2", "1") != "0"           # second design at stage 2 (A/B measurements and parity tests turn it off)
 
 
@@ -438,10 +439,14 @@ class SwinTransformer(nn.Module):
             dqkv, dxn1w = ops.swin_wmsa_bwd(dyw, qkv, lse, B, H, nH, blk.shift_size, wpt, wqt,
                                             at.relative_position_bias_table.data, at.scale, dtab)
         else:
-            dao = ops.gemm(dyw, ar.compute(at.proj.weight), b_kmajor=True)
+            wp = ar.compute(at.proj.weight)
+            if _SWIN_BWD_PROJ and ops.swin_bwd_proj_supported(dyw.dtype, nH, C // nH, blk.shift_size):
+                dao, wp = dyw, wp               # the projection's dgrad rides inside the attention backward (MvltAttn.dout_weight)
+            else:
+                dao, wp = ops.gemm(dyw, wp, b_kmajor=True), None
             dqkv = ops.attn_bwd(dao, qkv, ao, lse, L.ATTN_SWIN, B * nW, ws * ws, nH, C // nH, at.scale,
                                 dbias_table=dtab, bias_table=at.relative_position_bias_table.data, nW=nW, win_res=H,
-                                shift=blk.shift_size)
+                                shift=blk.shift_size, dout_weight=wp)
             dxn1w = ops.gemm(dqkv, ar.compute(at.qkv.weight), b_kmajor=True)
         dx0 = ops.layernorm_bwd(dxn1w, x, mean1, rstd1, blk.norm1.weight.data, g(blk.norm1.weight),
                                 g(blk.norm1.bias), dy_rowmap=n2w, dres=dx1, defer=self.__dict__["_lnq"])

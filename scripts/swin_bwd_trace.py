@@ -1,12 +1,14 @@
 """Where a workgroup of the Swin attention backward kernel spends its time: build the library with
 `make -C <pkg>/csrc EXTRA=-DSW2_TRACE` (thread 0 of every workgroup then stamps the 100 MHz wall clock at 12 points into
-the buffer passed as delta_ws), run this, rebuild without the flag."""
+the buffer passed as delta_ws), run this, rebuild without the flag.  FUSE=1: with the output projection's dgrad inside the launch
+(MvltAttn.dout_weight; stages 0-2)."""
 import os, sys, ctypes as C
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvlt_amd import ops, _lib as L
 torch.manual_seed(0)
 B = 32
+FUSE = os.environ.get("FUSE") == "1"
 NAMES = ["start", "issued", "tbl+barrier", "init", "top barrier", "staged", "phase A", "barrier", "phase B", "loop end",
          "lds flush", "end"]
 for st, (res, nH) in enumerate([(56, 3), (28, 6), (14, 12), (7, 24)]):
@@ -21,6 +23,10 @@ for st, (res, nH) in enumerate([(56, 3), (28, 6), (14, 12), (7, 24)]):
     buf = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
     p = ops._attn_struct(qkv, out, lse, L.ATTN_SWIN, nseq, 49, nH, 32, 32 ** -0.5, **kw)
     p.dout, p.dqkv, p.dbias_table, p.delta_ws = ops._p(dout), ops._p(dqkv), ops._p(dtbl), ops._p(buf)
+    if FUSE:
+        if nH > 12: continue
+        wproj = (torch.randn(Cc, Cc, device="cuda") * Cc ** -0.5).bfloat16()
+        p.dout_weight = ops._p(wproj)
     for _ in range(3):
         L.check(L.lib().mvlt_attn_bwd(C.byref(p), ops._stream()), "bwd")
     torch.cuda.synchronize()

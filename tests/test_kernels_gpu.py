@@ -645,6 +645,50 @@ def test_swin_attention_backward_full_batches(ops, res, nH, shift, B):
     assert rel(dtab, tr.grad) < 2e-2
 
 
+@pytest.mark.parametrize("res,nH,shift,B", [(14, 12, 3, 24), (14, 12, 0, 32), (28, 6, 3, 12), (28, 6, 0, 3), (56, 3, 3, 6), (56, 3, 0, 32)])
+def test_swin_attention_backward_with_projection_dgrad(ops, res, nH, shift, B):
+    """MvltAttn.dout_weight: the output projection's dgrad inside the Swin attention backward (WindowAttention.proj,
+    visual_feature_extractor.py:252 backward) == the separate product followed by the plain launch, and both == the fp32 torch
+    statement with the projection included, per window as well; unsupported shapes are refused, not mis-computed."""
+    from mvlt_amd._lib import ATTN_SWIN
+    dt = torch.bfloat16
+    nW = (res // 7) ** 2
+    B_, C_ = B * nW, 32 * nH
+    qkv = rnd((B_ * 49, 3 * C_), dt, 53)
+    table = (0.5 * torch.randn(169, nH, generator=torch.Generator().manual_seed(54))).cuda()
+    wproj = rnd((C_, C_), dt, 56, C_ ** -0.5)
+    scale = 32 ** -0.5
+    kw = dict(bias_table=table, nW=nW, win_res=res, shift=shift)
+    out, lse = ops.attn_fwd(qkv, ATTN_SWIN, B_, 49, nH, 32, scale, **kw)
+    dy = rnd(out.shape, dt, 55)
+    qr = qkv.float().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    (swin_ref(qr, tr, nW, res, shift, nH, scale) @ wproj.float().t()).backward(dy.float())
+    dtab_a, dtab_b = torch.zeros_like(table), torch.zeros_like(table)
+    dao = ops.gemm(dy, wproj, b_kmajor=True)
+    two = ops.attn_bwd(dao, qkv, out, lse, ATTN_SWIN, B_, 49, nH, 32, scale, dbias_table=dtab_a, **kw)
+    one = ops.attn_bwd(dy, qkv, out, lse, ATTN_SWIN, B_, 49, nH, 32, scale, dbias_table=dtab_b, dout_weight=wproj, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(one.float()).all()
+    assert rel(one, two) < 2e-3 and rel(dtab_b, dtab_a) < 2e-3          # same bf16 dO up to the summation order of its f32 sums
+    assert rel(one, qr.grad) < tol(dt) * 3
+    e = (one.float() - qr.grad).view(B_, -1).norm(dim=1) / (qr.grad.view(B_, -1).norm(dim=1) + 1e-30)
+    assert float(e.max()) < tol(dt) * 4, int(e.argmax())
+    assert rel(dtab_b, tr.grad) < 2e-2
+
+
+def test_swin_attention_backward_projection_dgrad_refusals(ops):
+    from mvlt_amd._lib import ATTN_SWIN
+    for dt, nH in ((torch.float32, 3), (torch.bfloat16, 24), (torch.bfloat16, 4)):
+        C_ = 32 * nH
+        qkv = rnd((49, 3 * C_), dt, 1)
+        table = torch.zeros(169, nH, device="cuda")
+        kw = dict(bias_table=table, nW=1, win_res=7, shift=0)
+        out, lse = ops.attn_fwd(qkv, ATTN_SWIN, 1, 49, nH, 32, 32 ** -0.5, **kw)
+        with pytest.raises(RuntimeError, match="(?i)unsupported"):
+            ops.attn_bwd(rnd(out.shape, dt, 2), qkv, out, lse, ATTN_SWIN, 1, 49, nH, 32, 32 ** -0.5, dout_weight=rnd((C_, C_), dt, 3), **kw)
+
+
 def wmsa_ref(x, w2n, nW, res, shift, nH, g1, b1, wqkv, bqkv, wproj, bproj, table, scale, rowscale):
     """Attention half of SwinTransformerBlock.forward as plain fp32 torch (visual_feature_extractor.py:356-384)."""
     C_ = x.shape[1]
