@@ -33,8 +33,9 @@ PER_GPU_BATCH, SEQ = 32, 80
 DOMINANT_NAME = ("forward + dgrad GEMM family of the Swin blocks / BertLayers: gemm_kernel<bf16,{128|64},{128|96|64},row,{row|kmajor}>, "
                  "gemm_glds_kernel<{64|128},{64|96|128}>, gemm8_kernel, rowstream_kernel (x W^T and dy W with fused epilogues; main "
                  "stream) -- the family with the largest share of GPU time (~45 %, profiles/r6_bench_kernel_stats.csv)")
-WGRAD_NAME = ("gemm_group_kernel<bf16,{128|64},{128|96},kmajor,kmajor> (grouped weight-gradient GEMMs dW_i = dY_i^T X_i "
-              "+ bias gradients of one layer per launch; side stream, beside the dgrad chain)")
+WGRAD_NAME = ("gemm_group_glds_kernel<{128|64},128,{2|3}> (LDS-DMA, both operands k-major; round 6) and gemm_group_kernel<bf16,64,96,kmajor,kmajor> / "
+              "gemm8_kernel (Swin stages 0 / 1): grouped weight-gradient GEMMs dW_i = dY_i^T X_i + bias gradients of one layer per "
+              "launch; side stream, beside the dgrad chain")
 DOMINANT = ("group", 1, 64, 128)   # gemm_group_kernel<bf16, BM=128|64, BN=128, A k-major, B k-major>: the grouped weight-
                                    # gradient GEMM (all dW of one BertLayer / Swin block per launch), the symbol with
                                    # the largest share of GPU time (profiles/r1_bench_kernel_stats.csv)

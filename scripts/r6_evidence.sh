@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ev6; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 if [ "${PART:-A}" = "A" ]; then
 python3 $R/scripts/pmc.py --out $O/pmc --match gemm --passes sq1,fetch,write \
-  --family "family=gemm_kernel|gemm_glds_kernel|rowstream_kernel|gemm8_kernelILi.ELi.ELb0|gemm8_kernel<., ., false" --family "wgrad_group=gemm_group_kernel" \
+  --family "family=gemm_kernel|gemm_glds_kernel|rowstream_kernel|gemm8_kernelILi.ELi.ELb0|gemm8_kernel<., ., false" --family "wgrad_group=gemm_group_kernel|gemm_group_glds_kernel" \
   --json $O/r6_dominant_kernel_traffic.json -- python3 $R/bench.py --no-extra --no-cpu-baseline --steps 4 --warmup 2 > $O/r6_step_gemm_pmc.txt 2>$O/pmc.err
 echo pmc done
 python3 $R/scripts/pmc.py --out $O/pmc_rs --match rowstream --passes sq1,fetch,write -- python3 $R/bench.py --no-extra --no-cpu-baseline --steps 4 --warmup 2 > $O/r6_step_rowstream_pmc.txt 2>$O/pmc_rs.err

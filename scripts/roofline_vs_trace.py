@@ -15,7 +15,7 @@ groups.append(cur)
 t0, t1 = groups[warm - 1][-1][1], groups[warm + steps - 1][-1][1]
 d = json.loads(open(line).read().strip().splitlines()[-1])
 FAM = r"gemm_kernel|gemm_glds_kernel|rowstream_kernel|gemm8_kernelILi.ELi.ELb0|gemm8_kernel<\d, \d, false"
-for key, pat in (("roofline", FAM), ("roofline_wgrad_group", r"gemm_group_kernel")):
+for key, pat in (("roofline", FAM), ("roofline_wgrad_group", r"gemm_group_kernel|gemm_group_glds_kernel")):
     k = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows
          if t0 <= int(r["Start_Timestamp"]) < t1 and re.search(pat, r["Kernel_Name"])]
     tr = sum(k) / len(k)
