@@ -41,7 +41,7 @@ int mvlt_version(void);            /* MVLT_ABI_VERSION of the loaded library */
 const char* mvlt_arch(void);       /* "gfx950" */
 enum { MVLT_STRUCT_GEMM = 0, MVLT_STRUCT_LAYERNORM = 1, MVLT_STRUCT_LAYERNORM_BWD = 2, MVLT_STRUCT_LN_REDUCE_ITEM = 3,
        MVLT_STRUCT_ATTN = 4, MVLT_STRUCT_SWIN_WMSA = 5, MVLT_STRUCT_EMBED = 6, MVLT_STRUCT_ATTN_CACHED = 7,
-       MVLT_STRUCT_ZERO_ITEM = 8, MVLT_STRUCT_RANGE = 9, MVLT_STRUCT_MLM_MASK = 10, MVLT_STRUCT_GREEDY_STATE = 11, MVLT_STRUCT_COUNT = 12 };
+       MVLT_STRUCT_ZERO_ITEM = 8, MVLT_STRUCT_RANGE = 9, MVLT_STRUCT_MLM_MASK = 10, MVLT_STRUCT_GREEDY_STATE = 11, MVLT_STRUCT_SWIN_DBIAS_ITEM = 12, MVLT_STRUCT_COUNT = 13 };
 size_t mvlt_sizeof(int struct_id);
 
 /* ------------------------------------------------------------------ GEMM
@@ -188,6 +188,10 @@ typedef struct MvltLayerNormBwd {
     float dz_dropout_p; uint64_t seed; uint32_t tag;
     int defer_param_reduce;          /* 1: leave the partial rows in `workspace`; reduce them later, batched */
     const int32_t* rows_dev;         /* optional, DEVICE int: valid rows (<= rows); see MvltGemm.m_dev */
+    /* optional: dy is the SUM of dy_parts (2 .. 4) tensors of the same shape, dy_part_stride elements apart, starting at `dy` (the
+     * partial qkv-dgrad products of mvlt_swin_wmsa2_bwd): added in f32 while the rows are loaded, the sum rounded to bf16 once.
+     * bf16, C = 4 * lanes * chunks widths (96 .. 1024), no gelu / merge; else MVLT_ERR_UNSUPPORTED.  0 / 1: plain dy. */
+    int dy_parts; int64_t dy_part_stride;
 } MvltLayerNormBwd;
 int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream);
 int mvlt_layernorm_bwd_workspace_rows(void);
@@ -290,6 +294,8 @@ typedef struct MvltSwinWmsa {
      * (window order, required) is the result, y / wproj / bproj / rowscale are unused; follow with mvlt_gemm
      * (bias, DropPath row scale, window-reverse row map, residual).  For launches with too few windows to fill the chip. */
     int head_split;
+    /* mvlt_swin_wmsa2_bwd only: per-workgroup sums of the relative-position-bias gradient (see there), or NULL */
+    float* dbias_ws;
 } MvltSwinWmsa;
 int mvlt_swin_wmsa_supported(int dtype, int C, int nH);   /* 1 when the fused kernels cover this width */
 int mvlt_swin_wmsa_fwd(const MvltSwinWmsa* p, void* stream);
@@ -314,6 +320,26 @@ int mvlt_swin_wmsa_bwd_supported(int dtype, int C, int nH);
 int mvlt_swin_wmsa2_supported(int dtype, int B, int res, int C, int nH);
 int mvlt_swin_wmsa2_sync_words(int B, int res);
 int mvlt_swin_wmsa2_fwd(const MvltSwinWmsa* p, int32_t* sync_ws, void* stream);
+/* The backward of the same block half in ONE launch, in the second design's shape (round 6): output-projection dgrad +
+ * attention backward + qkv dgrad (visual_feature_extractor.py:224-254 backward); unit = (two windows, 3 heads), window order
+ * throughout.  Reads dy_win [B*res*res, C] (gradient of the projection's output, rowscale applied), qkv_win, lse, wproj, wqkv,
+ * bias_table, scale, shift; writes dqkv [B*res*res, 3C] and -- because the qkv dgrad sums over the heads and the head groups
+ * are different workgroups that never meet -- nparts = mvlt_swin_wmsa2_bwd_parts() PARTIAL products
+ *   dxn_win [nparts][B*res*res, C],  sum over the parts (f32) = dqkv Wqkv,
+ * which mvlt_layernorm_bwd adds while it loads them (MvltLayerNormBwd.dy_parts); dbias_table f32 [169, nH] is ACCUMULATED.
+ * bf16, C = 96 / 192 / 384 with nH = C / 32, shift 0 or 3, an even number of windows; else MVLT_ERR_UNSUPPORTED.
+ * _ev: `event` completes with the kernel (as mvlt_attn_bwd_ev). */
+int mvlt_swin_wmsa2_bwd_parts(int dtype, int B, int res, int C, int nH);    /* nH / 3, or 0 = shape not covered */
+/* Relative-position-bias gradient of that launch: every workgroup stores the sums of its units' dS along the 169 diagonals for its
+ * three heads into MvltSwinWmsa.dbias_ws, f32 [mvlt_swin_wmsa2_bwd_workgroups()][3 * 169] (plain stores: nothing to zero, no
+ * atomics), and mvlt_swin_wmsa2_bwd_dbias ADDS the workgroups of up to any number of launches into their tables
+ * (dbias_table f32 [169, nH]) in a fixed order -- one small launch for all Swin blocks of a step; items is a HOST array.
+ * (MvltSwinWmsa.dbias_table itself is not touched by mvlt_swin_wmsa2_bwd; dbias_ws may be NULL: no bias gradient.) */
+typedef struct MvltSwinDbiasItem { const float* ws; int nwg; int nH; float* dbias_table; } MvltSwinDbiasItem;
+int mvlt_swin_wmsa2_bwd_workgroups(int dtype, int B, int res, int C, int nH);
+int mvlt_swin_wmsa2_bwd_dbias(const MvltSwinDbiasItem* items, int n, void* stream);
+int mvlt_swin_wmsa2_bwd(const MvltSwinWmsa* p, void* stream);
+int mvlt_swin_wmsa2_bwd_ev(const MvltSwinWmsa* p, void* stream, void* event);
 int mvlt_swin_wmsa2_set_timeout_ms(int ms);    /* bound of the hand-off wait, process-wide; 0 restores the default (2000) */
 /* Diagnostic: `blocks` workgroups of 256 threads, each holding lds_bytes of LDS, spin for `usec` microseconds (100 MHz
  * real-time clock) and exit.  The tests use it to take CUs away from a launch that needs its workgroups co-resident. */

@@ -51,7 +51,8 @@ class MvltLayerNormBwd(C.Structure):
                 ("dgamma", vp), ("dbeta", vp), ("accumulate", i32),
                 ("workspace", vp),
                 ("dz", vp), ("dz_rowmap", vp), ("dz_rowscale", vp), ("dz_rows_per_scale", i32),
-                ("dz_dropout_p", f32), ("seed", u64), ("tag", u32), ("defer_param_reduce", i32), ("rows_dev", vp)]
+                ("dz_dropout_p", f32), ("seed", u64), ("tag", u32), ("defer_param_reduce", i32), ("rows_dev", vp),
+                ("dy_parts", i32), ("dy_part_stride", i64)]
 
 
 class MvltLnReduceItem(C.Structure):
@@ -77,7 +78,11 @@ class MvltSwinWmsa(C.Structure):
                 ("bias_table", vp), ("scale", f32), ("rowscale", vp),
                 ("xn_win", vp), ("attn_out", vp), ("lse", vp), ("mean", vp), ("rstd", vp),
                 ("dy_win", vp), ("dqkv", vp), ("dxn_win", vp), ("dbias_table", vp), ("qkv_win", vp),
-                ("wproj_t", vp), ("wqkv_t", vp), ("head_split", i32)]
+                ("wproj_t", vp), ("wqkv_t", vp), ("head_split", i32), ("dbias_ws", vp)]
+
+
+class MvltSwinDbiasItem(C.Structure):
+    _fields_ = [("ws", vp), ("nwg", i32), ("nH", i32), ("dbias_table", vp)]
 
 
 class MvltEmbed(C.Structure):
@@ -146,6 +151,11 @@ SYMBOLS = {
     "mvlt_swin_wmsa2_supported": (i32, [i32, i32, i32, i32, i32]),
     "mvlt_swin_wmsa2_sync_words": (i32, [i32, i32]),
     "mvlt_swin_wmsa2_fwd": (i32, [C.POINTER(MvltSwinWmsa), vp, vp]),
+    "mvlt_swin_wmsa2_bwd_parts": (i32, [i32, i32, i32, i32, i32]),
+    "mvlt_swin_wmsa2_bwd_workgroups": (i32, [i32, i32, i32, i32, i32]),
+    "mvlt_swin_wmsa2_bwd_dbias": (i32, [C.POINTER(MvltSwinDbiasItem), i32, vp]),
+    "mvlt_swin_wmsa2_bwd": (i32, [C.POINTER(MvltSwinWmsa), vp]),
+    "mvlt_swin_wmsa2_bwd_ev": (i32, [C.POINTER(MvltSwinWmsa), vp, vp]),
     "mvlt_swin_wmsa2_set_timeout_ms": (i32, [i32]),
     "mvlt_debug_hold_cus": (i32, [i32, i32, i32, vp]),
     "mvlt_debug_stream_copy": (i32, [vp, vp, i64, i32, i32, vp]),
@@ -180,7 +190,7 @@ SYMBOLS = {
 
 # ctypes mirror of every struct, in the order of the MVLT_STRUCT_* ids of the header
 STRUCTS = [MvltGemm, MvltLayerNorm, MvltLayerNormBwd, MvltLnReduceItem, MvltAttn, MvltSwinWmsa, MvltEmbed,
-           MvltAttnCached, MvltZeroItem, MvltRange, MvltMlmMask, MvltGreedyState]
+           MvltAttnCached, MvltZeroItem, MvltRange, MvltMlmMask, MvltGreedyState, MvltSwinDbiasItem]
 
 _lib = None
 

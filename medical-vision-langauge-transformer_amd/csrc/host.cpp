@@ -268,8 +268,13 @@ struct LnQueue {
         off += nfloats;
         return w;
     }
+    std::vector<MvltSwinDbiasItem> dbias;          // per-workgroup bias-gradient sums of mvlt_swin_wmsa2_bwd launches (same pool)
     void flush(void* stream) {
-        if (items.empty()) { off = 0; return; }
+        if (!dbias.empty()) {
+            ck(mvlt_swin_wmsa2_bwd_dbias(dbias.data(), (int)dbias.size(), stream), "mvlt_swin_wmsa2_bwd_dbias");
+            dbias.clear();
+        }
+        if (items.empty()) { off = 0; retired.clear(); return; }
         ck(mvlt_layernorm_param_reduce_batch(items.data(), (int)items.size(), stream), "mvlt_layernorm_param_reduce_batch");
         items.clear(); off = 0; retired.clear();
     }
@@ -280,10 +285,11 @@ struct LnBranch { void* dz = nullptr; const int32_t* rowmap = nullptr; const flo
                   float drop_p = 0.f; uint64_t seed = 0; uint32_t tag = 0; };
 void ln_bwd(const Tensor& dy, const int32_t* dy_rowmap, const Tensor& x, const float* mean, const float* rstd, int rows, int C,
             int64_t gamma, int64_t dgamma, int64_t dbeta, const void* dres, Tensor& dx, const LnBranch& br, void* stream,
-            const int32_t* rows_dev = nullptr) {
+            const int32_t* rows_dev = nullptr, int dy_parts = 0) {
     static const int ws_rows = mvlt_layernorm_bwd_workspace_rows();
     MvltLayerNormBwd p{};
     p.dtype = dtype_of(x); p.rows = rows; p.C = C;
+    if (dy_parts > 1) { p.dy_parts = dy_parts; p.dy_part_stride = (int64_t)rows * C; }          // dy: [dy_parts][rows, C]
     p.dy = dp(dy); p.dy_rowmap = dy_rowmap; p.x = dp(x); p.mean = mean; p.rstd = rstd; p.gamma = P<float>(gamma);
     p.dres = dres; p.dx = dp(dx);
     p.dgamma = P<float>(dgamma); p.dbeta = P<float>(dbeta);
@@ -490,12 +496,33 @@ std::vector<Tensor> swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>&
     // 3 / 6 / 12 heads of 32; MVLT_SWIN_BWD_PROJ=0: the separate product)
     static const bool proj_in_attn = [] { const char* e = getenv("MVLT_SWIN_BWD_PROJ"); return !e || e[0] != '0'; }();
     const bool fuse_proj = proj_in_attn && dtype == MVLT_BF16 && C == 32 * nH && (nH == 3 || nH == 6 || nH == 12) && (shift == 0 || shift == 3);
+    // one launch for projection dgrad + attention backward + qkv dgrad where the second design covers the shape
+    // (mvlt_swin_wmsa2_bwd: partial qkv-dgrad products per head group, summed by the LayerNorm backward below; MVLT_SWIN_BWD_ONE=0: off)
+    // MVLT_SWIN_BWD_ONE = smallest width that takes it (default 384: stage 2; 96 / 192: stages 0 / 1 too, measured slower there --
+    // a workgroup walks 4 / 2 units one after the other and every phase of a unit is latency-bound whatever the width)
+    static const int one_minc = [] { const char* e = getenv("MVLT_SWIN_BWD_ONE"); const int v = e ? atoi(e) : 384; return v <= 0 ? 1 << 30 : (v == 1 ? 96 : v); }();
+    const int nparts = (C >= one_minc && (shift == 0 || shift == 3)) ? mvlt_swin_wmsa2_bwd_parts(dtype, B, res, C, nH) : 0;
     Tensor dao = dyw;
-    if (!fuse_proj) {
+    if (!fuse_proj && !nparts) {
         dao = empty2(rows, C, x);
         Epi e; e.pf = P(w[0]); e.pf_bytes = (int64_t)3 * C * C * esz; dgrad(dyw, w[1], C, dao, e, st);
     }
     Tensor dqkv = empty2(rows, 3 * C, x);
+    Tensor dxn1w;
+    if (nparts) {
+        dxn1w = at::empty({(int64_t)nparts * rows, (int64_t)C}, x.options());
+        const int nwg = mvlt_swin_wmsa2_bwd_workgroups(dtype, B, res, C, nH);
+        float* ws = g_lnq.take((int64_t)nwg * 507, x);
+        MvltSwinWmsa p{};
+        p.dtype = dtype; p.B = B; p.res = res; p.C = C; p.nH = nH; p.shift = shift;
+        p.dy_win = dp(dyw); p.qkv_win = dp(qkv); p.lse = fp(lse); p.wproj = P(w[1]); p.wqkv = P(w[0]);
+        p.bias_table = P<float>(f[4]); p.scale = (float)scale;
+        p.dqkv = dp(dqkv); p.dxn_win = dp(dxn1w); p.dbias_ws = ws;
+        g_lnq.dbias.push_back(MvltSwinDbiasItem{ws, nwg, nH, P<float>(g[6])});
+        hipEvent_t e = next_event();
+        ck(mvlt_swin_wmsa2_bwd_ev(&p, ss.main, e), "mvlt_swin_wmsa2_bwd_ev");
+        TORCH_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(ss.side), e, 0) == hipSuccess, "hipStreamWaitEvent");
+    } else
     { MvltAttn p{}; p.dtype = dtype; p.mode = MVLT_ATTN_SWIN; p.nseq = B * nW; p.L = 49; p.nH = nH; p.hd = C / nH;
       p.qkv = dp(qkv); p.out = dp(ao); p.lse = fp(lse); p.scale = (float)scale;
       p.bias_table = P<float>(f[4]); p.nW = nW; p.win_res = res; p.shift = shift;
@@ -505,19 +532,21 @@ std::vector<Tensor> swin_block_bwd(const Tensor& dx2, const std::vector<Tensor>&
     for (const Tensor* t : std::initializer_list<const Tensor*>{&dy2, &act, &dh, &xn2, &dyw, &ao, &dqkv, &xn1w}) g_side_keepalive.push_back(*t);
     wgrad_group({{&dy2, &act, g[11], g[12]}, {&dh, &xn2, g[9], g[10]}, {&dyw, &ao, g[4], g[5]}, {&dqkv, &xn1w, g[2], g[3]}},
                 ss.side, g_ws_side);
-    Tensor dxn1w = empty2(rows, C, x);
-    { Epi e; if (nb) { e.pf = P(w[6]); e.pf_bytes = w[7]; } dgrad(dqkv, w[0], C, dxn1w, e, st); }
+    if (!nparts) {
+        dxn1w = empty2(rows, C, x);
+        Epi e; if (nb) { e.pf = P(w[6]); e.pf_bytes = w[7]; } dgrad(dqkv, w[0], C, dxn1w, e, st);
+    }
     Tensor dx0 = empty2(rows, C, x), dy2n;
     { LnBranch br;
       if (s2_next) { dy2n = empty2(rows, C, x); br.dz = dp(dy2n); br.rowscale = P<float>(s2_next); br.rps = Lt; }
-      ln_bwd(dxn1w, n2w, x, fp(stat1), fp(stat1) + rows, (int)rows, C, f[0], g[0], g[1], dp(dx1), dx0, br, st); }
+      ln_bwd(dxn1w, n2w, x, fp(stat1), fp(stat1) + rows, (int)rows, C, f[0], g[0], g[1], dp(dx1), dx0, br, st, nullptr, nparts); }
     if (s2_next) return {dx0, dy2n};
     return {dx0};
 }
 
 // ----------------------------------------------------------------------------------------------- housekeeping
 void lnq_flush(int64_t stream) { g_lnq.flush(P(stream)); }
-int64_t lnq_pending() { return (int64_t)g_lnq.items.size(); }
+int64_t lnq_pending() { return (int64_t)(g_lnq.items.size() + g_lnq.dbias.size()); }
 void side_release() { g_side_keepalive.clear(); g_ws_side.retired.clear(); g_ws_main.retired.clear(); }
 // a HIP graph has recorded the addresses of the current scratch buffers: keep them alive for the life of the process
 std::vector<Tensor> g_pinned_scratch;
@@ -558,6 +587,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         return std::vector<int64_t>{(int64_t)sizeof(MvltGemm), (int64_t)sizeof(MvltLayerNorm), (int64_t)sizeof(MvltLayerNormBwd),
                                     (int64_t)sizeof(MvltLnReduceItem), (int64_t)sizeof(MvltAttn), (int64_t)sizeof(MvltSwinWmsa),
                                     (int64_t)sizeof(MvltEmbed), (int64_t)sizeof(MvltAttnCached), (int64_t)sizeof(MvltZeroItem),
-                                    (int64_t)sizeof(MvltRange), (int64_t)sizeof(MvltMlmMask), (int64_t)sizeof(MvltGreedyState)};
+                                    (int64_t)sizeof(MvltRange), (int64_t)sizeof(MvltMlmMask), (int64_t)sizeof(MvltGreedyState),
+                                    (int64_t)sizeof(MvltSwinDbiasItem)};
     });
 }

@@ -717,6 +717,7 @@ extern "C" size_t mvlt_sizeof(int struct_id) {
         case MVLT_STRUCT_RANGE: return sizeof(MvltRange);
         case MVLT_STRUCT_MLM_MASK: return sizeof(MvltMlmMask);
         case MVLT_STRUCT_GREEDY_STATE: return sizeof(MvltGreedyState);
+        case MVLT_STRUCT_SWIN_DBIAS_ITEM: return sizeof(MvltSwinDbiasItem);
         default: return 0;
     }
 }

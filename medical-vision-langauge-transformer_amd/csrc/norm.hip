@@ -21,6 +21,7 @@ struct LnDev {
     // optional second output: dz[zmap ? zmap[r] : r] = dropmask(dx[r]) * zscale[r / zrps]
     void* dz; const int* zmap; const float* zscale; int zrps; uint32_t zthresh; float zdscale; uint64_t seed; uint32_t tag;
     const int* rows_dev;     // optional: valid rows on the device (ragged batches planned on the GPU)
+    int dy_parts; long dy_part_bytes;      // dy = sum of dy_parts tensors dy_part_bytes apart (MvltLayerNormBwd.dy_parts), or 0 / 1
 };
 MVLT_DEV int ln_rows(const LnDev& p) { return p.rows_dev ? min(p.rows, max(*p.rows_dev, 0)) : p.rows; }
 
@@ -245,8 +246,11 @@ MVLT_DEV u32x2 ln_pack4(const f32x4& v) {
 // buffer descriptors: one 32-bit offset register per row instead of a 64-bit pointer per operand, rows past the end read
 // zeros and their stores are dropped by the range check -- no clamps, no predicated loads.  PF: two row groups in flight.
 struct LnRowSet { uint32_t voff, zoff; float mean, rstd, zs; };
-template <int LPR, int NV, bool PF>
-__global__ __launch_bounds__(256, PF ? (NV <= 2 ? 5 : 4) : (NV <= 3 ? 6 : 5)) void ln_bwd2_kernel(const LnDev p) {
+// PARTS: dy is the SUM of up to four tensors (the partial qkv-dgrad products of mvlt_swin_wmsa2_bwd): the extra parts are loaded
+// beside the first one -- absent parts through an out-of-range offset, which a buffer load answers with zeros -- and added in f32
+// where the row's values are first used; the sum is rounded to bf16 once (12 more registers per row group: looser launch bounds).
+template <int LPR, int NV, bool PF, bool PARTS = false>
+__global__ __launch_bounds__(256, PARTS ? 4 : (PF ? (NV <= 2 ? 5 : 4) : (NV <= 3 ? 6 : 5))) void ln_bwd2_kernel(const LnDev p) {
     constexpr int RPW = 64 / LPR;
     constexpr int JB = LPR * 8;                                       // bytes between a lane's 4-element chunks
     constexpr uint32_t OOB = 0x7fffffffu;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256, PF ? (NV <= 2 ? 5 : 4) : (NV <= 3 ? 6 : 5)) vo
     const int nrows = ln_rows(p);
     const int stride = gridDim.x * 4 * RPW;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, nrows * rowb, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, p.rows * rowb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, PARTS ? (int)((p.dy_parts - 1) * p.dy_part_bytes) + p.rows * rowb : p.rows * rowb, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dres ? p.dres : p.x), 0, p.dres ? nrows * rowb : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(p.dx, 0, nrows * rowb, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(p.dz ? p.dz : p.dx, 0, p.dz ? p.rows * rowb : 0, 0x00020000);
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(256, PF ? (NV <= 2 ? 5 : 4) : (NV <= 3 ? 6 : 5)) vo
         return *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(gaddr + j * LPR * 16);
     };
 
+    u32x2 dpx[PARTS ? 3 : 1][NV];                                     // PARTS: parts 1 .. 3 of the row group in flight
     auto request = [&](int r0, LnRowSet& st, u32x2 (&xr)[NV], u32x2 (&dr)[NV], u32x2 (&rr)[NV]) {
         const int r = r0 + lane / LPR, rc = min(r, nrows - 1);
         const bool rv = r < nrows;
@@ -290,6 +295,14 @@ __global__ __launch_bounds__(256, PF ? (NV <= 2 ? 5 : 4) : (NV <= 3 ? 6 : 5)) vo
             xr[j] = __builtin_amdgcn_raw_buffer_load_b64(rx, st.voff + j * JB, 0, 0);
             dr[j] = __builtin_amdgcn_raw_buffer_load_b64(rdy, doff + j * JB, 0, 0);
         }
+        if constexpr (PARTS) {
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                const uint32_t po = (rv && pp + 1 < p.dy_parts) ? doff + (uint32_t)((pp + 1) * p.dy_part_bytes) : OOB;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) dpx[pp][j] = __builtin_amdgcn_raw_buffer_load_b64(rdy, po + j * JB, 0, 0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NV; ++j) rr[j] = __builtin_amdgcn_raw_buffer_load_b64(rdr, st.voff + j * JB, 0, 0);
     };
@@ -299,6 +312,15 @@ __global__ __launch_bounds__(256, PF ? (NV <= 2 ? 5 : 4) : (NV <= 3 ? 6 : 5)) vo
     auto finish = [&](const LnRowSet& st, u32x2 (&xr)[NV], u32x2 (&dr)[NV], u32x2 (&rr)[NV]) {
         float s1 = 0.f, s2 = 0.f;
         const float nm = -st.mean * st.rstd;
+        if constexpr (PARTS) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                f32x4 d = ln_unpack4(dr[j]);
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) d += ln_unpack4(dpx[pp][j]);
+                dr[j] = ln_pack4(d);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             opaque(xr[j]); opaque(dr[j]);
@@ -542,6 +564,7 @@ void launch_fwd(const LnDev& d, bool merge, hipStream_t s) {
     if (merge) hipLaunchKernelGGL((ln_fwd_kernel<T, LPR, NV, true>), grid, dim3(256), 0, s, d);
     else hipLaunchKernelGGL((ln_fwd_kernel<T, LPR, NV, false>), grid, dim3(256), 0, s, d);
 }
+thread_local bool g_ln_parts_unsupported = false;
 template <typename T, int LPR, int NV>
 void launch_bwd(LnDev d, bool merge, hipStream_t s) {
     const int nw = ln_bwd_waves(d.C);
@@ -553,11 +576,13 @@ void launch_bwd(LnDev d, bool merge, hipStream_t s) {
         if (ln_bwd2_on() && !merge && !d.gelu && d.C == 4 * LPR * NV && (long)d.rows * d.C < (1L << 30) - 65536) {
             static const bool pf = [] { const char* e = getenv("MVLT_LN_BWD2_PF"); return e && e[0] == '1'; }();          // two row groups in flight per wave (A/B switch)
             const size_t sh2 = 3 * (size_t)d.C * sizeof(float);          // reduction rows [2][C] + gamma [C]
-            if (pf && NV <= 3) hipLaunchKernelGGL((ln_bwd2_kernel<LPR, NV, true>), dim3(blocks), dim3(256), sh2, s, d);
+            if (d.dy_parts > 1) hipLaunchKernelGGL((ln_bwd2_kernel<LPR, NV, false, true>), dim3(blocks), dim3(256), sh2, s, d);
+            else if (pf && NV <= 3) hipLaunchKernelGGL((ln_bwd2_kernel<LPR, NV, true>), dim3(blocks), dim3(256), sh2, s, d);
             else hipLaunchKernelGGL((ln_bwd2_kernel<LPR, NV, false>), dim3(blocks), dim3(256), sh2, s, d);
             return;
         }
     }
+    if (d.dy_parts > 1) { g_ln_parts_unsupported = true; return; }
     const size_t sh = 2 * (size_t)nw * d.C * sizeof(float);
     if (merge) hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, true>), dim3(blocks), dim3(64 * nw), sh, s, d);
     else hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NV, false>), dim3(blocks), dim3(64 * nw), sh, s, d);
@@ -639,12 +664,20 @@ extern "C" int mvlt_layernorm_bwd(const MvltLayerNormBwd* p, void* stream) {
     d.dz = p->dz; d.zmap = p->dz_rowmap; d.zscale = p->dz_rowscale; d.zrps = p->dz_rows_per_scale > 0 ? p->dz_rows_per_scale : 1;
     d.zthresh = (uint32_t)((double)p->dz_dropout_p * 4294967296.0); d.zdscale = 1.0f / (1.0f - p->dz_dropout_p);
     d.seed = p->seed; d.tag = p->tag; d.rows_dev = p->rows_dev;
+    if (p->dy_parts > 1) {
+        // the low-footprint bf16 kernel only (what mvlt_swin_wmsa2_bwd feeds): 2 .. 4 parts, no GELU, no merge
+        MVLT_CHECK(p->dy_parts <= 4 && p->dy_part_stride >= (int64_t)p->rows * p->C, MVLT_ERR_ARG);
+        if (p->dtype != MVLT_BF16 || merge || p->gelu || !ln_bwd2_on() || (double)p->dy_parts * p->dy_part_stride * 2 >= 2147483648.0) return MVLT_ERR_UNSUPPORTED;
+        d.dy_parts = p->dy_parts; d.dy_part_bytes = (long)p->dy_part_stride * 2;
+    }
+    g_ln_parts_unsupported = false;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (p->dtype == MVLT_F32) rc = dispatch<float, true>(d, merge, s);
     else if (p->dtype == MVLT_BF16) rc = dispatch<bf16_t, true>(d, merge, s);
     else return MVLT_ERR_UNSUPPORTED;
     if (rc != MVLT_OK) return rc;
+    if (g_ln_parts_unsupported) return MVLT_ERR_UNSUPPORTED;         // (a width the low-footprint kernel does not take: nothing was launched)
     // the number of partial rows written == number of blocks launched above
     const int blocks = ln_bwd_blocks(p->rows, p->C);
     if (p->defer_param_reduce) return MVLT_OK;       // caller batches it with mvlt_layernorm_param_reduce_batch

@@ -512,9 +512,10 @@ def layernorm_fwd(x, gamma, beta, eps, *, rows=None, C_=None, out=None, out_rowm
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_pre=None, dres=None, merge=None,
-                  accumulate=False, dx=None, branch=None, defer=None, rows_dev=None):
+                  accumulate=False, dx=None, branch=None, defer=None, rows_dev=None, dy_parts=False):
     """branch=dict(rowmap=, rowscale=(t, rps), dropout=(p, seed, tag)) also returns the branch gradient dz.
-    defer=LnReduceQueue: the dgamma/dbeta partial rows are reduced later in one batched launch."""
+    defer=LnReduceQueue: the dgamma/dbeta partial rows are reduced later in one batched launch.
+    dy_parts=True: dy is [parts, rows, C], 1 .. 4 partial tensors whose sum is the gradient (swin_wmsa2_bwd's dxn_parts)."""
     _need_cuda(dy, x)
     Cn = gamma.numel()
     nrows = mean.numel()
@@ -531,6 +532,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dy_rowmap=None, y_
     p = L.MvltLayerNormBwd()
     p.dtype, p.rows, p.C = _dt(x), nrows, Cn
     p.dy, p.x, p.mean, p.rstd, p.gamma = _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma)
+    if dy_parts:
+        assert dy.dim() == 3 and dy.is_contiguous() and dy.shape[1:] == (nrows, Cn)
+        if dy.shape[0] > 1:
+            p.dy_parts, p.dy_part_stride = dy.shape[0], dy.stride(0)
     if dy_rowmap is not None:
         p.dy_rowmap = _p(dy_rowmap)
     if y_pre is not None:
@@ -883,6 +888,59 @@ def swin_wmsa_bwd(dy_win, qkv_win, lse, B, res, nH, shift, wproj_t, wqkv_t, tabl
     dxn = torch.empty_like(dy_win)
     p.dqkv, p.dxn_win, p.dbias_table = dqkv.data_ptr(), dxn.data_ptr(), dtable.data_ptr()
     L.check(L.lib().mvlt_swin_wmsa_bwd(C.byref(p), _stream()), "mvlt_swin_wmsa_bwd")
+    return dqkv, dxn
+
+
+def swin_wmsa2_bwd_parts(dtype, B, res, C_, nH):
+    """Number of partial dXn tensors the one-launch backward of the second design writes (nH / 3); 0 = shape not covered."""
+    return int(L.lib().mvlt_swin_wmsa2_bwd_parts(_DT[dtype], B, res, C_, nH))
+
+
+def swin_dbias_reduce(items):
+    """items: [(ws f32 [nwg, 3 * 169], nH, dtable f32 [169, nH])]: the per-workgroup sums of mvlt_swin_wmsa2_bwd launches added
+    into their tables, one launch for all of them (mvlt_swin_wmsa2_bwd_dbias)."""
+    arr = (L.MvltSwinDbiasItem * len(items))()
+    for i, (ws, nH, dtable) in enumerate(items):
+        assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.shape[1] == 507 and dtable.dtype == torch.float32 and dtable.shape == (169, nH)
+        arr[i].ws, arr[i].nwg, arr[i].nH, arr[i].dbias_table = ws.data_ptr(), ws.shape[0], nH, dtable.data_ptr()
+    L.check(L.lib().mvlt_swin_wmsa2_bwd_dbias(arr, len(items), _stream()), "mvlt_swin_wmsa2_bwd_dbias")
+
+
+def swin_wmsa2_bwd(dy_win, qkv_win, lse, B, res, nH, shift, wproj, wqkv, table, scale, dtable, event=None, dbias_defer=None):
+    """Output-projection dgrad + window-attention backward + qkv dgrad in one launch, second design (mvlt_swin_wmsa2_bwd).
+    dy_win [rows, C] window order (DropPath scale applied); wproj [C, C], wqkv [3C, C] as stored (compute dtype).
+    Returns (dqkv [rows, 3C], dxn_parts [nH / 3, rows, C]): the qkv dgrad is the SUM of the parts (layernorm_bwd adds them
+    while it loads: dy_parts); dtable (f32 [169, nH]) is accumulated -- by a second small launch here, or later together with
+    other blocks' when dbias_defer (a list) is given: it receives (ws, nH, dtable) for swin_dbias_reduce."""
+    _need_cuda(dy_win)
+    rows, Cn = dy_win.shape
+    nparts = swin_wmsa2_bwd_parts(dy_win.dtype, B, res, Cn, nH)
+    assert nparts > 0, "mvlt_swin_wmsa2_bwd: shape not covered"
+    assert dy_win.is_contiguous() and qkv_win.is_contiguous() and qkv_win.shape == (rows, 3 * Cn) and rows == B * res * res
+    assert wproj.is_contiguous() and wproj.shape == (Cn, Cn) and wqkv.is_contiguous() and wqkv.shape == (3 * Cn, Cn)
+    assert wproj.dtype == dy_win.dtype and wqkv.dtype == dy_win.dtype
+    assert lse.dtype == torch.float32 and table.dtype == torch.float32 and dtable.dtype == torch.float32
+    p = L.MvltSwinWmsa()
+    p.dtype, p.B, p.res, p.C, p.nH, p.shift = _DT[dy_win.dtype], B, res, Cn, nH, shift
+    p.dy_win, p.qkv_win, p.lse = dy_win.data_ptr(), qkv_win.data_ptr(), lse.data_ptr()
+    p.wproj, p.wqkv, p.bias_table, p.scale = wproj.data_ptr(), wqkv.data_ptr(), table.data_ptr(), float(scale)
+    dqkv = torch.empty_like(qkv_win)
+    dxn = torch.empty((nparts, rows, Cn), dtype=dy_win.dtype, device=dy_win.device)
+    p.dqkv, p.dxn_win = dqkv.data_ptr(), dxn.data_ptr()
+    ws = None
+    if dtable is not None:
+        nwg = int(L.lib().mvlt_swin_wmsa2_bwd_workgroups(p.dtype, B, res, Cn, nH))
+        ws = torch.empty((nwg, 507), dtype=torch.float32, device=dy_win.device)
+        p.dbias_ws = ws.data_ptr()
+    if event is not None:
+        L.check(L.lib().mvlt_swin_wmsa2_bwd_ev(C.byref(p), _stream(), C.c_void_p(event)), "mvlt_swin_wmsa2_bwd_ev")
+    else:
+        L.check(L.lib().mvlt_swin_wmsa2_bwd(C.byref(p), _stream()), "mvlt_swin_wmsa2_bwd")
+    if ws is not None:
+        if dbias_defer is not None:
+            dbias_defer.append((ws, nH, dtable))
+        else:
+            swin_dbias_reduce([(ws, nH, dtable)])
     return dqkv, dxn
 
 

@@ -107,6 +107,8 @@ class PatchEmbed(nn.Module):
 _FUSED_WMSA_BWD = False      # mvlt_swin_wmsa_bwd (one-launch backward of the first design) is parity-tested but 1.3-3.5x slower than the
                              # three launches at B = 32: the tests switch it on through this attribute (Python host path)
 _FUSED_WMSA = os.environ.get("MVLT_FUSED_WMSA", "auto")     # "0" never, "1" wherever supported, "auto" where it wins
+_SWIN_BWD_ONE = int(os.environ.get("MVLT_SWIN_BWD_ONE", "384"))        # smallest width whose blocks take the one-launch backward (0: none; host.cpp reads it too)
+_SWIN_BWD_ONE = (1 << 30) if _SWIN_BWD_ONE <= 0 else (96 if _SWIN_BWD_ONE == 1 else _SWIN_BWD_ONE)
 _SWIN_BWD_PROJ = os.environ.get("MVLT_SWIN_BWD_PROJ", "1") != "0"     # proj dgrad inside the attention backward (A/B switch; host.cpp reads it too)
 _WMSA2 = os.environ.get("MVLT_WMSA2", "1") != "0"           # second design at stage 2 (A/B measurements and parity tests turn it off)
 
@@ -431,7 +433,11 @@ class SwinTransformer(nn.Module):
                                      branch=dict(rowmap=n2w, rowscale=(s1, Lt) if s1 is not None else None),
                                      defer=self.__dict__["_lnq"])
         dtab = g(at.relative_position_bias_table)          # zeroed for all blocks at once in _backward
-        if _FUSED_WMSA_BWD and ops.swin_wmsa_bwd_supported(dyw.dtype, C, nH):
+        if C >= _SWIN_BWD_ONE and blk.shift_size in (0, 3) and ops.swin_wmsa2_bwd_parts(dyw.dtype, B, H, C, nH):
+            # one launch, second design: dxn1w comes back as nH / 3 partial products that the LayerNorm backward below sums
+            dqkv, dxn1w = ops.swin_wmsa2_bwd(dyw, qkv, lse, B, H, nH, blk.shift_size, ar.compute(at.proj.weight),
+                                             ar.compute(at.qkv.weight), at.relative_position_bias_table.data, at.scale, dtab)
+        elif _FUSED_WMSA_BWD and ops.swin_wmsa_bwd_supported(dyw.dtype, C, nH):
             # opt-in (MVLT_FUSED_WMSA_BWD=1, Python host path): proj dgrad + attention backward + qkv dgrad in one
             # launch.  Correct, but slower than the three launches at B=32 (profiles/r2_wmsa_pmc.md), hence not default.
             wpt = ar.compute(at.proj.weight).t().contiguous()
@@ -449,7 +455,7 @@ class SwinTransformer(nn.Module):
                                 shift=blk.shift_size, dout_weight=wp)
             dxn1w = ops.gemm(dqkv, ar.compute(at.qkv.weight), b_kmajor=True)
         dx0 = ops.layernorm_bwd(dxn1w, x, mean1, rstd1, blk.norm1.weight.data, g(blk.norm1.weight),
-                                g(blk.norm1.bias), dy_rowmap=n2w, dres=dx1, defer=self.__dict__["_lnq"])
+                                g(blk.norm1.bias), dy_rowmap=n2w, dres=dx1, defer=self.__dict__["_lnq"], dy_parts=dxn1w.dim() == 3)
         # ---- weight / bias gradients (only the optimizer consumes them): side stream, overlapping the next block
         with ops.on_side(dx2.device, dy2, a, dh, xn2, dyw, ao, dqkv, xn1w):
             ops.wgrad_group([(dy2, a, g(mlp.fc2.weight), g(mlp.fc2.bias)),

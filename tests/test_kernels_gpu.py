@@ -689,6 +689,67 @@ def test_swin_attention_backward_projection_dgrad_refusals(ops):
             ops.attn_bwd(rnd(out.shape, dt, 2), qkv, out, lse, ATTN_SWIN, 1, 49, nH, 32, 32 ** -0.5, dout_weight=rnd((C_, C_), dt, 3), **kw)
 
 
+@pytest.mark.parametrize("res,nH,shift,B", [(14, 12, 3, 24), (14, 12, 0, 32), (14, 12, 3, 1), (28, 6, 3, 12), (28, 6, 0, 3), (56, 3, 3, 6), (56, 3, 0, 32)])
+def test_swin_wmsa2_backward_one_launch(ops, res, nH, shift, B):
+    """mvlt_swin_wmsa2_bwd: projection dgrad + attention backward + qkv dgrad of a Swin block in one launch (unit = two windows x
+    three heads, partial qkv-dgrad products per head group) == the three launches, and == the fp32 torch statement of
+    visual_feature_extractor.py:224-254 backward (dqkv per window, the SUM of the partial products, the bias-table gradient)."""
+    from mvlt_amd._lib import ATTN_SWIN
+    dt = torch.bfloat16
+    nW = (res // 7) ** 2
+    B_, C_ = B * nW, 32 * nH
+    assert ops.swin_wmsa2_bwd_parts(dt, B, res, C_, nH) == nH // 3
+    qkv = rnd((B_ * 49, 3 * C_), dt, 63)
+    table = (0.5 * torch.randn(169, nH, generator=torch.Generator().manual_seed(64))).cuda()
+    wproj, wqkv = rnd((C_, C_), dt, 66, C_ ** -0.5), rnd((3 * C_, C_), dt, 67, C_ ** -0.5)
+    scale = 32 ** -0.5
+    kw = dict(bias_table=table, nW=nW, win_res=res, shift=shift)
+    out, lse = ops.attn_fwd(qkv, ATTN_SWIN, B_, 49, nH, 32, scale, **kw)
+    dy = rnd(out.shape, dt, 65)
+    qr = qkv.float().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    (swin_ref(qr, tr, nW, res, shift, nH, scale) @ wproj.float().t()).backward(dy.float())
+    dtab_a, dtab_b = torch.zeros_like(table), torch.zeros_like(table)
+    three = ops.attn_bwd(ops.gemm(dy, wproj, b_kmajor=True), qkv, out, lse, ATTN_SWIN, B_, 49, nH, 32, scale, dbias_table=dtab_a, **kw)
+    dxn_three = ops.gemm(three, wqkv, b_kmajor=True)
+    one, parts = ops.swin_wmsa2_bwd(dy, qkv, lse, B, res, nH, shift, wproj, wqkv, table, scale, dtab_b)
+    torch.cuda.synchronize()
+    assert parts.shape == (nH // 3, B_ * 49, C_) and torch.isfinite(one.float()).all() and torch.isfinite(parts.float()).all()
+    assert rel(one, three) < 2e-3 and rel(dtab_b, dtab_a) < 2e-3
+    assert rel(one, qr.grad) < tol(dt) * 3
+    e = (one.float() - qr.grad).view(B_, -1).norm(dim=1) / (qr.grad.view(B_, -1).norm(dim=1) + 1e-30)
+    assert float(e.max()) < tol(dt) * 4, int(e.argmax())
+    assert rel(dtab_b, tr.grad) < 2e-2
+    dxn_ref = qr.grad @ wqkv.float()
+    dxn = parts.float().sum(0)
+    assert rel(dxn, dxn_ref) < tol(dt) * 3 and rel(dxn, dxn_three) < tol(dt) * 2
+    e = (dxn - dxn_ref).view(B_, -1).norm(dim=1) / (dxn_ref.view(B_, -1).norm(dim=1) + 1e-30)
+    assert float(e.max()) < tol(dt) * 4, int(e.argmax())
+
+
+@pytest.mark.parametrize("rows,C_,parts", [(6272, 384, 4), (25088, 192, 2), (3001, 384, 3), (400, 768, 4), (6272, 96, 1)])
+def test_layernorm_bwd_sum_of_partial_dy(ops, rows, C_, parts):
+    """MvltLayerNormBwd.dy_parts: dy given as 2 .. 4 partial tensors (mvlt_swin_wmsa2_bwd's partial qkv-dgrad products) == the
+    plain launch on their bf16-rounded f32 sum, with a gathered dy and a residual-path gradient as the Swin block uses them."""
+    dt = torch.bfloat16
+    x = rnd((rows, C_), dt, 71)
+    gamma = (1.0 + 0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(72))).cuda()
+    dyp = rnd((parts, rows, C_), dt, 73, 0.5)
+    dres = rnd((rows, C_), dt, 74)
+    perm = torch.randperm(rows, generator=torch.Generator().manual_seed(75)).to(torch.int32).cuda()
+    mean = x.float().mean(1)
+    rstd = (x.float().var(1, unbiased=False) + 1e-5).rsqrt()
+    dsum = dyp.float().sum(0).to(dt)
+    outs = []
+    for dy in (dyp, dsum):
+        dg, db = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dy_rowmap=perm, dres=dres, dy_parts=dy.dim() == 3)
+        outs.append((dx, dg, db))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def wmsa_ref(x, w2n, nW, res, shift, nH, g1, b1, wqkv, bqkv, wproj, bproj, table, scale, rowscale):
     """Attention half of SwinTransformerBlock.forward as plain fp32 torch (visual_feature_extractor.py:356-384)."""
     C_ = x.shape[1]
