@@ -148,7 +148,6 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
     const float sc2 = p.scale * LOG2E_;
     const float MASKL2 = -100.0f * LOG2E_;
     const int nwx = p.res / 7;
-    const __amdgpu_buffer_rsrc_t dq_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dqkv, 0, (int)((long)p.nwin * 49 * 3 * C * 2), 0x00020000);
 
     // once per workgroup: bias values of the group's heads (times log2 e), the pair facts of this thread's score elements
     for (int i = tid0; i < G * 176; i += 512) {
@@ -165,6 +164,16 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
     float dbsum[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) dbsum[i] = 0.f;
+    // entry (dy, dx) sums dS[q][q - (7 dy + dx)] over the q = (qy, qx) with qy - dy and qx - dx inside the window: ONE element offset
+    // per thread and 7 + 7 validity flags (hipcc keeps them as lane masks in scalar registers: an s_and + a v_cndmask per element)
+    const int db_e = tid0 & 255, db_dy = db_e / 13 - 6, db_dx = db_e % 13 - 6;
+    const int db_off = -(db_dy * 7 + db_dx);
+    bool db_rok[7], db_cok[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+        db_rok[a] = db_e < 169 && a - db_dy >= 0 && a - db_dy <= 6;
+        db_cok[a] = a - db_dx >= 0 && a - db_dx <= 6;
+    }
 
 #pragma unroll 1
     for (int unit = bid; unit < p.nunits; unit += gridDim.x) {
@@ -291,10 +300,8 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
             float* lse_s = reinterpret_cast<float*>(hb + 3 * B2_IMG + 2 * B2_PIMG);
             uint32_t mb = 0;
             if (p.shift) { const int w = seq % p.nW; mb = ((w / nwx) == nwx - 1 ? rowA : 0u) | ((w % nwx) == nwx - 1 ? colA : 0u); }
-            auto store_rows = [&](int row, bool valid, int gcol, int tcol, const f32x4& v) {     // 4 bf16: dqkv[rs + row][gcol ..] and the LDS tile
+            auto store_rows = [&](int row, bool valid, int tcol, const f32x4& v) {     // 4 bf16 of the group's dqkv tile (HBM: once per unit, below)
                 bf16x4 r; r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
-                const uint32_t off = valid ? (uint32_t)(((rs + row) * 3 * C + gcol) * 2) : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, r), dq_rsrc, off, 0, 0);
                 if (valid) *reinterpret_cast<bf16x4*>(qtile + xoff<QC>(49 * half + row, tcol >> 3) + (tcol & 7) * 2) = r;
             };
 #pragma unroll
@@ -329,6 +336,7 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
                         M::mma(dp[t], fv[t], fd);
                     }
                     issue_v(i + 1);                            // the V registers are free again
+                    if (i == 0) WB2_STAMP(18);                 // (diagnostic) phase-A score / dP products issued
                     const int q = 16 * tq + c15;
                     const float lse_q = lse_s[q];
                     const float* tb = tbl + i * 176;
@@ -353,6 +361,7 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
                         for (int j = 0; j < 4; ++j) sc[t][j] = sc[t][j] * (dp[t][j] - dl);
                         store4f(si + q * B2_LDP + 16 * t + 4 * g, sc[t]);
                     }
+                    if (i == 0) WB2_STAMP(19);                 // (diagnostic) softmax / dS done, images written
                     f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) {
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
                         for (int td = 0; td < 2; ++td) M::mma(dq[td], frag_tok(ki, B2_LD, 16 * td, kb), fs);
                     }
 #pragma unroll
-                    for (int td = 0; td < 2; ++td) store_rows(q, q < 49, h * 32 + 16 * td + 4 * g, 32 * i + 16 * td + 4 * g, dq[td] * p.scale);
+                    for (int td = 0; td < 2; ++td) store_rows(q, q < 49, 32 * i + 16 * td + 4 * g, dq[td] * p.scale);
                 }
                 __syncthreads();                               // P and dS of every query tile are in LDS
                 WB2_STAMP(4 + 3 * i);                          // phase A done
@@ -379,27 +388,24 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
                             M::mma(dv[td], frag_tok(di, B2_LD, 16 * td, kb), fp);
                         }
                     }
+                    if (i == 0) WB2_STAMP(16);                 // (diagnostic) phase-B products issued
                     const int k = 16 * tk + c15;
 #pragma unroll
                     for (int td = 0; td < 2; ++td) {
-                        store_rows(k, k < 49, C + h * 32 + 16 * td + 4 * g, OC + 32 * i + 16 * td + 4 * g, dk[td] * p.scale);
-                        store_rows(k, k < 49, 2 * C + h * 32 + 16 * td + 4 * g, 2 * OC + 32 * i + 16 * td + 4 * g, dv[td]);
+                        store_rows(k, k < 49, OC + 32 * i + 16 * td + 4 * g, dk[td] * p.scale);
+                        store_rows(k, k < 49, 2 * OC + 32 * i + 16 * td + 4 * g, dv[td]);
                     }
                 }
-                if (ht < 169) {
-                    // 49 independent, clamped LDS reads of this entry's diagonal of dS[q][k] (k = q - (7 dy + dx) where both are inside).
-                    // (the entry's coordinates come from an opaque copy of the thread index: left visible, hipcc hoists the 49 offsets
-                    // and validity flags out of the unit loop and carries ~100 registers through every phase)
-                    int e0 = ht;
-                    asm volatile("" : "+v"(e0));          // (hipcc otherwise shares the 49 offsets and flags between the three heads)
-                    const int db_dy = e0 / 13 - 6, db_dx = e0 % 13 - 6, db_shift = db_dy * 7 + db_dx;
+                if (i == 0) WB2_STAMP(17);                     // (diagnostic) phase-B stores issued
+                if (hw < 3) {                                  // (entries 0 .. 168 live in the first three waves of a half)
+                    // 49 independent LDS reads at base + 73 q (an invalid element may lie outside the image -- never outside the
+                    // workgroup's LDS -- and is dropped by the select)
+                    const T* sb = si + db_off;
                     float sum = 0.f;
 #pragma unroll
                     for (int qq = 0; qq < 49; ++qq) {
-                        const int qy = qq / 7, qx = qq % 7;
-                        const bool ok = qy - db_dy >= 0 && qy - db_dy <= 6 && qx - db_dx >= 0 && qx - db_dx <= 6;
-                        const float v = (float)si[qq * B2_LDP + min(max(qq - db_shift, 0), 48)];
-                        sum += ok ? v : 0.f;
+                        const float v = (float)sb[qq * (B2_LDP + 1)];
+                        sum += (db_rok[qq / 7] && db_cok[qq % 7]) ? v : 0.f;
                     }
                     dbsum[i] += sum;
                 }
@@ -462,6 +468,13 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
                 T* dst = p.dxn + (long)hg * p.part_stride + grow0 * C;
                 for (int f = tid; f < 98 * CPR; f += 512)
                     *reinterpret_cast<bf16x8*>(dst + (long)f * 8) = *reinterpret_cast<const bf16x8*>(regA + xoff<C>(f / CPR, f % CPR));
+                // dq / dk / dv of the group (the qkv weight gradient reads them): the tile is still whole -- 16-byte pieces, three
+                // 192-byte runs per row (q, k, v columns of the group's heads)
+                T* dq0 = p.dqkv + grow0 * 3 * C + head0 * 32;
+                for (int f = tid; f < 98 * (QC / 8); f += 512) {
+                    const int row = f / (QC / 8), c = f - row * (QC / 8), part = c / (OC / 8), cc = c - part * (OC / 8);
+                    *reinterpret_cast<bf16x8*>(dq0 + (long)row * 3 * C + part * C + cc * 8) = *reinterpret_cast<const bf16x8*>(qtile + xoff<QC>(row, c));
+                }
             }
         }
     }

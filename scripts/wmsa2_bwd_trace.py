@@ -36,3 +36,9 @@ for st, (res, nH) in enumerate([(56, 3), (28, 6), (14, 12)]):
         d = (t[:, k] - prev) / 100
         print(f"   {NAMES[k - 1]:>18s}: + {float(d.median()):6.2f} us median (min {float(d.min()):6.2f}, max {float(d.max()):6.2f}); at {float((t[:, k] - t[:, 0]).median()) / 100:6.2f} us")
         prev = t[:, k]
+    tt = buf.view(-1, 32).cpu().double()
+    tt = tt[tt[:, 0] > 0]
+    for a, b, name in ((3, 18, "problem 0: staged -> score / dP products issued"), (18, 19, "-> softmax / dS, images written"), (19, 4, "-> dQ products, stores, barrier"),
+                       (4, 16, "phase B: barrier -> products issued"), (16, 17, "-> stores issued"), (17, 5, "-> bias-gradient diagonals")):
+        d = (tt[:, b] - tt[:, a]) / 100
+        print(f"      {name:>52s}: {float(d.median()):6.2f} us")
