@@ -165,13 +165,22 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
 #pragma unroll
     for (int i = 0; i < G; ++i) dbsum[i] = 0.f;
     // entry (dy, dx) sums dS[q][q - (7 dy + dx)] over the q = (qy, qx) with qy - dy and qx - dx inside the window: ONE element offset
-    // per thread and 7 + 7 validity flags (hipcc keeps them as lane masks in scalar registers: an s_and + a v_cndmask per element)
-    const int db_e = tid0 & 255, db_dy = db_e / 13 - 6, db_dx = db_e % 13 - 6;
+    // per thread and 7 + 7 validity flags (hipcc keeps them as lane masks in scalar registers: an s_and + a v_cndmask per element).
+    // The 169 entries are dealt to the four waves of a half by the query rows they can touch, so that no wave reads more than four
+    // of the seven rows: wave 0: dy = -6 .. -3 (entries 0 .. 51, rows 0 .. 3), wave 1: dy = 3 .. 6 (117 .. 168, rows 3 .. 6),
+    // waves 2 / 3: dy = -2 .. 2 (52 .. 115; rows 0 .. 3 / 4 .. 6); the 65th entry of that band (116) rides on lane 52 of waves 0
+    // (rows 0 .. 3) and 1 (rows 4 .. 6).  An entry's parts meet when the workgroup stores its sums.
+    const int db_w = (tid0 >> 6) & 3, db_l = tid0 & 63;
+    const int db_e = db_w == 0 ? (db_l < 52 ? db_l : 116) : (db_w == 1 ? (db_l < 52 ? 117 + db_l : 116) : 52 + db_l);
+    const bool db_act = db_w >= 2 || db_l <= 52;
+    const int db_dy = db_e / 13 - 6, db_dx = db_e % 13 - 6;
     const int db_off = -(db_dy * 7 + db_dx);
+    const int db_r0 = (db_w == 0 || db_w == 2) ? 0 : ((db_w == 1 && db_l < 52) ? 3 : 4);      // first row of this thread's part
+    const int db_r1 = (db_w == 0 || db_w == 2) ? 3 : 6;                                        // last
     bool db_rok[7], db_cok[7];
 #pragma unroll
     for (int a = 0; a < 7; ++a) {
-        db_rok[a] = db_e < 169 && a - db_dy >= 0 && a - db_dy <= 6;
+        db_rok[a] = db_act && a >= db_r0 && a <= db_r1 && a - db_dy >= 0 && a - db_dy <= 6;
         db_cok[a] = a - db_dx >= 0 && a - db_dx <= 6;
     }
 
@@ -321,7 +330,6 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
                 __syncthreads();
                 WB2_STAMP(3 + 3 * i);                          // problem i staged
                 if (i == G - 1) fill3(0);                      // the dO tile has been read for the last time: ring slot 0 fills under this problem
-                issue(i + 1);                                  // next head in flight (last head: re-read, harmless)
                 // ---- phase A: keys on accumulator rows, query tile hw on the columns -> dQ, dBias, P and dS images
                 {
                     const int tq = hw;
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
                         M::mma(sc[t], frag_rowmajor<T>(ki, B2_LD, 16 * t, 0), fq);
                         M::mma(dp[t], fv[t], fd);
                     }
+                    issue(i + 1);                              // next head in flight (last head: re-read, harmless)
                     issue_v(i + 1);                            // the V registers are free again
                     if (i == 0) WB2_STAMP(18);                 // (diagnostic) phase-A score / dP products issued
                     const int q = 16 * tq + c15;
@@ -397,15 +406,21 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
                     }
                 }
                 if (i == 0) WB2_STAMP(17);                     // (diagnostic) phase-B stores issued
-                if (hw < 3) {                                  // (entries 0 .. 168 live in the first three waves of a half)
-                    // 49 independent LDS reads at base + 73 q (an invalid element may lie outside the image -- never outside the
-                    // workgroup's LDS -- and is dropped by the select)
+                {
+                    // <= 28 independent LDS reads at base + 73 q (an invalid element may lie outside the image -- never outside the
+                    // workgroup's LDS -- and is dropped by the select); the rows of a wave are wave-uniform
                     const T* sb = si + db_off;
                     float sum = 0.f;
+                    const int ra = (hw == 0 || hw == 2) ? 0 : (hw == 1 ? 3 : 4), rb = (hw == 0 || hw == 2) ? 3 : 6;
 #pragma unroll
-                    for (int qq = 0; qq < 49; ++qq) {
-                        const float v = (float)sb[qq * (B2_LDP + 1)];
-                        sum += (db_rok[qq / 7] && db_cok[qq % 7]) ? v : 0.f;
+                    for (int qy = 0; qy < 7; ++qy) {
+                        if (qy >= ra && qy <= rb) {
+#pragma unroll
+                            for (int qx = 0; qx < 7; ++qx) {
+                                const float v = (float)sb[(7 * qy + qx) * (B2_LDP + 1)];
+                                sum += (db_rok[qy] && db_cok[qx]) ? v : 0.f;
+                            }
+                        }
                     }
                     dbsum[i] += sum;
                 }
@@ -480,20 +495,26 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
     }
 
     { const int unit = bid; WB2_STAMP(14); }
-    // ---- relative-position-bias gradient of the workgroup's units: half 1 hands its sums to half 0 through LDS, half 0 stores
-    // the workgroup's [G][169] sums (no atomics: mvlt_swin_wmsa2_bwd_dbias adds the workgroups up in a fixed order)
+    // ---- relative-position-bias gradient of the workgroup's units: the (up to four) parts of an entry -- two row ranges x two halves
+    // -- are added in LDS in a fixed order, then the workgroup stores its [G][169] sums (no atomics: mvlt_swin_wmsa2_bwd_dbias adds
+    // the workgroups up in a fixed order too)
     if (p.dbias_ws) {
-        const int half = tid0 >> 8, ht = tid0 & 255;
         float* sh = reinterpret_cast<float*>(regA);
         __syncthreads();
-        if (half == 1 && ht < 169) {
+        for (int i = tid0; i < G * 176; i += 512) sh[i] = 0.f;
+        const int rank = (tid0 >> 8) * 2 + (db_w & 1);          // (an entry has at most one contributor per rank)
 #pragma unroll
-            for (int i = 0; i < G; ++i) sh[i * 176 + ht] = dbsum[i];
+        for (int r = 0; r < 4; ++r) {
+            __syncthreads();
+            if (rank == r && db_act) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) sh[i * 176 + db_e] += dbsum[i];
+            }
         }
         __syncthreads();
-        if (half == 0 && ht < 169) {
+        if (tid0 < 169) {
 #pragma unroll
-            for (int i = 0; i < G; ++i) p.dbias_ws[(long)bid * (G * 169) + i * 169 + ht] = dbsum[i] + sh[i * 176 + ht];
+            for (int i = 0; i < G; ++i) p.dbias_ws[(long)bid * (G * 169) + i * 169 + tid0] = sh[i * 176 + tid0];
         }
     }
     { const int unit = bid; WB2_STAMP(15); }
