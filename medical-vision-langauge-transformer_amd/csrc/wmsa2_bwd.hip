@@ -313,7 +313,9 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
                 bf16x4 r; r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
                 if (valid) *reinterpret_cast<bf16x4*>(qtile + xoff<QC>(49 * half + row, tcol >> 3) + (tcol & 7) * 2) = r;
             };
-#pragma unroll
+            // (not unrolled: a workgroup runs this code once or a few times, and every copy of it is 5 KB more to fetch through a cold
+            // instruction cache)
+#pragma unroll 1
             for (int i = 0; i < G; ++i) {
                 const int h = head0 + i;
                 __syncthreads();                               // phase B of the previous problem has read the images (i = 0: the dO tile is complete)
@@ -422,7 +424,8 @@ __global__ __launch_bounds__(512) void wmsa2_bwd_kernel(const Wb2Dev p) {
                             }
                         }
                     }
-                    dbsum[i] += sum;
+#pragma unroll
+                    for (int k = 0; k < G; ++k) dbsum[k] += (k == i) ? sum : 0.f;
                 }
                 WB2_STAMP(5 + 3 * i);                          // phase B done
             }
